@@ -1,0 +1,88 @@
+"""Synthetic inputs of SURVEY.md section 8(d), shared by bench.py and the tests.
+
+All arrays follow the reference's host layout (src/Domain/CDomain.h:26-33, CDomain.cpp:171-180):
+state ``[rows][cols][4] = {Z (free-surface level), Zmax, Qx, Qy}``, row 0 = south;
+``bed[rows][cols]``; ``manning[rows][cols]``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+WALL_BED = 9999.9     # closed-edge bed elevation, src/Domain/Cartesian/CDomainCartesian.cpp:790-796
+
+
+def _walls(state, bed):
+    """Outer ring as imposeBoundaryModification leaves it: bed = 9999.9, Z = 0."""
+    for sl in (np.s_[0, :], np.s_[-1, :], np.s_[:, 0], np.s_[:, -1]):
+        bed[sl] = WALL_BED
+        state[sl] = 0.0
+    return state, bed
+
+
+def round4(x):
+    """Input rounding of the reference (util.cpp:69-82 via CDomain.cpp:304-395): 4 decimal places."""
+    return np.round(np.asarray(x, dtype=np.float64) * 1e4) / 1e4
+
+
+def s_dam(cols, rows, dtype=np.float64, wet_right=True, manning=0.03):
+    """S-DAM: flat bed, Z = 10 m for x < cols/2 else 1 m (all wet); S-DAM-DRY: right half dry."""
+    state = np.zeros((rows, cols, 4), dtype)
+    bed = np.zeros((rows, cols), dtype)
+    state[:, : cols // 2, 0] = 10.0
+    state[:, cols // 2:, 0] = 1.0 if wet_right else 0.0
+    state[..., 1] = state[..., 0]
+    _walls(state, bed)
+    return state, bed, np.full((rows, cols), manning, dtype)
+
+
+def s_rough(cols, rows, dtype=np.float64, seed=20240917, amplitude=0.5, pool_level=0.35, manning=0.03,
+            walls=True):
+    """S-ROUGH: undulating bed + noise, partially flooded (wet/dry fronts, bed steps), moving water."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    bed = amplitude * np.sin(2 * np.pi * x / 37.0) * np.cos(2 * np.pi * y / 29.0) + rng.uniform(-0.01, 0.01, (rows, cols))
+    bed = round4(bed)
+    level = np.where(x < cols / 2, pool_level + 0.4, pool_level)
+    z = np.maximum(bed, level)
+    state = np.zeros((rows, cols, 4), np.float64)
+    state[..., 0] = round4(z)
+    state[..., 1] = state[..., 0]
+    wet = (state[..., 0] - bed) > 1e-3
+    state[..., 2] = round4(np.where(wet, rng.uniform(-0.2, 0.2, (rows, cols)), 0.0))
+    state[..., 3] = round4(np.where(wet, rng.uniform(-0.2, 0.2, (rows, cols)), 0.0))
+    man = round4(rng.uniform(0.02, 0.05, (rows, cols))) if manning is None else np.full((rows, cols), manning)
+    if walls:
+        _walls(state, bed)
+    return state.astype(dtype), bed.astype(dtype), man.astype(dtype)
+
+
+def s_rain(cols, rows, dx=2.0, dtype=np.float32, seed=7, grid_cells=64, slices=13, interval=300.0):
+    """S-RAIN: initially dry undulating terrain + gridded rainfall stack (mm/h), config C5."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    bed = round4(5.0 * 0.5 * np.sin(2 * np.pi * x / 37.0) * np.cos(2 * np.pi * y / 29.0)) + 10.0
+    state = np.zeros((rows, cols, 4), np.float64)
+    state[..., 0] = bed
+    state[..., 1] = bed
+    _walls(state, bed)
+    resolution = dx * max(cols, rows) / grid_cells
+    grids = rng.uniform(0.0, 120.0, (slices, grid_cells, grid_cells))
+    rain = dict(grids=grids.astype(dtype), resolution=resolution, off_x=0.0, off_y=0.0, interval=interval)
+    return state.astype(dtype), bed.astype(dtype), np.full((rows, cols), 0.03, dtype), rain
+
+
+def newcastle_like(cols=342, rows=195, dtype=np.float64, seed=342195):
+    """Stand-in for config C1's DEM (342x195 @ 2 m; the HFA raster needs GDAL, absent here): an urban-ish
+    terrain (gentle valley + blocky 'buildings'), initially dry, for the uniform rain + drainage case."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    bed = 30.0 + 0.02 * x + 0.015 * np.abs(y - rows / 2) + 0.3 * np.sin(x / 17.0) * np.cos(y / 13.0)
+    for _ in range(40):
+        cx, cy = rng.integers(5, cols - 15), rng.integers(5, rows - 15)
+        w, h = rng.integers(4, 12), rng.integers(4, 12)
+        bed[cy:cy + h, cx:cx + w] += rng.uniform(3.0, 9.0)
+    bed = round4(bed)
+    state = np.zeros((rows, cols, 4), np.float64)
+    state[..., 0] = bed
+    state[..., 1] = bed
+    return state.astype(dtype), bed.astype(dtype), np.full((rows, cols), 0.03, dtype)

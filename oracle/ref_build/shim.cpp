@@ -1,0 +1,215 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle/_ref build) -- not product code.
+ *
+ * Work-item shim + NDRange drivers for the reference's OpenCL C kernels when they are compiled
+ * for the host with `clang -x cl -target x86_64` (recipe: SURVEY.md Appendix B).
+ *
+ * What is here and why:
+ *  1. the OpenCL work-item / math built-ins the compiled kernel text leaves undefined
+ *     (get_global_id ..., sqrt, pow, fmax ...) -- each is the obvious one-liner over libm;
+ *  2. the run-time parameter variables that prelude.cl declares (the reference bakes the same
+ *     values in as #defines, CSchemeGodunov.cpp:666-784);
+ *  3. drivers that walk an NDRange serially (x fastest, then y) and call the kernel once per
+ *     work-item.  The launch geometry of each driver follows the reference's host code, cited
+ *     per function.  No arithmetic of the scheme is restated here.
+ *
+ * Built twice per precision: -DREF_GODUNOV (Godunov program) / -DREF_MUSCL (MUSCL program).
+ */
+#include <cstddef>
+#include <cstdint>
+
+#ifdef REF_FP32
+typedef float real;
+#else
+typedef double real;
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// 1. built-ins (C++ linkage on purpose: the kernel object references the Itanium-mangled names)
+// ---------------------------------------------------------------------------------------------
+static thread_local size_t t_gid[3], t_lid[3], t_grp[3], t_lsz[3] = {1, 1, 1}, t_gsz[3] = {1, 1, 1};
+
+size_t get_global_id(unsigned d)   { return t_gid[d]; }
+size_t get_local_id(unsigned d)    { return t_lid[d]; }
+size_t get_group_id(unsigned d)    { return t_grp[d]; }
+size_t get_local_size(unsigned d)  { return t_lsz[d]; }
+size_t get_global_size(unsigned d) { return t_gsz[d]; }
+void   barrier(unsigned)           {}
+
+long   max(long a, long b)         { return a > b ? a : b; }
+long   min(long a, long b)         { return a < b ? a : b; }
+
+double sqrt(double x)              { return __builtin_sqrt(x); }
+double pow(double x, double y)     { return __builtin_pow(x, y); }
+double pown(double x, int n)       { return __builtin_powi(x, n); }
+double fabs(double x)              { return __builtin_fabs(x); }
+double fmax(double a, double b)    { return __builtin_fmax(a, b); }
+double fmin(double a, double b)    { return __builtin_fmin(a, b); }
+double fmod(double a, double b)    { return __builtin_fmod(a, b); }
+double floor(double x)             { return __builtin_floor(x); }
+double max(double a, double b)     { return __builtin_fmax(a, b); }
+double min(double a, double b)     { return __builtin_fmin(a, b); }
+
+float  sqrt(float x)               { return __builtin_sqrtf(x); }
+float  pow(float x, float y)       { return __builtin_powf(x, y); }
+float  pown(float x, int n)        { return __builtin_powif(x, n); }
+float  fabs(float x)               { return __builtin_fabsf(x); }
+float  fmax(float a, float b)      { return __builtin_fmaxf(a, b); }
+float  fmin(float a, float b)      { return __builtin_fminf(a, b); }
+float  fmod(float a, float b)      { return __builtin_fmodf(a, b); }
+float  floor(float x)              { return __builtin_floorf(x); }
+float  max(float a, float b)       { return __builtin_fmaxf(a, b); }
+float  min(float a, float b)       { return __builtin_fminf(a, b); }
+
+// ---------------------------------------------------------------------------------------------
+// 2. run-time parameters
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+real     REFP_VERY_SMALL = (real)1e-10, REFP_QUITE_SMALL = (real)1e-9, REFP_DELTAX = 1, REFP_DELTAY = 1;
+real     REFP_ENDTIME = (real)1e30, REFP_OUTPUTTIME = (real)1e30, REFP_COURANT = (real)0.5, REFP_FIXED_DT = 0;
+long     REFP_COLS = 0, REFP_ROWS = 0, REFP_CELLCOUNT = 0;
+unsigned REFP_WORKERS = 1;
+
+// ---- the reference kernels (defined in the compiled .clc text) ----
+void tst_Reduce(real* state, const real* bed, real* scratch);
+void tst_Advance_Normal(real* t, real* dt, real* thydro, real* scratch, real* state, real* bed,
+                        real* tsync, real* batchdt, unsigned* ok, unsigned* skipped);
+void tst_UpdateTimestep(real* t, real* dt, real* scratch, real* tsync, real* batchdt);
+void tst_ResetCounters(real* batchdt, unsigned* ok, unsigned* skipped);
+void per_Friction(const real* dt, real* state, real* bed, real* manning, real* time);
+void bdy_Uniform(const void* cfg, const real* series, real* t, real* dt, real* thydro,
+                 real* state, real* bed, real* manning);
+void bdy_Gridded(const void* cfg, const real* series, real* t, real* dt, real* thydro,
+                 real* state, real* bed, real* manning);
+void bdy_Cell(const void* cfg, const uint64_t* relations, const real* series, real* t, real* dt,
+              real* thydro, real* state, real* bed, real* manning);
+#ifdef REF_GODUNOV
+void gts_cacheDisabled(const real* dt, const real* bed, real* src, real* dst, const real* manning);
+#endif
+#ifdef REF_MUSCL
+void mch_1st_cacheNone(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW);
+void mch_2nd_cacheNone(const real* dt, real* state, const real* bed, const real* manning,
+                       real* fN, real* fE, real* fS, real* fW);
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// 3. drivers
+// ---------------------------------------------------------------------------------------------
+int ref_real_bytes(void) { return (int)sizeof(real); }
+
+/* CSchemeGodunov.cpp:666-784 -- the constants every kernel is compiled against.
+ * `workers` = TIMESTEP_WORKERS = reduction GLOBAL size (CSchemeGodunov.cpp:764, quirk Q5). */
+void ref_configure(long cols, long rows, double dx, double very_small, double courant,
+                   double endtime, unsigned workers, double fixed_dt)
+{
+	REFP_COLS = cols; REFP_ROWS = rows; REFP_CELLCOUNT = cols * rows;
+	REFP_DELTAX = (real)dx; REFP_DELTAY = (real)dx;
+	REFP_VERY_SMALL = (real)very_small; REFP_QUITE_SMALL = (real)(very_small * 10);   /* CSchemeGodunov.cpp:522-523 */
+	REFP_COURANT = (real)courant; REFP_ENDTIME = (real)endtime; REFP_OUTPUTTIME = (real)endtime;
+	REFP_WORKERS = workers; REFP_FIXED_DT = (real)fixed_dt;
+}
+
+static inline void set_item_2d(size_t x, size_t y, size_t gx, size_t gy)
+{
+	t_gid[0] = x; t_gid[1] = y; t_gid[2] = 0;
+	t_grp[0] = x; t_grp[1] = y; t_grp[2] = 0;
+	t_lid[0] = t_lid[1] = t_lid[2] = 0;
+	t_lsz[0] = t_lsz[1] = t_lsz[2] = 1;
+	t_gsz[0] = gx; t_gsz[1] = gy; t_gsz[2] = 1;
+}
+
+#ifdef REF_GODUNOV
+/* global size = cols x rows rounded up to the group (CSchemeGodunov.cpp:636-637, :958-965);
+ * work-items beyond the grid return at the bounds guard, so cols x rows is equivalent. */
+void ref_gts(const real* dt, const real* bed, real* src, real* dst, const real* manning)
+{
+	for (long y = 0; y < REFP_ROWS; ++y)
+		for (long x = 0; x < REFP_COLS; ++x) {
+			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
+			gts_cacheDisabled(dt, bed, src, dst, manning);
+		}
+}
+#endif
+
+#ifdef REF_MUSCL
+void ref_mch_1st(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW)
+{
+	for (long y = 0; y < REFP_ROWS; ++y)
+		for (long x = 0; x < REFP_COLS; ++x) {
+			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
+			mch_1st_cacheNone(dt, bed, state, fN, fE, fS, fW);
+		}
+}
+/* In-place corrector: result depends on work-item order (quirk Q6).  Driven row-major, x fastest. */
+void ref_mch_2nd(const real* dt, real* state, const real* bed, const real* manning,
+                 real* fN, real* fE, real* fS, real* fW)
+{
+	for (long y = 0; y < REFP_ROWS; ++y)
+		for (long x = 0; x < REFP_COLS; ++x) {
+			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
+			mch_2nd_cacheNone(dt, state, bed, manning, fN, fE, fS, fW);
+		}
+}
+#endif
+
+/* 1-D, global size = TIMESTEP_WORKERS, group size 1 here (prelude.cl) so group id == global id. */
+void ref_reduce(real* state, const real* bed, real* scratch)
+{
+	for (size_t g = 0; g < (size_t)REFP_WORKERS; ++g) {
+		t_gid[0] = g; t_grp[0] = g; t_lid[0] = 0; t_lsz[0] = 1; t_gsz[0] = REFP_WORKERS;
+		t_gid[1] = t_gid[2] = 0;
+		tst_Reduce(state, bed, scratch);
+	}
+}
+
+void ref_advance(real* t, real* dt, real* thydro, real* scratch, real* state, real* bed,
+                 real* tsync, real* batchdt, unsigned* ok, unsigned* skipped)
+{
+	set_item_2d(0, 0, 1, 1);
+	tst_Advance_Normal(t, dt, thydro, scratch, state, bed, tsync, batchdt, ok, skipped);
+}
+
+void ref_update_timestep(real* t, real* dt, real* scratch, real* tsync, real* batchdt)
+{
+	set_item_2d(0, 0, 1, 1);
+	tst_UpdateTimestep(t, dt, scratch, tsync, batchdt);
+}
+
+/* Global size floor(cols/8)*8 x floor(rows/8)*8 : integer division inside ceil(), applied before
+ * the 8x8 group size is set (CBoundaryUniform.cpp:294-295, CBoundaryGridded.cpp:298-299 -- quirk Q9).
+ * `full_range` != 0 covers the whole grid instead. */
+void ref_bdy_uniform(const void* cfg, const real* series, real* t, real* dt, real* thydro,
+                     real* state, real* bed, real* manning, int full_range)
+{
+	long gx = full_range ? REFP_COLS : (REFP_COLS / 8) * 8;
+	long gy = full_range ? REFP_ROWS : (REFP_ROWS / 8) * 8;
+	for (long y = 0; y < gy; ++y)
+		for (long x = 0; x < gx; ++x) {
+			set_item_2d((size_t)x, (size_t)y, (size_t)gx, (size_t)gy);
+			bdy_Uniform(cfg, series, t, dt, thydro, state, bed, manning);
+		}
+}
+
+void ref_bdy_gridded(const void* cfg, const real* series, real* t, real* dt, real* thydro,
+                     real* state, real* bed, real* manning, int full_range)
+{
+	long gx = full_range ? REFP_COLS : (REFP_COLS / 8) * 8;
+	long gy = full_range ? REFP_ROWS : (REFP_ROWS / 8) * 8;
+	for (long y = 0; y < gy; ++y)
+		for (long x = 0; x < gx; ++x) {
+			set_item_2d((size_t)x, (size_t)y, (size_t)gx, (size_t)gy);
+			bdy_Gridded(cfg, series, t, dt, thydro, state, bed, manning);
+		}
+}
+
+/* 1-D over the relation list (CBoundaryCell.cpp:442-443: global = (n/8+1)*8, group 8; items >= n return). */
+void ref_bdy_cell(const void* cfg, const uint64_t* relations, const real* series, real* t, real* dt,
+                  real* thydro, real* state, real* bed, real* manning, long count)
+{
+	for (long i = 0; i < count; ++i) {
+		set_item_2d((size_t)i, 0, (size_t)count, 1);
+		bdy_Cell(cfg, relations, series, t, dt, thydro, state, bed, manning);
+	}
+}
+
+} // extern "C"
