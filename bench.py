@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""bench.py -- Mcell-steps/s of the Godunov + HLLC fp64 step on the synthetic flat-DEM dam-break (S-DAM).
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+N = 1 : BASELINE.json configs[1], 4096 x 4096, one MI355X.
+N > 1 : one process per GPU (torch.distributed.run), 1-D row strips with per-step ghost-row exchange and an 8-byte
+        MAX all-reduce over RCCL; weak scaling along the configs' ladder 4096^2 -> 8192x4096 -> 8192^2 -> 16384x8192
+        (configs[3] at N = 8), i.e. 16,777,216 cells per GPU at every N.
+
+The timed region starts with all inputs resident in HBM.  `roofline` prices the flux kernel from HIP events recorded
+on the domain's own stream; `cpu_baseline` times the plain-C oracle (oracle/, "port") on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "hipims-ocl_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+BYTES_PER_CELL_STEP = {"f64": 80.0, "f32": 40.0}      # read state+bed+Manning, write state
+
+LADDER = {1: (4096, 4096), 2: (8192, 4096), 4: (8192, 8192), 8: (16384, 8192)}
+
+
+def grid_for(n_gpus, cols, rows):
+    if cols and rows:
+        return cols, rows
+    if n_gpus in LADDER:
+        return LADDER[n_gpus]
+    return 4096, 4096 * n_gpus
+
+
+def cpu_baseline(cols, precision, scheme, budget_s=12.0):
+    """Plain-C oracle (kind "port"), OpenMP over rows on all host cores, on a bounded strip of the same workload."""
+    import oracle
+    from hipims_mi import synthetic as syn
+    cores = os.cpu_count() or 1
+    rows = 512
+    real = np.float64 if precision == "f64" else np.float32
+    st, bed, man = syn.s_dam(cols, rows, dtype=real)
+    sim = oracle.OracleSim(cols, rows, precision=precision, scheme=scheme, threads=cores,
+                           quirks=oracle.QUIRKS_REFERENCE & ~oracle.Q6_MUSCL_SERIAL)
+    sim.upload(st, bed, man)
+    sim.set_target(1e9)
+    sim.run(2)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        sim.run(2)
+        steps += 2
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 400:
+            break
+    return {"value": cols * rows * steps / el / 1e6, "unit": "Mcell-steps/s", "cores": cores, "kind": "port",
+            "sample": f"S-DAM {cols}x{rows} strip, {steps} steps, {el:.1f} s, oracle/swe_oracle.c OpenMP x{cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cols", type=int, default=0)
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--scheme", choices=["godunov", "muscl"], default="godunov")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--math", choices=["fast", "strict"], default="fast")
+    ap.add_argument("--kernel", choices=["auto", "basic"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import hipims_mi as hp
+    from hipims_mi import synthetic as syn
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    cols, rows = grid_for(world, args.cols, args.rows)
+    scheme = hp.SCHEME_GODUNOV if args.scheme == "godunov" else hp.SCHEME_MUSCL_HANCOCK
+    math_mode = hp.MATH_FAST if args.math == "fast" else hp.MATH_STRICT
+    kernel = hp.KERNEL_AUTO if args.kernel == "auto" else hp.KERNEL_BASIC
+    real = np.float64 if args.precision == "f64" else np.float32
+
+    if world == 1:
+        from hipims_mi.strips import SingleRunner as Runner
+        runner = Runner(cols, rows, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
+                        device=local_rank)
+    else:
+        from hipims_mi.strips import StripRunner as Runner
+        runner = Runner(cols, rows, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
+                        device=local_rank, rank=rank, world=world)
+
+    st, bed, man = syn.s_dam(cols, runner.local_rows_total, dtype=real) if world == 1 else runner.make_s_dam(real)
+    runner.upload(st, bed, man)
+    del st, bed, man
+    runner.set_target_time(1e9)
+
+    runner.step(args.warmup)
+    runner.barrier()
+    runner.domain.kernel_timing(max(1, args.steps // 50))
+    t0 = time.perf_counter()
+    runner.step(args.steps)
+    runner.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = runner.max_over_ranks(elapsed)
+    k_ms, k_n = runner.domain.kernel_timing_read()
+    sc = runner.domain.read_scalars()
+
+    if rank == 0:
+        cells = cols * rows
+        value = cells * args.steps / elapsed / 1e6
+        cells_per_launch = cols * runner.local_rows_total
+        bpc = BYTES_PER_CELL_STEP[args.precision]
+        achieved = bpc * cells_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Mcell-steps/sec fp64 Godunov+HLLC, 4096^2 grid, 1/2/4/8 MI355X; % HBM roofline",
+            "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"S-DAM flat-DEM dam-break {cols}x{rows}, {args.scheme}+HLLC, friction fused, "
+                                   f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
+                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}",
+                       "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": runner.flux_kernel_name, "avg_launch_ms": k_ms, "launches_sampled": k_n,
+                         "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": cells_per_launch},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cols, args.precision,
+                                               0 if args.scheme == "godunov" else 1)
+        print(json.dumps(out), flush=True)
+    runner.close()
+
+
+if __name__ == "__main__":
+    main()

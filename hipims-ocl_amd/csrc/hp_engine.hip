@@ -1,0 +1,639 @@
+// hp_engine.hip -- host side of libhipims_mi.so: the C ABI of include/hipims_mi.h over the HIP kernels.
+//
+// Mirrors what the reference's CSchemeGodunov / CSchemeMUSCLHancock do against COCLDevice/COCLBuffer/COCLKernel
+// (buffers: CSchemeGodunov.cpp:789-892; iteration graph: :1617-1666) -- one HIP stream per domain stands in for
+// the reference's per-device command queue, stream order for its explicit queueBarrier() calls.
+#include "../../include/hipims_mi.h"
+#include "hp_kernels.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hp;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+	g_last_error = msg;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+	do {                                                                                               \
+		hipError_t e_ = (expr);                                                                        \
+		if (e_ != hipSuccess)                                                                          \
+			return fail(HP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+	} while (0)
+
+struct Boundary {
+	int      kind;         // 0 uniform, 1 gridded
+	int      definition;
+	void*    data;         // device
+	uint64_t entries, grows, gcols;
+	double   interval, length, resolution, off_x, off_y;
+};
+
+} // namespace
+
+struct hp_domain {
+	hp_domain_desc_t desc;
+	hipStream_t      stream = nullptr;
+	size_t           cells = 0, esize = 0;
+	void*            state[2] = {nullptr, nullptr};   // [0] = primary "Cell states", [1] = "Cell states (alternate)"
+	void*            bed = nullptr;
+	void*            manning = nullptr;
+	void*            scalars = nullptr;               // Scalars<T> on the device
+	void*            cfl_slot = nullptr;              // one T: running max wave speed
+	void*            host_scalars = nullptr;          // pinned mirror
+	int              use_alt = 0;                     // bUseAlternateKernel
+	bool             in_step = false;
+	std::vector<Boundary> bdy;
+	uint64_t         cells_calculated = 0, iterations = 0;
+	hipEvent_t       ev_start = nullptr, ev_stop = nullptr;
+	// flux-kernel timing samples
+	int              timing_stride = 0;
+	uint64_t         timing_counter = 0;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
+	long             own_lo = 0, own_hi = 0;          // rows this rank owns (CFL reduction range)
+};
+
+namespace {
+
+template <typename T> Params<T> make_params(const hp_domain* d)
+{
+	Params<T> p;
+	p.cols = d->desc.cols; p.rows = d->desc.rows;
+	p.row_offset = d->desc.row_offset; p.global_rows = d->desc.global_rows;
+	p.dx = (T)d->desc.dx;
+	p.vs = (T)d->desc.dry_threshold;
+	p.qs = (T)d->desc.dry_threshold * T(10);             // CSchemeGodunov.cpp:57, :523
+	p.courant = (T)d->desc.courant;
+	p.t_end = (T)d->desc.t_end;
+	p.dt_fixed = (T)d->desc.dt_fixed;
+	p.friction = d->desc.friction;
+	p.dynamic_dt = d->desc.dynamic_dt;
+	return p;
+}
+
+inline dim3 grid2d(long cols, long rows, dim3 block)
+{
+	return dim3((unsigned)((cols + block.x - 1) / block.x), (unsigned)((rows + block.y - 1) / block.y));
+}
+
+template <typename T> int apply_boundaries(hp_domain* d, void* target)
+{
+	const Params<T> p = make_params<T>(d);
+	const bool truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
+	const dim3 block(64, 4), grid = grid2d(p.cols, p.rows, block);
+	for (const Boundary& b : d->bdy) {
+		if (b.kind == 0) {
+			UniformBdy<T> u{(const T*)b.data, (uint32_t)b.entries, b.definition, (T)b.interval, (T)b.length};
+			hipLaunchKernelGGL(bdy_uniform<T>, grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars, u,
+			                   (State4<T>*)target, (const T*)d->bed, truncated);
+		} else {
+			GriddedBdy<T> g{(const T*)b.data, b.entries, b.grows, b.gcols, b.definition,
+			                (T)b.resolution, (T)b.off_x, (T)b.off_y, (T)b.interval};
+			hipLaunchKernelGGL(bdy_gridded<T>, grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars, g,
+			                   (State4<T>*)target, truncated);
+		}
+	}
+	HIP_TRY(hipGetLastError());
+	return HP_OK;
+}
+
+template <typename T> int launch_reduce(hp_domain* d, const void* state, long row_lo, long row_hi)
+{
+	const Params<T> p = make_params<T>(d);
+	const size_t n = (size_t)(row_hi - row_lo) * p.cols;
+	unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
+	if (blocks > 2048) blocks = 2048;
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(cfl_reduce<T>, dim3(blocks), dim3(256), 0, d->stream, p, (const State4<T>*)state,
+	                   (const T*)d->bed, row_lo, row_hi, (T*)d->cfl_slot);
+	HIP_TRY(hipGetLastError());
+	return HP_OK;
+}
+
+template <typename T, bool STRICT> int launch_flux(hp_domain* d, const void* src, void* dst)
+{
+	const Params<T> p = make_params<T>(d);
+	if (d->desc.scheme != HP_SCHEME_GODUNOV)
+		return fail(HP_ERR_UNSUPPORTED, "MUSCL-Hancock kernel not built yet");
+	const dim3 block(64, 4), grid = grid2d(p.cols, p.rows, block);
+	hipLaunchKernelGGL((godunov_basic<STRICT, T>), grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars,
+	                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning);
+	HIP_TRY(hipGetLastError());
+	return HP_OK;
+}
+
+// boundaries -> flux -> local CFL maximum   (CSchemeGodunov.cpp:1637-1657)
+template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
+{
+	void* src = d->state[d->use_alt];
+	void* dst = d->state[d->use_alt ^ 1];
+	int rc;
+	if (!d->bdy.empty() && d->desc.scheme == HP_SCHEME_GODUNOV)          // MUSCL never applies them (Q8)
+		if ((rc = apply_boundaries<T>(d, src)) != HP_OK) return rc;
+
+	const bool sample = d->timing_stride > 0 && (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (sample) {
+		HIP_TRY(hipEventCreate(&e0));
+		HIP_TRY(hipEventCreate(&e1));
+		HIP_TRY(hipEventRecord(e0, d->stream));
+	}
+	if ((rc = launch_flux<T, STRICT>(d, src, dst)) != HP_OK) return rc;
+	if (sample) {
+		HIP_TRY(hipEventRecord(e1, d->stream));
+		d->timing_events.emplace_back(e0, e1);
+	}
+
+	if (d->desc.dynamic_dt) {
+		// Q1: the reference's reduction always reads the primary buffer (CSchemeGodunov.cpp:1629/:1634)
+		const void* reduce_buf = (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) ? d->state[0] : dst;
+		if ((rc = launch_reduce<T>(d, reduce_buf, d->own_lo, d->own_hi)) != HP_OK) return rc;
+	}
+	return HP_OK;
+}
+
+template <typename T> int step_end_impl(hp_domain* d)
+{
+	const Params<T> p = make_params<T>(d);
+	hipLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, p, (Scalars<T>*)d->scalars,
+	                   (T*)d->cfl_slot);
+	HIP_TRY(hipGetLastError());
+	d->use_alt ^= 1;                                                      // Threaded_runBatch :1300
+	d->cells_calculated += (uint64_t)d->desc.cols * (uint64_t)d->desc.rows;   // :1299
+	d->iterations += 1;
+	return HP_OK;
+}
+
+int dispatch_begin(hp_domain* d)
+{
+	const bool strict = d->desc.math_mode == HP_MATH_STRICT;
+	if (d->desc.precision == 8) return strict ? step_begin_impl<double, true>(d) : step_begin_impl<double, false>(d);
+	return strict ? step_begin_impl<float, true>(d) : step_begin_impl<float, false>(d);
+}
+
+int dispatch_end(hp_domain* d)
+{
+	return d->desc.precision == 8 ? step_end_impl<double>(d) : step_end_impl<float>(d);
+}
+
+template <typename T> int write_scalars_initial(hp_domain* d)
+{
+	Scalars<T> s;
+	s.t = T(0); s.dt = (T)d->desc.dt_initial; s.t_hydro = T(0); s.t_sync = T(0); s.batch_dt = T(0);
+	s.batch_ok = 0; s.batch_skipped = 0;                                  // CSchemeGodunov.cpp:805-867
+	HIP_TRY(hipMemcpy(d->scalars, &s, sizeof s, hipMemcpyHostToDevice));
+	return HP_OK;
+}
+
+template <typename T> int set_scalar_field(hp_domain* d, size_t offset, double value)
+{
+	T v = (T)value;
+	std::memcpy((char*)d->host_scalars + 256, &v, sizeof v);
+	HIP_TRY(hipMemcpyAsync((char*)d->scalars + offset, (char*)d->host_scalars + 256, sizeof v, hipMemcpyHostToDevice,
+	                       d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return HP_OK;
+}
+
+int check_domain(hp_domain* d)
+{
+	if (!d) return fail(HP_ERR_INVALID, "null domain");
+	hipError_t e = hipSetDevice(d->desc.device);
+	if (e != hipSuccess) return fail(HP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+	return HP_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+int hp_abi_version(void) { return HP_ABI_VERSION; }
+
+const char* hp_last_error(void) { return g_last_error.c_str(); }
+
+int hp_device_count(int* count)
+{
+	if (!count) return fail(HP_ERR_INVALID, "count == NULL");
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		*count = 0;
+		return fail(HP_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+	}
+	*count = n;
+	return HP_OK;
+}
+
+int hp_device_info(int device, hp_device_info_t* info)
+{
+	if (!info) return fail(HP_ERR_INVALID, "info == NULL");
+	int n = 0, rc = hp_device_count(&n);
+	if (rc != HP_OK) return rc;
+	if (device < 0 || device >= n) return fail(HP_ERR_INVALID, "device index out of range");
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	std::memset(info, 0, sizeof *info);
+	std::snprintf(info->name, sizeof info->name, "%s", prop.name);
+	std::snprintf(info->arch, sizeof info->arch, "%s", prop.gcnArchName);
+	info->compute_units = prop.multiProcessorCount;
+	info->clock_mhz = prop.clockRate / 1000;
+	info->global_mem_bytes = prop.totalGlobalMem;
+	info->lds_bytes_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+	info->wavefront = prop.warpSize;
+	info->fp64 = 1;
+	return HP_OK;
+}
+
+void hp_domain_desc_default(hp_domain_desc_t* desc)
+{
+	if (!desc) return;
+	std::memset(desc, 0, sizeof *desc);
+	desc->struct_size = (uint32_t)sizeof *desc;
+	desc->device = 0;
+	desc->dx = 1.0;
+	desc->precision = 8;
+	desc->scheme = HP_SCHEME_GODUNOV;
+	desc->courant = 0.5;                 // CScheme.cpp:48
+	desc->dry_threshold = 1e-10;         // CSchemeGodunov.cpp:56
+	desc->friction = 1;                  // CScheme.cpp:51
+	desc->dynamic_dt = 1;                // CScheme.cpp:50
+	desc->dt_fixed = 0.001;
+	desc->dt_initial = 0.001;            // CScheme.cpp:49
+	desc->t_end = 1e30;
+	desc->quirks = HP_QUIRKS_REFERENCE;
+	desc->math_mode = HP_MATH_FAST;
+	desc->kernel = HP_KERNEL_AUTO;
+}
+
+int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
+{
+	if (!desc || !out) return fail(HP_ERR_INVALID, "null argument");
+	if (desc->struct_size != sizeof(hp_domain_desc_t)) return fail(HP_ERR_INVALID, "hp_domain_desc_t size mismatch");
+	if (desc->cols < 3 || desc->rows < 3) return fail(HP_ERR_INVALID, "grid must be at least 3x3");
+	if (desc->precision != 8 && desc->precision != 4) return fail(HP_ERR_INVALID, "precision must be 8 or 4");
+	if (desc->scheme != HP_SCHEME_GODUNOV && desc->scheme != HP_SCHEME_MUSCL_HANCOCK)
+		return fail(HP_ERR_INVALID, "unknown scheme");
+	if (!(desc->dx > 0)) return fail(HP_ERR_INVALID, "dx must be positive");
+	int n = 0, rc = hp_device_count(&n);
+	if (rc != HP_OK) return rc;
+	if (desc->device < 0 || desc->device >= n) return fail(HP_ERR_INVALID, "device index out of range");
+	HIP_TRY(hipSetDevice(desc->device));
+
+	hp_domain* d = new hp_domain();
+	d->desc = *desc;
+	if (d->desc.global_rows <= 0) { d->desc.global_rows = d->desc.rows; d->desc.row_offset = 0; }
+	if (d->desc.row_offset < 0 || d->desc.row_offset + d->desc.rows > d->desc.global_rows) {
+		delete d;
+		return fail(HP_ERR_INVALID, "strip does not fit the global grid");
+	}
+	const long g = (desc->scheme == HP_SCHEME_MUSCL_HANCOCK) ? 2 : 1;     // ghost rows per side
+	d->own_lo = (d->desc.row_offset > 0) ? g : 0;
+	d->own_hi = d->desc.rows - ((d->desc.row_offset + d->desc.rows < d->desc.global_rows) ? g : 0);
+	d->cells = (size_t)desc->cols * (size_t)desc->rows;
+	d->esize = (size_t)desc->precision;
+
+	auto cleanup = [&](int code) { hp_domain_destroy(d); return code; };
+#define HIP_TRY_C(expr)                                                                                \
+	do {                                                                                               \
+		hipError_t e_ = (expr);                                                                        \
+		if (e_ != hipSuccess)                                                                          \
+			return cleanup(fail(HP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)));       \
+	} while (0)
+	HIP_TRY_C(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+	HIP_TRY_C(hipMalloc(&d->state[0], d->cells * 4 * d->esize));
+	HIP_TRY_C(hipMalloc(&d->state[1], d->cells * 4 * d->esize));
+	HIP_TRY_C(hipMalloc(&d->bed, d->cells * d->esize));
+	HIP_TRY_C(hipMalloc(&d->manning, d->cells * d->esize));
+	HIP_TRY_C(hipMalloc(&d->scalars, 256));
+	HIP_TRY_C(hipMalloc(&d->cfl_slot, 256));
+	HIP_TRY_C(hipHostMalloc(&d->host_scalars, 512, hipHostMallocDefault));
+	HIP_TRY_C(hipMemset(d->state[0], 0, d->cells * 4 * d->esize));
+	HIP_TRY_C(hipMemset(d->state[1], 0, d->cells * 4 * d->esize));
+	HIP_TRY_C(hipMemset(d->bed, 0, d->cells * d->esize));
+	HIP_TRY_C(hipMemset(d->manning, 0, d->cells * d->esize));
+	HIP_TRY_C(hipMemset(d->cfl_slot, 0, 256));
+	HIP_TRY_C(hipMemset(d->scalars, 0, 256));
+	HIP_TRY_C(hipEventCreate(&d->ev_start));
+	HIP_TRY_C(hipEventCreate(&d->ev_stop));
+#undef HIP_TRY_C
+	rc = (d->desc.precision == 8) ? write_scalars_initial<double>(d) : write_scalars_initial<float>(d);
+	if (rc != HP_OK) return cleanup(rc);
+	*out = d;
+	return HP_OK;
+}
+
+int hp_domain_destroy(hp_domain_t* d)
+{
+	if (!d) return HP_OK;
+	hipSetDevice(d->desc.device);
+	if (d->stream) hipStreamSynchronize(d->stream);
+	for (auto& b : d->bdy) hipFree(b.data);
+	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
+	hipFree(d->scalars); hipFree(d->cfl_slot);
+	if (d->host_scalars) hipHostFree(d->host_scalars);
+	if (d->ev_start) hipEventDestroy(d->ev_start);
+	if (d->ev_stop) hipEventDestroy(d->ev_stop);
+	if (d->stream) hipStreamDestroy(d->stream);
+	delete d;
+	return HP_OK;
+}
+
+int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!host) return fail(HP_ERR_INVALID, "host == NULL");
+	if (d->in_step) return fail(HP_ERR_STATE, "upload between hp_step_begin and hp_step_end");
+	switch (which) {
+	case HP_ARRAY_STATE:
+		if (bytes != d->cells * 4 * d->esize) return fail(HP_ERR_INVALID, "state size mismatch");
+		// both ping-pong buffers get the same host array (CSchemeGodunov.cpp:1064-1065)
+		HIP_TRY(hipMemcpyAsync(d->state[0], host, bytes, hipMemcpyHostToDevice, d->stream));
+		HIP_TRY(hipMemcpyAsync(d->state[1], host, bytes, hipMemcpyHostToDevice, d->stream));
+		d->use_alt = 0;                                                   // :1075
+		return HP_OK;
+	case HP_ARRAY_BED:
+		if (bytes != d->cells * d->esize) return fail(HP_ERR_INVALID, "bed size mismatch");
+		HIP_TRY(hipMemcpyAsync(d->bed, host, bytes, hipMemcpyHostToDevice, d->stream));
+		return HP_OK;
+	case HP_ARRAY_MANNING:
+		if (bytes != d->cells * d->esize) return fail(HP_ERR_INVALID, "manning size mismatch");
+		HIP_TRY(hipMemcpyAsync(d->manning, host, bytes, hipMemcpyHostToDevice, d->stream));
+		return HP_OK;
+	}
+	return fail(HP_ERR_INVALID, "unknown array id");
+}
+
+int hp_domain_download(hp_domain_t* d, int which, void* host, int64_t row0, int64_t nrows)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!host) return fail(HP_ERR_INVALID, "host == NULL");
+	if (row0 < 0 || nrows < 0 || row0 + nrows > d->desc.rows) return fail(HP_ERR_INVALID, "row range out of bounds");
+	const size_t per_row = (size_t)d->desc.cols * d->esize * (which == HP_ARRAY_STATE ? 4 : 1);
+	const void* base;
+	switch (which) {
+	case HP_ARRAY_STATE:   base = d->state[d->use_alt]; break;            // getNextCellSourceBuffer (:1705-1715)
+	case HP_ARRAY_BED:     base = d->bed; break;
+	case HP_ARRAY_MANNING: base = d->manning; break;
+	default: return fail(HP_ERR_INVALID, "unknown array id");
+	}
+	HIP_TRY(hipMemcpyAsync(host, (const char*)base + (size_t)row0 * per_row, (size_t)nrows * per_row,
+	                       hipMemcpyDeviceToHost, d->stream));
+	return HP_OK;
+}
+
+int hp_domain_upload_rows(hp_domain_t* d, const void* host, int64_t row0, int64_t nrows)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!host) return fail(HP_ERR_INVALID, "host == NULL");
+	if (row0 < 0 || nrows < 0 || row0 + nrows > d->desc.rows) return fail(HP_ERR_INVALID, "row range out of bounds");
+	const size_t per_row = (size_t)d->desc.cols * d->esize * 4;
+	HIP_TRY(hipMemcpyAsync((char*)d->state[d->use_alt] + (size_t)row0 * per_row, host, (size_t)nrows * per_row,
+	                       hipMemcpyHostToDevice, d->stream));
+	return HP_OK;
+}
+
+int hp_boundary_add_uniform(hp_domain_t* d, int definition, const void* series, uint32_t entries,
+                            double interval, double length)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!series || entries == 0 || !(interval > 0)) return fail(HP_ERR_INVALID, "bad uniform boundary");
+	if (definition != HP_UNIFORM_RAIN_INTENSITY && definition != HP_UNIFORM_LOSS_RATE)
+		return fail(HP_ERR_INVALID, "unknown uniform boundary definition");
+	Boundary b{};
+	b.kind = 0; b.definition = definition; b.entries = entries; b.interval = interval; b.length = length;
+	const size_t bytes = (size_t)entries * 2 * d->esize;
+	HIP_TRY(hipMalloc(&b.data, bytes));
+	HIP_TRY(hipMemcpy(b.data, series, bytes, hipMemcpyHostToDevice));
+	d->bdy.push_back(b);
+	return HP_OK;
+}
+
+int hp_boundary_add_gridded(hp_domain_t* d, int definition, const void* grids, uint64_t entries,
+                            uint64_t grid_rows, uint64_t grid_cols, double resolution,
+                            double offset_x, double offset_y, double interval)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!grids || entries == 0 || grid_rows == 0 || grid_cols == 0 || !(resolution > 0) || !(interval > 0))
+		return fail(HP_ERR_INVALID, "bad gridded boundary");
+	Boundary b{};
+	b.kind = 1; b.definition = definition; b.entries = entries; b.grows = grid_rows; b.gcols = grid_cols;
+	b.resolution = resolution; b.off_x = offset_x; b.off_y = offset_y; b.interval = interval;
+	const size_t bytes = (size_t)entries * grid_rows * grid_cols * d->esize;
+	HIP_TRY(hipMalloc(&b.data, bytes));
+	HIP_TRY(hipMemcpy(b.data, grids, bytes, hipMemcpyHostToDevice));
+	d->bdy.push_back(b);
+	return HP_OK;
+}
+
+int hp_boundary_clear(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	for (auto& b : d->bdy) hipFree(b.data);
+	d->bdy.clear();
+	return HP_OK;
+}
+
+int hp_set_target_time(hp_domain_t* d, double t)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	return d->desc.precision == 8 ? set_scalar_field<double>(d, offsetof(Scalars<double>, t_sync), t)
+	                              : set_scalar_field<float>(d, offsetof(Scalars<float>, t_sync), t);
+}
+
+int hp_force_timestep(hp_domain_t* d, double dt)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	return d->desc.precision == 8 ? set_scalar_field<double>(d, offsetof(Scalars<double>, dt), dt)
+	                              : set_scalar_field<float>(d, offsetof(Scalars<float>, dt), dt);
+}
+
+int hp_reset_counters(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	const size_t off = d->desc.precision == 8 ? offsetof(Scalars<double>, batch_dt) : offsetof(Scalars<float>, batch_dt);
+	const size_t end = d->desc.precision == 8 ? sizeof(Scalars<double>) : sizeof(Scalars<float>);
+	HIP_TRY(hipMemsetAsync((char*)d->scalars + off, 0, end - off, d->stream));
+	return HP_OK;
+}
+
+int hp_update_timestep(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	// tst_Reduce reads the primary buffer (arg wiring CSchemeGodunov.cpp:922, :927), then tst_UpdateTimestep
+	if (d->desc.precision == 8) {
+		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
+		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot);
+	} else {
+		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
+		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot);
+	}
+	HIP_TRY(hipGetLastError());
+	return HP_OK;
+}
+
+int hp_step_begin(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (d->in_step) return fail(HP_ERR_STATE, "hp_step_begin called twice");
+	if ((rc = dispatch_begin(d)) != HP_OK) return rc;
+	d->in_step = true;
+	return HP_OK;
+}
+
+int hp_step_end(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!d->in_step) return fail(HP_ERR_STATE, "hp_step_end without hp_step_begin");
+	d->in_step = false;
+	return dispatch_end(d);
+}
+
+int hp_step_batch(hp_domain_t* d, uint32_t n_iterations)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	for (uint32_t i = 0; i < n_iterations; ++i) {
+		if ((rc = dispatch_begin(d)) != HP_OK) return rc;
+		if ((rc = dispatch_end(d)) != HP_OK) return rc;
+	}
+	return HP_OK;
+}
+
+int hp_read_scalars(hp_domain_t* d, hp_scalars_t* out)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!out) return fail(HP_ERR_INVALID, "out == NULL");
+	HIP_TRY(hipMemcpyAsync(d->host_scalars, d->scalars, 128, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	if (d->desc.precision == 8) {
+		const Scalars<double>* s = (const Scalars<double>*)d->host_scalars;
+		out->time = s->t; out->timestep = s->dt; out->time_hydrological = s->t_hydro; out->time_target = s->t_sync;
+		out->batch_timesteps = s->batch_dt; out->batch_successful = s->batch_ok; out->batch_skipped = s->batch_skipped;
+	} else {
+		const Scalars<float>* s = (const Scalars<float>*)d->host_scalars;
+		out->time = s->t; out->timestep = s->dt; out->time_hydrological = s->t_hydro; out->time_target = s->t_sync;
+		out->batch_timesteps = s->batch_dt; out->batch_successful = s->batch_ok; out->batch_skipped = s->batch_skipped;
+	}
+	out->cells_calculated = d->cells_calculated;
+	out->iterations = d->iterations;
+	return HP_OK;
+}
+
+int hp_sync(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return HP_OK;
+}
+
+int hp_is_busy(hp_domain_t* d, int* busy)
+{
+	if (!d || !busy) return fail(HP_ERR_INVALID, "null argument");
+	hipError_t e = hipStreamQuery(d->stream);
+	if (e == hipSuccess) { *busy = 0; return HP_OK; }
+	if (e == hipErrorNotReady) { *busy = 1; return HP_OK; }
+	return fail(HP_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+}
+
+int hp_device_ptr(hp_domain_t* d, int which, void** ptr)
+{
+	if (!d || !ptr) return fail(HP_ERR_INVALID, "null argument");
+	switch (which) {
+	case HP_PTR_STATE_NEXT_SRC: *ptr = d->state[d->use_alt]; return HP_OK;
+	case HP_PTR_STATE_OTHER:    *ptr = d->state[d->use_alt ^ 1]; return HP_OK;
+	case HP_PTR_BED:            *ptr = d->bed; return HP_OK;
+	case HP_PTR_MANNING:        *ptr = d->manning; return HP_OK;
+	case HP_PTR_CFL_MAX:        *ptr = d->cfl_slot; return HP_OK;
+	case HP_PTR_SCALARS:        *ptr = d->scalars; return HP_OK;
+	}
+	return fail(HP_ERR_INVALID, "unknown pointer id");
+}
+
+int hp_stream(hp_domain_t* d, void** hip_stream)
+{
+	if (!d || !hip_stream) return fail(HP_ERR_INVALID, "null argument");
+	*hip_stream = (void*)d->stream;
+	return HP_OK;
+}
+
+int hp_timer_start(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	HIP_TRY(hipEventRecord(d->ev_start, d->stream));
+	return HP_OK;
+}
+
+int hp_timer_stop(hp_domain_t* d, float* elapsed_ms)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!elapsed_ms) return fail(HP_ERR_INVALID, "elapsed_ms == NULL");
+	HIP_TRY(hipEventRecord(d->ev_stop, d->stream));
+	HIP_TRY(hipEventSynchronize(d->ev_stop));
+	HIP_TRY(hipEventElapsedTime(elapsed_ms, d->ev_start, d->ev_stop));
+	return HP_OK;
+}
+
+int hp_kernel_timing(hp_domain_t* d, int enable_stride)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+	d->timing_events.clear();
+	d->timing_counter = 0;
+	d->timing_stride = enable_stride > 0 ? enable_stride : 0;
+	return HP_OK;
+}
+
+int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!avg_ms || !samples) return fail(HP_ERR_INVALID, "null argument");
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	double total = 0.0;
+	uint32_t n = 0;
+	for (auto& ev : d->timing_events) {
+		float ms = 0.f;
+		HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+		total += ms;
+		++n;
+	}
+	*avg_ms = n ? total / n : 0.0;
+	*samples = n;
+	return HP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,308 @@
+// hp_math.hpp -- device-side arithmetic of the shallow-water step (gfx950, wave64).
+//
+// Written from the numerical specification in SURVEY.md Appendix A; each block cites the reference
+// statement it must agree with (paths relative to the reference's src/).  Unlike the reference, a cell
+// face is solved ONCE and finished twice -- once for the cell on its left/south side and once for the
+// cell on its right/north side -- because everything expensive in the reconstruction + HLLC solve
+// (depths, velocities, celerities, wave speeds: all the divisions and square roots) is independent of
+// which cell is "own"; only the vertical shift (CLSchemeGodunov.clc:85-86, :136-139) differs.
+//
+// The translation unit is compiled with -ffp-contract=off: STRICT code therefore rounds exactly like
+// the oracle; FAST code asks for every fused multiply-add explicitly (fma_()).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hp {
+
+enum : int { AXIS_X = 0, AXIS_Y = 1 };
+
+template <typename T> struct Params {
+	long cols, rows;             // local array size
+	long row_offset, global_rows;
+	T    dx, vs, qs, courant, t_end, dt_fixed;
+	int  friction, dynamic_dt;
+};
+
+// device-resident time-control block ("Time", "Timestep", ... buffers, CSchemeGodunov.cpp:852-872)
+template <typename T> struct Scalars {
+	T        t, dt, t_hydro, t_sync, batch_dt;
+	uint32_t batch_ok, batch_skipped;
+};
+
+template <typename T> struct alignas(sizeof(T) * 4) State4 { T z, zmax, qx, qy; };
+
+template <typename T> __device__ __forceinline__ constexpr T gravity() { return T(9.81); }   // CLUniversalHeader.clh:33
+
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float  fma_(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double sqrt_(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float  sqrt_(float x)  { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float  pow_(float x, float y)   { return powf(x, y); }
+__device__ __forceinline__ double cbrt_(double x) { return cbrt(x); }
+__device__ __forceinline__ float  cbrt_(float x)  { return cbrtf(x); }
+__device__ __forceinline__ double fabs_(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float  fabs_(float x)  { return __builtin_fabsf(x); }
+__device__ __forceinline__ double fmax_(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float  fmax_(float a, float b)   { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fmin_(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float  fmin_(float a, float b)   { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double floor_(double x) { return __builtin_floor(x); }
+__device__ __forceinline__ float  floor_(float x)  { return __builtin_floorf(x); }
+
+// One side of a face as the cell owner prepares it: raw state + the cell-centre velocities of
+// reconstructInterface (CLSchemeGodunov.clc:39-61): u0 = (Z - zb < VERY_SMALL) ? 0 : Qx / (Z - zb).
+template <typename T> struct Side { T eta, zb, qx, qy, u0, v0; };
+
+template <typename T>
+__device__ __forceinline__ Side<T> make_side(T z, T qx, T qy, T zb, T vs)
+{
+	Side<T> s;
+	s.eta = z; s.zb = zb; s.qx = qx; s.qy = qy;
+	const T h0 = z - zb;
+	s.u0 = (h0 < vs ? T(0) : qx / h0);
+	s.v0 = (h0 < vs ? T(0) : qy / h0);
+	return s;
+}
+
+// What a cell needs from one of its four faces: the flux vector (mass, x-momentum, y-momentum), the
+// neighbour-side reconstructed level and bed for the bed-slope source term (CLSchemeGodunov.clc:268-269,
+// :323-325) and whether a stopping condition fired (:107-130).
+template <typename T> struct FaceFlux { T f0, fx, fy, eta_nb, zb_nb; bool stop; };
+
+// Solve the face between cell L (west/south) and cell R (east/north).
+//   forL : the face as cell L sees it (its E or N face; "own" = left,  ucDirection < DOMAIN_DIR_S)
+//   forR : the face as cell R sees it (its W or S face; "own" = right)
+// Reference: reconstructInterface (CLSchemeGodunov.clc:27-159) + riemannSolver (CLSolverHLLC.clc:27-248).
+template <int AXIS, bool STRICT, bool WANT_L, bool WANT_R, typename T>
+__device__ __forceinline__ void face_solve(const Side<T>& L, const Side<T>& R, const T vs,
+                                           FaceFlux<T>& forL, FaceFlux<T>& forR)
+{
+	const T g = gravity<T>();
+	const T half_g = T(0.5) * g;
+
+	// ---- reconstruction (:84-97) ----
+	const T zbm = (L.zb > R.zb ? L.zb : R.zb);
+	const T hL = (L.eta - zbm > T(0) ? (L.eta - zbm) : T(0));
+	const T hR = (R.eta - zbm > T(0) ? (R.eta - zbm) : T(0));
+	const T etaL = hL + zbm, etaR = hR + zbm;
+	const T qxL = hL * L.u0, qyL = hL * L.v0;
+	const T qxR = hR * R.u0, qyR = hR * R.v0;
+	T shL = zbm - L.eta; if (shL < T(0)) shL = T(0);          // shift when the LEFT cell is own (:85-86)
+	T shR = zbm - R.eta; if (shR < T(0)) shR = T(0);          // shift when the RIGHT cell is own
+
+	// ---- stopping conditions (:101-133): first test is direction specific, the other two shared ----
+	{
+		const T vnL = (AXIS == AXIS_X ? L.u0 : L.v0), vnR = (AXIS == AXIS_X ? R.u0 : R.v0);
+		const T qrawL = (AXIS == AXIS_X ? L.qx : L.qy), qrawR = (AXIS == AXIS_X ? R.qx : R.qy);
+		const bool shared = (hR <= vs && vnL < T(0)) || (hL <= vs && vnR > T(0));
+		forL.stop = shared || (hL <= vs && qrawL > T(0));      // N / E case
+		forR.stop = shared || (hR <= vs && qrawR < T(0));      // S / W case
+	}
+
+	// ---- HLLC ----
+	if (hL < vs && hR < vs) {
+		// both sides dry (CLSolverHLLC.clc:45-61): pressure-like term only, left bed on both (Q4)
+		auto finish = [&](const T s, FaceFlux<T>& o, const bool own_left) {
+			const T a = etaL - s, b = etaR - s, zb = zbm - s;
+			const T p = half_g * (((a + b) / 2) * ((a + b) / 2) - zb * (a + b));
+			o.f0 = T(0);
+			o.fx = (AXIS == AXIS_X ? p : T(0));
+			o.fy = (AXIS == AXIS_Y ? p : T(0));
+			o.eta_nb = own_left ? b : a;
+			o.zb_nb = zb;
+		};
+		if (WANT_L) finish(shL, forL, true);
+		if (WANT_R) finish(shR, forR, false);
+		return;
+	}
+
+	// velocities (:87-92).  STRICT: recomputed from the reconstructed discharges as the reference does;
+	// FAST: h*u0/h == u0 up to rounding, so the four divisions are dropped.
+	T uL, vL, uR, vR;
+	if (STRICT) {
+		uL = (hL < vs ? T(0) : qxL / hL); vL = (hL < vs ? T(0) : qyL / hL);
+		uR = (hR < vs ? T(0) : qxR / hR); vR = (hR < vs ? T(0) : qyR / hR);
+	} else {
+		uL = (hL < vs ? T(0) : L.u0); vL = (hL < vs ? T(0) : L.v0);
+		uR = (hR < vs ? T(0) : R.u0); vR = (hR < vs ? T(0) : R.v0);
+	}
+	const T unL = (AXIS == AXIS_X ? uL : vL), unR = (AXIS == AXIS_X ? uR : vR);       // dVel   (:95-98)
+	const T utL = (AXIS == AXIS_X ? vL : uL), utR = (AXIS == AXIS_X ? vR : uR);       // tangential velocity
+	const T qnL = (AXIS == AXIS_X ? qxL : qyL), qnR = (AXIS == AXIS_X ? qxR : qyR);   // dDis   (:99-102)
+	const T qtL = (AXIS == AXIS_X ? qyL : qxL), qtR = (AXIS == AXIS_X ? qyR : qxR);
+	const T aL = sqrt_(g * hL), aR = sqrt_(g * hR);                                   // dA     (:103-106)
+
+	// two-rarefaction star state and wave speeds (:123-142)
+	const T a_avg = (aL + aR) / 2;
+	const T tmp = a_avg + (unL - unR) / 4;
+	const T h_star = STRICT ? (tmp * tmp) / g : (tmp * tmp) * (T(1) / g);
+	const T u_star = (unL + unR) / 2 + aL - aR;
+	const T a_star = sqrt_(g * h_star);
+	T sL, sR;
+	if (hL < vs) sL = unR - 2 * aR;
+	else         sL = (((unL - aL) > (u_star - a_star)) ? (u_star - a_star) : (unL - aL));
+	if (hR < vs) sR = unL + 2 * aL;
+	else         sR = (((unR + aR) < (u_star + a_star)) ? (u_star + a_star) : (unR + aR));
+	const T sM = (sL * hR * (unR - sR) - sR * hL * (unL - sL)) / (hR * (unR - sR) - hL * (unL - sL));
+
+	// region selection (:174-177); NaN wave speeds fall through to "right" exactly as in the reference
+	const bool bLeft = sL >= T(0);
+	const bool bMid1 = sL < T(0) && sR >= T(0) && sM >= T(0);
+	const bool bMid2 = sL < T(0) && sR >= T(0) && !bMid1;
+	const bool bRight = !bLeft && !bMid1 && !bMid2;
+
+	const T inv_ds = STRICT ? T(0) : T(1) / (sR - sL);
+	const T sLsR = sL * sR;
+
+	auto finish = [&](const T s, FaceFlux<T>& o, const bool own_left) {
+		const T a = etaL - s, b = etaR - s, zb = zbm - s;
+		// normal-momentum flux of each side in free-surface form, left bed on both sides (:146-157, Q4)
+		T fnL, fnR;
+		if (STRICT) {
+			fnL = unL * qnL + half_g * (a * a - 2 * zb * a);
+			fnR = unR * qnR + half_g * (b * b - 2 * zb * b);
+		} else {
+			fnL = fma_(unL, qnL, half_g * (a * (a - 2 * zb)));
+			fnR = fma_(unR, qnR, half_g * (b * (b - 2 * zb)));
+		}
+		T f0, fn, ft;
+		if (bLeft)       { f0 = qnL; fn = fnL; ft = unL * qtL; }
+		else if (bRight) { f0 = qnR; fn = fnR; ft = unR * qtR; }
+		else {
+			// HLL middle state (:200-224)
+			T f1m, f2m;
+			if (STRICT) {
+				f1m = (sR * qnL - sL * qnR + sLsR * (b - a)) / (sR - sL);
+				f2m = (sR * fnL - sL * fnR + sLsR * (qnR - qnL)) / (sR - sL);
+			} else {
+				f1m = fma_(sLsR, (b - a), fma_(sR, qnL, -(sL * qnR))) * inv_ds;
+				f2m = fma_(sLsR, (qnR - qnL), fma_(sR, fnL, -(sL * fnR))) * inv_ds;
+			}
+			f0 = f1m; fn = f2m; ft = f1m * (bMid1 ? utL : utR);
+		}
+		o.f0 = f0;
+		o.fx = (AXIS == AXIS_X ? fn : ft);
+		o.fy = (AXIS == AXIS_X ? ft : fn);
+		o.eta_nb = own_left ? b : a;
+		o.zb_nb = zb;
+	};
+	if (WANT_L) finish(shL, forL, true);
+	if (WANT_R) finish(shR, forR, false);
+}
+
+// Point-implicit Manning friction (Schemes/CLFriction.clc:26-72)
+template <bool STRICT, typename T>
+__device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, const T n, const T dt, const T vs)
+{
+	const T g = gravity<T>();
+	const T q = sqrt_(qx * qx + qy * qy);
+	const T h = z - zb;
+	if (h < vs || q < vs) return;
+	if (STRICT) {
+		const T cf  = (g * n * n) / pow_(h, T(T(1.0) / T(3.0)));
+		const T sfx = (-cf / (h * h)) * qx * q;
+		const T sfy = (-cf / (h * h)) * qy * q;
+		const T dx  = T(1.0) + dt * (cf / (h * h)) * (2 * (qx * qx) + (qy * qy)) / q;
+		const T dy  = T(1.0) + dt * (cf / (h * h)) * ((qx * qx) + 2 * (qy * qy)) / q;
+		T fx = sfx / dx, fy = sfy / dy;
+		if (qx >= T(0)) { if (fx < -qx / dt) fx = -qx / dt; } else { if (fx > -qx / dt) fx = -qx / dt; }
+		if (qy >= T(0)) { if (fy < -qy / dt) fy = -qy / dt; } else { if (fy > -qy / dt) fy = -qy / dt; }
+		qx = qx + dt * fx;
+		qy = qy + dt * fy;
+	} else {
+		// k = g n^2 / h^(7/3); S = -k q Q; D = 1 + dt k (2q^2 + p^2)/Q; clamp dt*S/D to [-|q|, |q|]-side
+		const T k    = (g * n * n) / (cbrt_(h) * h * h);
+		const T kq   = k * q, dtk_q = dt * k / q;
+		const T qx2 = qx * qx, qy2 = qy * qy;
+		const T ddx = fma_(dtk_q, fma_(T(2), qx2, qy2), T(1));
+		const T ddy = fma_(dtk_q, fma_(T(2), qy2, qx2), T(1));
+		T dqx = -(dt * kq) * qx / ddx;            // dt * Fx
+		T dqy = -(dt * kq) * qy / ddy;
+		// friction can stop the flow, not reverse it (:52-65): dt*Fx limited to -qx
+		if (qx >= T(0)) { if (dqx < -qx) dqx = -qx; } else { if (dqx > -qx) dqx = -qx; }
+		if (qy >= T(0)) { if (dqy < -qy) dqy = -qy; } else { if (dqy > -qy) dqy = -qy; }
+		qx += dqx;
+		qy += dqy;
+	}
+}
+
+template <typename T>
+__device__ __forceinline__ T small_to_zero(const T v, const T vs)
+{
+	return ((v > T(0) && v < vs) || (v < T(0) && v > -vs)) ? T(0) : v;      // CLSchemeGodunov.clc:340-348
+}
+
+// Godunov cell update from its four finished faces (CLSchemeGodunov.clc:321-383).
+// Returns the new state; `c` holds {Z, Zmax, Qx, Qy} of the cell before the step.
+template <bool STRICT, typename T>
+__device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, const T n, const T dt,
+                                                    const FaceFlux<T>& fN, const FaceFlux<T>& fE,
+                                                    const FaceFlux<T>& fS, const FaceFlux<T>& fW,
+                                                    const T dx, const T vs, const bool with_friction)
+{
+	const T g = gravity<T>();
+	// bed-slope source from the neighbour-side reconstructed values (:323-325)
+	const T sx = -1 * g * ((fE.eta_nb + fW.eta_nb) / 2) * ((fE.zb_nb - fW.zb_nb) / dx);
+	const T sy = -1 * g * ((fN.eta_nb + fS.eta_nb) / 2) * ((fN.zb_nb - fS.zb_nb) / dx);
+
+	T d0 = (fE.f0 - fW.f0) / dx + (fN.f0 - fS.f0) / dx - T(0);      // :328-336
+	T d2 = (fE.fx - fW.fx) / dx + (fN.fx - fS.fx) / dx - sx;
+	T d3 = (fE.fy - fW.fy) / dx + (fN.fy - fS.fy) / dx - sy;
+	d0 = small_to_zero(d0, vs);
+	d2 = small_to_zero(d2, vs);
+	d3 = small_to_zero(d3, vs);
+
+	if (fN.stop || fE.stop || fS.stop || fW.stop) { c.qx = T(0); c.qy = T(0); }   // :351-355
+
+	c.z  = c.z  - dt * d0;                                           // :358-360
+	c.qx = c.qx - dt * d2;
+	c.qy = c.qy - dt * d3;
+
+	if (with_friction) friction<STRICT>(c.qx, c.qy, c.z, zb, n, dt, vs);          // :362-372
+
+	if (c.z > c.zmax && c.zmax > T(-9990.0)) c.zmax = c.z;           // :375-376
+	if (c.z - zb < vs) c.z = zb;                                     // :379-380
+	return c;
+}
+
+// Wave speed of one cell for the CFL reduction (CLDynamicTimestep.clc:185-216)
+template <typename T>
+__device__ __forceinline__ T cfl_speed(const T z, const T zmax, const T qx, const T qy, const T zb, const T qs)
+{
+	const T h = z - zb;
+	if (h > qs && zmax > T(-9999.0)) {
+		T vx = qx / h, vy = qy / h;
+		if (vx < T(0)) vx = -vx;
+		if (vy < T(0)) vy = -vy;
+		const T a = sqrt_(gravity<T>() * h);
+		vx += a; vy += a;
+		return (vx < vy) ? vy : vx;
+	}
+	return T(0);
+}
+
+// ---- order-preserving unsigned image of a non-negative float, for an exact atomic max ----
+__device__ __forceinline__ void atomic_max_nonneg(double* slot, double v)
+{
+	atomicMax(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void atomic_max_nonneg(float* slot, float v)
+{
+	atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(v));
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_max(T v)
+{
+	// `>`-style max: NaN never wins (CLDynamicTimestep.clc:215-216)
+	for (int off = 32; off > 0; off >>= 1) {
+		const T o = __shfl_xor(v, off, 64);
+		v = (o > v) ? o : v;
+	}
+	return v;
+}
+
+} // namespace hp

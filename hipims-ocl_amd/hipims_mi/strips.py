@@ -1,0 +1,235 @@
+"""1-D row-strip decomposition of ONE logical grid over the GPUs of a node (one process per GPU).
+
+Replaces the reference's overlapping-domain links (src/Domain/Links/CDomainLink.cpp:286-382: strips staged through
+host memory, optionally MPI, several iterations between exchanges, forecast/rollback) with the `timestep` sync
+semantic only (src/CModel.cpp:650-694): every iteration
+
+    step_begin  : boundaries + flux kernel + LOCAL max wave speed          (device, domain stream)
+    halo        : `g` ghost rows of the NEW state <-> the two strip neighbours   (RCCL send/recv over xGMI)
+    all-reduce  : MAX of one scalar (the wave speed; replaces MPI_Allreduce(MIN dt), CMPIManager.cpp:852-861)
+    step_end    : tst_Advance_Normal on every rank redundantly -> identical dt everywhere, no host round trip
+
+so a decomposed run is bit-identical to the single-GPU run (max is exact and order independent).
+g = 1 row for Godunov, 2 for MUSCL-Hancock (13-point stencil).
+
+The exchange is written against torch.distributed so that the very same code runs over RCCL ("nccl") on GPUs and
+over "gloo" on CPU tensors in the world_size-2 tests (tests/test_strips_gloo.py, with the oracle as engine).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import (KERNEL_AUTO, MATH_FAST, PTR_CFL_MAX, PTR_STATE_NEXT_SRC, PTR_STATE_OTHER, QUIRKS_REFERENCE,
+               SCHEME_GODUNOV, SCHEME_MUSCL_HANCOCK, Domain)
+from . import synthetic as syn
+
+
+def ghost_rows(scheme) -> int:
+    return 2 if scheme == SCHEME_MUSCL_HANCOCK else 1
+
+
+def partition(global_rows: int, world: int, g: int):
+    """Rows owned by each rank and the rows it stores: [(own_lo, own_hi, local_lo, local_hi)] (global indices)."""
+    parts = []
+    for k in range(world):
+        own_lo, own_hi = (k * global_rows) // world, ((k + 1) * global_rows) // world
+        parts.append((own_lo, own_hi, max(0, own_lo - g), min(global_rows, own_hi + g)))
+    for own_lo, own_hi, _, _ in parts:
+        if own_hi - own_lo < 2 * g + 1:
+            raise ValueError("strip thinner than its halo")
+    return parts
+
+
+class HipEngine:
+    """The HIP domain of one strip + zero-copy torch views of its device buffers."""
+
+    flux_kernel_name = "hp::godunov_*"
+
+    def __init__(self, cols, local_rows, global_rows, row_offset, **kw):
+        import torch
+        self.torch = torch
+        self.domain = Domain(cols, local_rows, global_rows=global_rows, row_offset=row_offset, **kw)
+        self.device = torch.device("cuda", kw.get("device", 0))
+        torch.cuda.set_device(self.device)
+        # run torch's collectives in order with the engine's kernels: make the domain's stream torch's current one
+        self.stream = torch.cuda.ExternalStream(self.domain.stream_ptr(), device=self.device)
+        torch.cuda.set_stream(self.stream)
+        self._views = {}
+
+    def _view(self, which):
+        ptr = self.domain.device_ptr(which)
+        key = (which, ptr)
+        if key not in self._views:
+            self._views[key] = self.torch.as_tensor(self.domain.device_array(which), device=self.device)
+        return self._views[key]
+
+    def step_begin(self):
+        self.domain.step_begin()
+
+    def step_end(self):
+        self.domain.step_end()
+
+    def new_state(self):
+        """Buffer the iteration in flight has just written (valid between step_begin and step_end)."""
+        return self._view(PTR_STATE_OTHER)
+
+    def cfl_slot(self):
+        return self._view(PTR_CFL_MAX)
+
+    def upload(self, st, bed, man):
+        self.domain.upload(st, bed, man)
+
+    def download(self):
+        return self.domain.download()
+
+    def set_target_time(self, t):
+        self.domain.set_target_time(t)
+
+    def scalars(self):
+        s = self.domain.read_scalars()
+        return dict(t=s["time"], dt=s["timestep"], batch_ok=s["batch_successful"], batch_skipped=s["batch_skipped"])
+
+    def sync(self):
+        self.domain.sync()
+
+    def close(self):
+        self.domain.close()
+
+
+class SingleRunner:
+    """N = 1: the plain batch call, no torch involved."""
+
+    def __init__(self, cols, rows, **kw):
+        self.domain = Domain(cols, rows, **kw)
+        self.local_rows_total = rows
+        self.flux_kernel_name = "hp::godunov_*"
+
+    def upload(self, st, bed, man):
+        self.domain.upload(st, bed, man)
+
+    def set_target_time(self, t):
+        self.domain.set_target_time(t)
+
+    def step(self, n):
+        self.domain.step_batch(n)
+
+    def barrier(self):
+        self.domain.sync()
+
+    def max_over_ranks(self, x):
+        return x
+
+    def close(self):
+        self.domain.close()
+
+
+class StripRunner:
+    """One rank of the strip-decomposed run.  `engine_factory(cols, local_rows, global_rows, row_offset)` lets the
+    CPU tests substitute an oracle-backed engine; the default builds the HIP engine."""
+
+    def __init__(self, cols, rows, scheme=SCHEME_GODUNOV, precision="f64", rank=0, world=1, device=0,
+                 engine_factory=None, backend=None, init_process_group=True, **kw):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.cols, self.rows, self.rank, self.world = cols, rows, rank, world
+        self.g = ghost_rows(scheme)
+        self.scheme, self.precision = scheme, precision
+        self.parts = partition(rows, world, self.g)
+        self.own_lo, self.own_hi, self.local_lo, self.local_hi = self.parts[rank]
+        self.local_rows_total = self.local_hi - self.local_lo
+        if engine_factory is None:
+            self.engine = HipEngine(cols, self.local_rows_total, rows, self.local_lo, scheme=scheme,
+                                    precision=precision, device=device, **kw)
+            backend = backend or "nccl"
+        else:
+            self.engine = engine_factory(cols, self.local_rows_total, rows, self.local_lo)
+            backend = backend or "gloo"
+        self.domain = getattr(self.engine, "domain", None)
+        self.flux_kernel_name = getattr(self.engine, "flux_kernel_name", "")
+        if init_process_group and not dist.is_initialized():
+            kwargs = {}
+            if backend == "nccl":
+                kwargs["device_id"] = torch.device("cuda", device)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        self.south = rank - 1 if rank > 0 else None
+        self.north = rank + 1 if rank < world - 1 else None
+
+    # ---- data placement ----
+    def local_slice(self):
+        return slice(self.local_lo, self.local_hi)
+
+    def make_s_dam(self, real):
+        """This rank's rows of the global S-DAM input (built strip by strip: a 16384 x 8192 fp64 state is 4 GiB)."""
+        st, bed, man = syn.s_dam(self.cols, self.local_rows_total, dtype=real)
+        # s_dam walls all four edges of what it builds; only the global south/north rows are walls
+        z_col = st[1, :, 0].copy() if self.local_rows_total > 2 else None
+        if self.local_lo > 0:
+            st[0, :, 0] = z_col; st[0, :, 1] = z_col; bed[0, :] = 0.0
+            st[0, 0, :] = 0; st[0, -1, :] = 0; bed[0, 0] = bed[0, -1] = syn.WALL_BED
+        if self.local_hi < self.rows:
+            st[-1, :, 0] = z_col; st[-1, :, 1] = z_col; bed[-1, :] = 0.0
+            st[-1, 0, :] = 0; st[-1, -1, :] = 0; bed[-1, 0] = bed[-1, -1] = syn.WALL_BED
+        return st, bed, man
+
+    def upload(self, st_local, bed_local, man_local):
+        self.engine.upload(st_local, bed_local, man_local)
+
+    def upload_global(self, st, bed, man):
+        sl = self.local_slice()
+        self.engine.upload(st[sl], bed[sl], man[sl])
+
+    def set_target_time(self, t):
+        self.engine.set_target_time(t)
+
+    # ---- the per-iteration protocol ----
+    def _exchange_halo(self):
+        dist, g = self.dist, self.g
+        new = self.engine.new_state()            # [local_rows, cols, 4]
+        n = new.shape[0]
+        ops = []
+        if self.south is not None:
+            ops.append(dist.P2POp(dist.isend, new[g:2 * g], self.south))          # my first owned rows
+            ops.append(dist.P2POp(dist.irecv, new[0:g], self.south))              # into my south ghost rows
+        if self.north is not None:
+            ops.append(dist.P2POp(dist.isend, new[n - 2 * g:n - g], self.north))  # my last owned rows
+            ops.append(dist.P2POp(dist.irecv, new[n - g:n], self.north))          # into my north ghost rows
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def step(self, n):
+        dist = self.dist
+        for _ in range(n):
+            self.engine.step_begin()
+            self._exchange_halo()
+            if self.world > 1:
+                dist.all_reduce(self.engine.cfl_slot(), op=dist.ReduceOp.MAX)
+            self.engine.step_end()
+
+    def barrier(self):
+        self.engine.sync()
+        if self.world > 1:
+            self.dist.barrier()
+        self.engine.sync()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        dev = getattr(self.engine, "device", "cpu")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_owned(self):
+        """All ranks' owned rows assembled on every rank (tests)."""
+        local = self.engine.download()
+        mine = np.ascontiguousarray(local[self.own_lo - self.local_lo:self.own_hi - self.local_lo])
+        out = [None] * self.world
+        self.dist.all_gather_object(out, mine)
+        return np.concatenate(out, axis=0)
+
+    def close(self):
+        self.engine.close()
+        if self.dist.is_initialized():
+            self.dist.destroy_process_group()

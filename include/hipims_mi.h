@@ -1,0 +1,209 @@
+/*
+ * hipims_mi.h -- C ABI of the MI355X-native shallow-water step engine (libhipims_mi.so).
+ *
+ * This is the drop-in boundary for ONE path of HiPIMS-OCL (lukeshope/hipims-ocl): the per-timestep
+ * update that `CSchemeGodunov` / `CSchemeMUSCLHancock` drive through the OpenCL executor classes
+ * (`COCLProgram`, `COCLKernel`, `COCLBuffer`, `COCLDevice`).  The HIP engine owns the kernel graph,
+ * so the reference's generic program/kernel/argument layer collapses into semantic calls; each
+ * entry point below cites the reference interface it replaces (paths relative to the reference's
+ * `src/`).  INTEGRATION.md shows the binding a HiPIMS maintainer would add.
+ *
+ * Conventions
+ *  - plain C, plain pointers and sizes; no C++/torch types cross this boundary;
+ *  - every function returns 0 (HP_OK) or a negative hp_status; hp_last_error() gives the message of
+ *    the calling thread's last failure.  Nothing throws, nothing calls exit() (the reference's
+ *    model::doError levels, main.cpp:631-652, are left to the host);
+ *  - host arrays use the reference's layout unchanged (Domain/CDomain.h:26-33, CDomain.cpp:171-180):
+ *    state = cols*rows x {Z free-surface level, Zmax, Qx, Qy}, row-major, row 0 = south;
+ *    bed / manning = cols*rows scalars.  Element type = double (precision 8) or float (precision 4);
+ *  - transfers and steps are ASYNCHRONOUS on the domain's HIP stream, exactly like the reference's
+ *    non-blocking queueWrite / queueRead / scheduleExecution: host memory passed to upload/download
+ *    must stay alive until hp_sync() (COCLDevice::blockUntilFinished) returns;
+ *  - threading contract = the reference's (Schemes/CSchemeGodunov.cpp:1116-1370): one worker thread
+ *    per domain may call step/read/sync; hp_is_busy may be called from another thread; everything
+ *    else requires the domain to be idle.
+ *  - there is NO CPU fallback: every call fails with HP_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef HIPIMS_MI_H
+#define HIPIMS_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HP_ABI_VERSION 1
+
+typedef enum {
+	HP_OK              =  0,
+	HP_ERR_INVALID     = -1,    /* bad argument / descriptor */
+	HP_ERR_NO_DEVICE   = -2,    /* no usable HIP device (never falls back to the CPU) */
+	HP_ERR_HIP         = -3,    /* a HIP runtime call failed; see hp_last_error() */
+	HP_ERR_UNSUPPORTED = -4,
+	HP_ERR_STATE       = -5     /* call not valid in the domain's current state */
+} hp_status;
+
+/* Schemes: Schemes/CScheme.cpp:141-190 (createFromConfig "Godunov" / "MUSCL-Hancock") */
+enum { HP_SCHEME_GODUNOV = 0, HP_SCHEME_MUSCL_HANCOCK = 1 };
+
+/* which array an upload / download moves: COCLBuffer "Cell states", "Bed elevations",
+ * "Manning coefficients" (Schemes/CSchemeGodunov.cpp:832-845) */
+enum { HP_ARRAY_STATE = 0, HP_ARRAY_BED = 1, HP_ARRAY_MANNING = 2 };
+
+/* Behaviours of the reference a parity run reproduces; each can be switched off.
+ * HP_QUIRKS_REFERENCE is the default and is what the parity tests run. */
+enum {
+	HP_QUIRK_CFL_READS_PRIMARY = 1u << 0,  /* Q1: tst_Reduce always reads the primary state buffer
+	                                          (CSchemeGodunov.cpp:1629/:1634 set a non-existent arg) */
+	HP_QUIRK_BDY_TRUNCATED     = 1u << 1,  /* Q9: boundary kernels cover floor(n/8)*8 cells per axis
+	                                          (Boundaries/CBoundaryUniform.cpp:294-295) */
+	HP_QUIRKS_REFERENCE        = 3u
+};
+
+/* Arithmetic flavour of the device kernels.
+ *  STRICT: the reference's expression order, IEEE division/sqrt, no FMA contraction -- bit-identical to
+ *          the oracle except for pow() in the friction term;
+ *  FAST  : algebraically identical, fewer divisions, explicit FMAs (the reference itself ships with
+ *          -cl-mad-enable, OpenCL/Executors/COCLProgram.cpp:73, so its own results are compiler
+ *          dependent at this level).  Default. */
+enum { HP_MATH_FAST = 0, HP_MATH_STRICT = 1 };
+
+/* Kernel selection (diagnostics): AUTO = the tuned kernel; BASIC = one thread per cell, four face
+ * solves per cell -- the same dataflow as gts_cacheDisabled, kept as an on-device cross-check. */
+enum { HP_KERNEL_AUTO = 0, HP_KERNEL_BASIC = 1 };
+
+typedef struct hp_domain hp_domain_t;
+
+/* ---- device discovery: COCLDevice capability fields (OpenCL/Executors/COCLDevice.h:53-99),
+ *      CExecutorControlOpenCL::createDevices (CExecutorControlOpenCL.cpp:211) ---- */
+typedef struct {
+	char     name[128];          /* clDeviceName */
+	char     arch[32];           /* gcnArchName, e.g. "gfx950" */
+	int32_t  compute_units;      /* clDeviceComputeUnits */
+	int32_t  clock_mhz;          /* clDeviceClockFrequency */
+	uint64_t global_mem_bytes;   /* clDeviceGlobalMemSize */
+	uint64_t lds_bytes_per_cu;   /* clDeviceLocalSize */
+	int32_t  wavefront;          /* 64 on gfx950 */
+	int32_t  fp64;               /* COCLDevice::isDoubleCompatible */
+} hp_device_info_t;
+
+int hp_abi_version(void);
+int hp_device_count(int* count);
+int hp_device_info(int device, hp_device_info_t* info);
+const char* hp_last_error(void);
+
+/* ---- domain: CScheme::prepareAll + the registerConstant set
+ *      (Schemes/CSchemeGodunov.cpp:386-470, :666-784; XML parameters :128-333, CScheme.cpp:46-55) ---- */
+typedef struct {
+	uint32_t struct_size;        /* = sizeof(hp_domain_desc_t) */
+	int32_t  device;             /* <domain deviceNumber=...> (Domain/CDomainManager.cpp:203-220) */
+	int64_t  cols, rows;         /* LOCAL array size (all rows this rank stores, ghosts included) */
+	double   dx;                 /* cell resolution; DOMAIN_DELTAX == DOMAIN_DELTAY */
+	int32_t  precision;          /* 8 (fp64) or 4 (fp32): <simulation floatingPointPrecision> */
+	int32_t  scheme;             /* HP_SCHEME_* */
+	double   courant;            /* courantNumber, default 0.5 */
+	double   dry_threshold;      /* dryThreshold = VERY_SMALL, default 1e-10; QUITE_SMALL = 10x */
+	int32_t  friction;           /* frictionEffects (fused into the flux kernel) */
+	int32_t  dynamic_dt;         /* timestepMode: 1 = CFL, 0 = fixed */
+	double   dt_fixed;           /* TIMESTEP_FIXED */
+	double   dt_initial;         /* timestepInitial, default 0.001 */
+	double   t_end;              /* simulation duration = SCHEME_ENDTIME */
+	uint32_t quirks;             /* HP_QUIRK_* mask */
+	int32_t  math_mode;          /* HP_MATH_* */
+	int32_t  kernel;             /* HP_KERNEL_* */
+	/* 1-D row-strip decomposition (replaces Domain/Links/CDomainLink + MPI).
+	 * A single-GPU domain has global_rows == rows and row_offset == 0. */
+	int64_t  global_rows;        /* rows of the whole logical grid */
+	int64_t  row_offset;         /* global row index of local row 0 */
+} hp_domain_desc_t;
+
+void hp_domain_desc_default(hp_domain_desc_t* desc);   /* reference defaults, CScheme.cpp:46-55 */
+int  hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out);
+int  hp_domain_destroy(hp_domain_t* d);                /* CSchemeGodunov::release1OResources, :993-1048 */
+
+/* COCLBuffer::queueWriteAll (COCLBuffer.h:40): HP_ARRAY_STATE fills BOTH ping-pong buffers, as
+ * prepareSimulation does (CSchemeGodunov.cpp:1064-1065), and resets the ping-pong phase. */
+int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes);
+/* COCLBuffer::queueReadAll / queueReadPartial (COCLBuffer.h:38-43); for HP_ARRAY_STATE reads the buffer
+ * the NEXT iteration would use as its source (CSchemeGodunov::getNextCellSourceBuffer, :1705-1715,
+ * which is what readDomainAll / saveCurrentState / CDomainLink::pullFromBuffer read). */
+int hp_domain_download(hp_domain_t* d, int which, void* host, int64_t row0, int64_t nrows);
+/* COCLBuffer::queueWritePartial into the next source buffer (CDomainLink::pushToBuffer, CDomainLink.cpp:252-270) */
+int hp_domain_upload_rows(hp_domain_t* d, const void* host, int64_t row0, int64_t nrows);
+
+/* ---- boundaries: CBoundaryUniform / CBoundaryGridded::prepareBoundary
+ *      (Boundaries/CBoundaryUniform.cpp:180-296, CBoundaryGridded.cpp:166-300); the arrays are the packed
+ *      buffers those functions build.  Applied in the order added (the reference's order is unspecified, Q7) */
+enum { HP_UNIFORM_RAIN_INTENSITY = 0, HP_UNIFORM_LOSS_RATE = 1 };           /* Boundaries/CLBoundaries.clh:44-45 */
+enum { HP_GRIDDED_RAIN_INTENSITY = 0, HP_GRIDDED_RAIN_ACCUMUL = 1, HP_GRIDDED_MASS_FLUX = 2 };   /* :47-50 */
+/* series: `entries` x {time, value} pairs (value in mm/h), element type = domain precision */
+int hp_boundary_add_uniform(hp_domain_t* d, int definition, const void* series, uint32_t entries,
+                            double interval, double length);
+/* grids: [entries][grid_rows][grid_cols] rates (mm/h), element type = domain precision */
+int hp_boundary_add_gridded(hp_domain_t* d, int definition, const void* grids, uint64_t entries,
+                            uint64_t grid_rows, uint64_t grid_cols, double resolution,
+                            double offset_x, double offset_y, double interval);
+int hp_boundary_clear(hp_domain_t* d);
+
+/* ---- time control ---- */
+int hp_set_target_time(hp_domain_t* d, double t);     /* CScheme::setTargetTime -> "Target time (sync)" buffer (:1166-1176) */
+int hp_force_timestep(hp_domain_t* d, double dt);     /* CSchemeGodunov::forceTimestep (:1803-1811) + write (:1213-1232) */
+int hp_reset_counters(hp_domain_t* d);                /* tst_ResetCounters (CLDynamicTimestep.clc:151-161) */
+int hp_update_timestep(hp_domain_t* d);               /* tst_Reduce + tst_UpdateTimestep (:1189-1195, :1254-1260) */
+
+/* ---- the hot loop: `n` x CScheme*::scheduleIteration (CSchemeGodunov.cpp:1617-1666,
+ *      CSchemeMUSCLHancock.cpp:646-680), enqueued without blocking ---- */
+int hp_step_batch(hp_domain_t* d, uint32_t n_iterations);
+
+typedef struct {
+	double   time;               /* "Time" buffer */
+	double   timestep;           /* "Timestep" buffer; negative = suspended at the sync point */
+	double   time_hydrological;
+	double   time_target;
+	double   batch_timesteps;    /* "Batch timesteps cumulative" */
+	uint32_t batch_successful;   /* "Batch successful iterations" */
+	uint32_t batch_skipped;      /* "Batch skipped iterations" */
+	uint64_t cells_calculated;   /* ulCurrentCellsCalculated: cols*rows per queued iteration (:1299) */
+	uint64_t iterations;
+} hp_scalars_t;
+
+/* CSchemeGodunov::readKeyStatistics (:1817-1835) after the five queueReadAll calls (:1309-1313); BLOCKS */
+int hp_read_scalars(hp_domain_t* d, hp_scalars_t* out);
+int hp_sync(hp_domain_t* d);                          /* COCLDevice::blockUntilFinished */
+int hp_is_busy(hp_domain_t* d, int* busy);            /* COCLDevice::isBusy */
+
+/* ---- multi-GPU strips (one process per GPU).  The engine never talks to other ranks itself: the host
+ *      moves ghost rows and the wave-speed maximum with its collective library (RCCL through
+ *      torch.distributed in this repo) on the domain's stream, between these calls.  Replaces
+ *      CDomainLink::pullFromBuffer/pushToBuffer + CMPIManager (MPI/CMPIManager.cpp:555-709, :852-861). ---- */
+/* Split form of one iteration: boundaries + flux kernel (+ local CFL maximum) ... */
+int hp_step_begin(hp_domain_t* d);
+/* ... then, after the host has all-reduced (MAX) the 8-byte value at hp_device_ptr(HP_PTR_CFL_MAX),
+ * the time advance (tst_Advance_Normal) and the ping-pong flip. */
+int hp_step_end(hp_domain_t* d);
+
+enum {
+	HP_PTR_STATE_NEXT_SRC = 0,   /* state buffer the next iteration reads (ghost rows are written here) */
+	HP_PTR_STATE_OTHER    = 1,
+	HP_PTR_BED            = 2,
+	HP_PTR_MANNING        = 3,
+	HP_PTR_CFL_MAX        = 4,   /* one element of the domain precision: local max wave speed */
+	HP_PTR_SCALARS        = 5
+};
+int hp_device_ptr(hp_domain_t* d, int which, void** ptr);
+int hp_stream(hp_domain_t* d, void** hip_stream);     /* the domain's hipStream_t (COCLDevice's command queue) */
+
+/* ---- measurement hooks (no reference counterpart; COCLDevice has no profiling queue, COCLDevice.cpp:283-288) ----
+ * Bracket a region of the domain's stream with HIP events and return the elapsed milliseconds. */
+int hp_timer_start(hp_domain_t* d);
+int hp_timer_stop(hp_domain_t* d, float* elapsed_ms);  /* BLOCKS until the stop event completes */
+/* Average device time of the dominant (flux) kernel: every `stride`-th launch is bracketed with events. */
+int hp_kernel_timing(hp_domain_t* d, int enable_stride);
+int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples);   /* BLOCKS */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPIMS_MI_H */

@@ -56,6 +56,14 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _aligned_zeros(shape, dtype, align=64):
+    """numpy only guarantees 16-byte alignment; the AVX (-mfma) reference build loads double4 with 32-byte moves."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.zeros(n + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
 # =================================================================================================
 #  C restatement
 # =================================================================================================
@@ -349,12 +357,12 @@ class RefSim(_SimBase):
         stem = ("god_" if self.scheme == GODUNOV else "mch_") + self.precision + ("_mad" if mad else "")
         self.lib = _load_ref(stem)
         n = self.rows * self.cols
-        self.primary = np.zeros((self.rows, self.cols, 4), self.real)
-        self.alt = np.zeros_like(self.primary)
+        self.primary = _aligned_zeros((self.rows, self.cols, 4), self.real)
+        self.alt = _aligned_zeros((self.rows, self.cols, 4), self.real)
         self.bed = np.zeros((self.rows, self.cols), self.real)
         self.manning = np.zeros((self.rows, self.cols), self.real)
         if self.scheme == MUSCL:
-            self.faces = [np.zeros((n, 4), self.real) for _ in range(4)]
+            self.faces = [_aligned_zeros((n, 4), self.real) for _ in range(4)]
         z = lambda v=0.0: np.array([v], self.real)
         self.t, self.dt, self.t_hydro, self.t_sync, self.batch_dt = z(), z(self.dt_initial), z(), z(), z()
         self.ok, self.skipped = np.zeros(1, np.uint32), np.zeros(1, np.uint32)

@@ -1,0 +1,30 @@
+"""pytest configuration: markers, import paths, and building the CPU-side checkers."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "hipims-ocl_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C oracle is test infrastructure: build it once per session (2 s with gcc)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"])
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def load_golden(name):
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Runs only where /root/reference exists: the reference's OpenCL C kernel sources are compiled for the
+host (oracle/ref_build -> oracle/_ref/*.so, strict = -ffp-contract=off) and executed on seeded inputs;
+inputs and outputs are stored as .npz.  The fixtures are data only -- no reference source travels.
+
+    python tests/golden/generate.py          # rewrites tests/golden/*.npz
+
+Fixture list follows SURVEY.md section 8(c) (F1..F10).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "hipims-ocl_amd"))
+
+import oracle  # noqa: E402
+from hipims_mi import synthetic as syn  # noqa: E402
+
+VS = 1e-10
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def random_cells(rng, n, real):
+    """Random (state, bed) pairs mixing deep / shallow / dry / stepped-bed cases."""
+    bed = rng.uniform(-1.0, 1.0, n)
+    kind = rng.integers(0, 5, n)
+    depth = np.where(kind == 0, 0.0,                                  # dry
+            np.where(kind == 1, rng.uniform(0, 2e-10, n),             # around VERY_SMALL
+            np.where(kind == 2, rng.uniform(1e-6, 1e-3, n),           # thin film
+                     rng.uniform(0.01, 3.0, n))))                     # ordinary
+    st = np.zeros((n, 4))
+    st[:, 0] = bed + depth
+    st[:, 1] = st[:, 0]
+    vel = rng.uniform(-3.0, 3.0, (n, 2)) * (rng.random((n, 1)) > 0.2)
+    st[:, 2] = depth * vel[:, 0]
+    st[:, 3] = depth * vel[:, 1]
+    # a few dry cells that still carry discharge (exercise the stopping conditions)
+    odd = (kind == 0) & (rng.random(n) < 0.5)
+    st[odd, 2] = rng.uniform(-0.1, 0.1, odd.sum())
+    st[odd, 3] = rng.uniform(-0.1, 0.1, odd.sum())
+    return st.astype(real), bed.astype(real)
+
+
+def function_level(precision, tag):
+    real = np.float64 if precision == "f64" else np.float32
+    ref = oracle.RefFunctions(precision=precision)
+    rng = np.random.default_rng(20240917)
+    n = 384
+    sL, bL = random_cells(rng, n, real)
+    sR, bR = random_cells(rng, n, real)
+    # equal beds on a third of the pairs (the common flat case)
+    same = rng.random(n) < 0.33
+    dz = (sR[:, 0] - bR).copy()
+    bR[same] = bL[same]
+    sR[same, 0] = bR[same] + dz[same]
+    sR[:, 1] = sR[:, 0]
+
+    rec_L = np.zeros((4, n, 8), real); rec_R = np.zeros((4, n, 8), real); rec_stop = np.zeros((4, n), np.int32)
+    flux = np.zeros((4, n, 4), real)
+    for d in range(4):
+        for i in range(n):
+            oL, oR, stop = ref.reconstruct(d, sL[i], bL[i], sR[i], bR[i])
+            rec_L[d, i], rec_R[d, i], rec_stop[d, i] = oL, oR, stop
+            flux[d, i] = ref.hllc(d, oL, oR)
+    save(f"f1_f2_reconstruct_hllc_{tag}", sL=sL, bL=bL, sR=sR, bR=bR, rec_L=rec_L, rec_R=rec_R,
+         rec_stop=rec_stop, flux=flux, very_small=np.array(VS))
+
+    # friction
+    st, bd = random_cells(rng, 768, real)
+    man = rng.uniform(0.01, 0.08, 768).astype(real)
+    dts = (10.0 ** rng.uniform(-4, 0.5, 768)).astype(real)
+    fr = np.array([ref.friction(st[i], bd[i], man[i], dts[i]) for i in range(768)], real)
+    save(f"f3_friction_{tag}", state=st, bed=bd, manning=man, dt=dts, out=fr)
+
+    # limiter
+    a, ba = random_cells(rng, 768, real); b, bb = random_cells(rng, 768, real); c, bc = random_cells(rng, 768, real)
+    dup = rng.random(768) < 0.15          # zero left difference / sign changes
+    b[dup] = a[dup]
+    lim = np.array([ref.limiter(a[i], b[i], c[i], ba[i], bb[i], bc[i]) for i in range(768)], real)
+    save(f"f4_limiter_{tag}", sL=a, sC=b, sR=c, bL=ba, bC=bb, bR=bc, out=lim)
+
+    # MUSCL predictor + 2nd-order reconstruction
+    m = 384
+    sts = np.zeros((m, 5, 4), real); bds = np.zeros((m, 5), real)
+    base, bbase = random_cells(rng, m, real)
+    for k in range(5):
+        pert, bpert = random_cells(rng, m, real)
+        smooth = rng.random(m) < 0.7      # mostly smooth neighbourhoods so slopes are non-trivial
+        bds[:, k] = np.where(smooth, bbase + 0.02 * (k - 2), bpert)
+        depth = np.where(smooth, np.maximum(base[:, 0] - bbase, 0) * (1 + 0.05 * rng.standard_normal(m)), pert[:, 0] - bpert)
+        depth = np.maximum(depth, 0)
+        sts[:, k, 0] = bds[:, k] + depth
+        sts[:, k, 1] = sts[:, k, 0]
+        sts[:, k, 2] = np.where(smooth, base[:, 2] * (1 + 0.1 * rng.standard_normal(m)), pert[:, 2])
+        sts[:, k, 3] = np.where(smooth, base[:, 3] * (1 + 0.1 * rng.standard_normal(m)), pert[:, 3])
+    sts[rng.random(m) < 0.05, 2, 1] = -9999.0           # a disabled neighbour -> first-order fallback
+    dts = (10.0 ** rng.uniform(-3, -1, m)).astype(real)
+    faces = np.zeros((m, 4, 4), real); first = np.zeros(m, np.int32)
+    for i in range(m):
+        faces[i], first[i] = ref.mch_1st(dts[i], sts[i].reshape(-1), bds[i])
+    r2L = np.zeros((4, m, 8), real); r2R = np.zeros((4, m, 8), real); r2stop = np.zeros((4, m), np.int32)
+    perm = rng.permutation(m)
+    for d in range(4):
+        for i in range(m):
+            j = perm[i]
+            # left/right estimates: opposite faces of two predictor outputs (N<->S, E<->W)
+            eL, eR = (faces[i, d], faces[j, (d + 2) % 4]) if d < 2 else (faces[j, (d + 2) % 4], faces[i, d])
+            oL, oR, stop = ref.reconstruct2(d, sts[i, 0], bds[i, 0], sts[j, 0], bds[j, 0], eL, eR)
+            r2L[d, i], r2R[d, i], r2stop[d, i] = oL, oR, stop
+    save(f"f5_muscl_predict_{tag}", states=sts, beds=bds, dt=dts, faces=faces, first=first, perm=perm,
+         r2L=r2L, r2R=r2R, r2stop=r2stop)
+
+
+def trajectories(precision, tag, mad=False):
+    real = np.float64 if precision == "f64" else np.float32
+    out = {}
+    st, bed, man = syn.s_rough(64, 64, dtype=real, manning=None)
+    out.update(rough_state=st, rough_bed=bed, rough_manning=man)
+    for scheme, sname in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch")):
+        for quirks, qname in ((oracle.QUIRKS_REFERENCE, "q"), (oracle.QUIRKS_REFERENCE & ~oracle.Q1_CFL_READS_PRIMARY, "noq1")):
+            if scheme == oracle.MUSCL and qname == "noq1":
+                continue
+            sim = oracle.RefSim(64, 64, scheme=scheme, precision=precision, quirks=quirks, mad=mad)
+            sim.upload(st, bed, man)
+            sim.set_target(1e9)
+            t1 = sim.run(1)
+            s1 = sim.download()
+            t2 = sim.run(199)
+            out[f"{sname}_{qname}_state1"] = s1
+            out[f"{sname}_{qname}_state200"] = sim.download()
+            out[f"{sname}_{qname}_dt"] = np.concatenate([t1, t2])
+            out[f"{sname}_{qname}_t"] = np.array(sim.scalars()["t"])
+    # all-wet dam break with walls (the benchmark's shape, small)
+    st, bed, man = syn.s_dam(96, 48, dtype=real)
+    for scheme, sname in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch")):
+        sim = oracle.RefSim(96, 48, scheme=scheme, precision=precision, mad=mad)
+        sim.upload(st, bed, man)
+        sim.set_target(1e9)
+        out[f"dam_{sname}_dt"] = sim.run(150)
+        out[f"dam_{sname}_state150"] = sim.download()
+    # dam break onto a dry bed
+    st, bed, man = syn.s_dam(96, 48, dtype=real, wet_right=False)
+    sim = oracle.RefSim(96, 48, scheme=oracle.GODUNOV, precision=precision, mad=mad)
+    sim.upload(st, bed, man)
+    sim.set_target(1e9)
+    out["damdry_god_dt"] = sim.run(150)
+    out["damdry_god_state150"] = sim.download()
+    save(f"f6_f7_trajectories_{tag}", **out)
+
+
+def time_control(precision, tag):
+    """F8: tst_Advance_Normal / tst_UpdateTimestep scalar traces driven with prescribed wave speeds."""
+    real = np.float64 if precision == "f64" else np.float32
+    rng = np.random.default_rng(8)
+    sim = oracle.RefSim(8, 8, precision=precision, end_time=20.0, dx=2.0)
+    sim._configure()
+    C = oracle.C
+    P = oracle._ptr
+    rows = []
+    speeds = np.concatenate([[0.0, 0.0], 10 ** rng.uniform(-2, 1.3, 400)]).astype(real)
+    sim.t_sync[0] = 5.0
+    for i, v in enumerate(speeds):
+        sim.scratch[:] = 0
+        sim.scratch[i % sim.WORKERS] = v
+        if i == 150:
+            sim.t_sync[0] = 12.0        # host moves the sync point on (CSchemeGodunov.cpp:1166-1176)
+        if i == 300:
+            sim.t_sync[0] = 1e9
+        sim.lib.ref_advance(P(sim.t), P(sim.dt), P(sim.t_hydro), P(sim.scratch), P(sim.primary), P(sim.bed),
+                            P(sim.t_sync), P(sim.batch_dt), P(sim.ok), P(sim.skipped))
+        rows.append([sim.t[0], sim.dt[0], sim.t_hydro[0], sim.t_sync[0], sim.batch_dt[0], sim.ok[0], sim.skipped[0]])
+    adv = np.array(rows, np.float64)
+    # tst_UpdateTimestep from a set of states
+    upd_in, upd_out = [], []
+    for _ in range(200):
+        t = float(rng.uniform(0, 100)); dt = float(rng.uniform(-0.5, 0.5)); ts = float(t + rng.uniform(-0.1, 2.0))
+        bdt = float(rng.uniform(0, 10)); v = float(10 ** rng.uniform(-2, 1.3))
+        sim.t[0], sim.dt[0], sim.t_sync[0], sim.batch_dt[0] = t, dt, ts, bdt
+        upd_in.append([sim.t[0], sim.dt[0], sim.t_sync[0], sim.batch_dt[0], real(v)])
+        sim.scratch[:] = 0
+        sim.scratch[3] = v
+        sim.lib.ref_update_timestep(P(sim.t), P(sim.dt), P(sim.scratch), P(sim.t_sync), P(sim.batch_dt))
+        upd_out.append([sim.dt[0], sim.batch_dt[0]])
+    save(f"f8_time_control_{tag}", speeds=speeds, advance=adv, update_in=np.array(upd_in, np.float64),
+         update_out=np.array(upd_out, np.float64), dx=np.array(2.0), end_time=np.array(20.0))
+
+
+def rain(precision, tag):
+    """F9: uniform rain + loss and gridded rain on 48x40 (not multiples of 8 -> quirk Q9 visible)."""
+    real = np.float64 if precision == "f64" else np.float32
+    cols, rows = 50, 43
+    st, bed, man = syn.s_rough(cols, rows, dtype=real, pool_level=-10.0, amplitude=0.2, walls=False)   # dry
+    st[..., 2:] = 0
+    series = np.array([[0, 70.0], [3600, 70.0], [7200, 0.0], [10800, 0.0]], real)       # test/newcastle-centre rain CSV shape
+    loss = np.array([[0, 12.0], [10800, 12.0]], real)
+    rng = np.random.default_rng(7)
+    grids = rng.uniform(0, 120, (3, 5, 6)).astype(real)
+    out = dict(state=st, bed=bed, manning=man, series=series, loss=loss, grids=grids)
+    for name, setup in (("uniform", lambda s: (s.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, series, 3600.0, 10800.0),
+                                                 s.add_uniform(oracle.UNIFORM_LOSS_RATE, loss, 10800.0, 10800.0))),
+                        ("gridded", lambda s: s.add_gridded(oracle.GRIDDED_RAIN_INTENSITY, grids, 10.0, 0.0, 0.0, 20.0))):
+        sim = oracle.RefSim(cols, rows, precision=precision, dx=1.0)
+        sim.upload(st, bed, man)
+        setup(sim)
+        sim.set_target(1e9)
+        out[f"{name}_dt"] = sim.run(420)
+        out[f"{name}_state"] = sim.download()
+        out[f"{name}_t"] = np.array(sim.scalars()["t"])
+    save(f"f9_rain_{tag}", **out)
+
+
+def newcastle(precision, tag):
+    """F10: Newcastle-shaped (342x195 @ 2 m) rain + drainage, Godunov fp64 (config C1 stand-in DEM)."""
+    real = np.float64
+    st, bed, man = syn.newcastle_like(dtype=real)
+    series = np.array([[0, 70.0], [3600, 70.0], [7200, 0.0], [10800, 0.0]], real)
+    loss = np.array([[0, 12.0], [10800, 12.0]], real)
+    sim = oracle.RefSim(342, 195, precision=precision, dx=2.0, end_time=7200.0)
+    sim.upload(st, bed, man)
+    sim.add_uniform(oracle.UNIFORM_LOSS_RATE, loss, 10800.0, 10800.0)
+    sim.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, series, 3600.0, 10800.0)
+    sim.set_target(1e9)
+    dt = sim.run(900)
+    final = sim.download()
+    depth = np.maximum(0, final[..., 0] - bed)
+    save(f"f10_newcastle_{tag}", series=series, loss=loss, dt=dt, t=np.array(sim.scalars()["t"]),
+         depth=depth.astype(np.float32), z=final[..., 0], qx=final[..., 2].astype(np.float32),
+         qy=final[..., 3].astype(np.float32))
+
+
+if __name__ == "__main__":
+    oracle.build(ref=True)
+    for precision in ("f64", "f32"):
+        function_level(precision, precision)
+        trajectories(precision, precision)
+        time_control(precision, precision)
+        rain(precision, precision)
+    trajectories("f64", "f64_mad", mad=True)
+    newcastle("f64", "f64")

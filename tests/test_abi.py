@@ -1,0 +1,57 @@
+"""The C-ABI library: loads without a GPU, exports exactly what include/hipims_mi.h declares, and refuses
+to run on the CPU (no compute call is made here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import hipims_mi
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "hipims_mi.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hipims_mi.load_library()
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in hipims_mi.h but not exported"
+    assert sorted(hipims_mi.EXPORTS) == names
+
+
+def test_abi_version_and_defaults():
+    lib = hipims_mi.load_library()
+    assert lib.hp_abi_version() == 1
+    d = hipims_mi.DomainDesc()
+    lib.hp_domain_desc_default(C.byref(d))
+    # reference defaults: CScheme.cpp:46-55, CSchemeGodunov.cpp:56
+    assert d.struct_size == C.sizeof(hipims_mi.DomainDesc)
+    assert (d.courant, d.dt_initial, d.dry_threshold) == (0.5, 0.001, 1e-10)
+    assert d.friction == 1 and d.dynamic_dt == 1 and d.precision == 8
+    assert d.quirks == hipims_mi.QUIRKS_REFERENCE
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(hipims_mi.HipimsError, match="no HIP device|failed"):
+        hipims_mi.Domain(16, 16)
+
+
+def test_descriptor_validation_precedes_device_use():
+    lib = hipims_mi.load_library()
+    d = hipims_mi.DomainDesc()
+    lib.hp_domain_desc_default(C.byref(d))
+    d.struct_size = 4
+    h = C.c_void_p()
+    assert lib.hp_domain_create(C.byref(d), C.byref(h)) == -1
+    assert b"size mismatch" in lib.hp_last_error()

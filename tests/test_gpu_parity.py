@@ -1,0 +1,203 @@
+"""Parity of the HIP engine (through the C ABI) with the oracle and the golden fixtures.  GPU only.
+
+Tolerances (fp64, north_star): depth RMSE < 1e-9 m, max |depth diff| < 1e-7 m, dt relative < 1e-12.
+STRICT arithmetic is additionally required to be bit-identical wherever pow() is not involved.
+fp32: depth RMSE < 1e-4 m.
+"""
+import numpy as np
+import pytest
+
+import hipims_mi as hp
+import oracle
+from conftest import load_golden
+from hipims_mi import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [hp.KERNEL_AUTO, hp.KERNEL_BASIC]
+MODES = [hp.MATH_FAST, hp.MATH_STRICT]
+
+
+def compare(dom, ref, precision="f64", check_t=True):
+    dg, ug, vg = dom.depth_velocity()
+    dr, ur, vr = ref.depth_velocity()
+    rmse = float(np.sqrt(np.mean((dg - dr) ** 2)))
+    mx = float(np.abs(dg - dr).max())
+    if precision == "f64":
+        assert rmse < 1e-9 and mx < 1e-7, (rmse, mx)
+        assert np.abs(ug - ur).max() < 1e-5 and np.abs(vg - vr).max() < 1e-5
+    else:
+        assert rmse < 1e-4, rmse
+    if check_t:
+        sc, sr = dom.read_scalars(), ref.scalars()
+        tol = 1e-12 if precision == "f64" else 1e-4
+        assert abs(sc["time"] - sr["t"]) <= tol * max(1.0, abs(sr["t"])), (sc["time"], sr["t"])
+        assert sc["batch_successful"] == sr["batch_ok"] and sc["batch_skipped"] == sr["batch_skipped"]
+    return rmse, mx
+
+
+def make_pair(cols, rows, st, bed, man, precision="f64", scheme=0, quirks=hp.QUIRKS_REFERENCE, dx=1.0, **kw):
+    oq = (quirks & 3) | (0 if scheme == hp.SCHEME_MUSCL_HANCOCK else oracle.Q6_MUSCL_SERIAL)
+    ref = oracle.OracleSim(cols, rows, scheme=scheme, precision=precision, quirks=oq, dx=dx,
+                           end_time=kw.get("t_end", 1e30))
+    dom = hp.Domain(cols, rows, scheme=scheme, precision=precision, quirks=quirks, dx=dx, **kw)
+    for s in (ref, dom):
+        s.upload(st, bed, man)
+    return dom, ref
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("mode", MODES)
+def test_godunov_rough_bed_200_steps(kernel, mode):
+    st, bed, man = syn.s_rough(64, 64, manning=None)
+    dom, ref = make_pair(64, 64, st, bed, man, kernel=kernel, math_mode=mode)
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    tr_ref = ref.run(200)
+    tr_gpu = dom.run(200)
+    assert np.abs(tr_gpu - tr_ref).max() <= 1e-12 * tr_ref.max()
+    compare(dom, ref)
+    # and against the committed fixture produced by the reference's own kernels
+    g = load_golden("f6_f7_trajectories_f64")
+    depth_g = np.maximum(0, g["god_q_state200"][..., 0] - bed)
+    dg, _, _ = dom.depth_velocity()
+    assert np.sqrt(np.mean((dg - depth_g) ** 2)) < 1e-9
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_strict_mode_is_bit_identical_without_friction(kernel):
+    """With friction off no transcendental is involved: STRICT must reproduce the oracle bit for bit."""
+    st, bed, man = syn.s_rough(72, 40, manning=None)
+    ref = oracle.OracleSim(72, 40, friction=False)
+    dom = hp.Domain(72, 40, friction=False, math_mode=hp.MATH_STRICT, kernel=kernel)
+    for s in (ref, dom):
+        s.upload(st, bed, man)
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    ref.run(120); dom.step_batch(120)
+    assert np.array_equal(dom.download(), ref.download())
+    assert dom.read_scalars()["time"] == ref.scalars()["t"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("wet", [True, False])
+def test_dam_break_fixture(kernel, wet):
+    key = "dam" if wet else "damdry"
+    g = load_golden("f6_f7_trajectories_f64")
+    st, bed, man = syn.s_dam(96, 48, wet_right=wet)
+    dom = hp.Domain(96, 48, kernel=kernel)
+    dom.upload(st, bed, man)
+    dom.set_target_time(1e9)
+    dom.step_batch(150)
+    out = dom.download()
+    dg = np.maximum(0, out[..., 0] - bed)
+    dr = np.maximum(0, g[f"{key}_god_state150"][..., 0] - bed)
+    assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
+    t_ref = float(g[f"{key}_god_dt"].sum())
+    assert abs(dom.read_scalars()["time"] - t_ref) < 1e-10
+
+
+def test_quirk_q1_off_matches_oracle():
+    st, bed, man = syn.s_rough(64, 64, manning=None)
+    q = hp.QUIRKS_REFERENCE & ~hp.QUIRK_CFL_READS_PRIMARY
+    for kernel in KERNELS:
+        dom, ref = make_pair(64, 64, st, bed, man, quirks=q, kernel=kernel)
+        dom.set_target_time(1e9); ref.set_target(1e9)
+        ref.run(100); dom.step_batch(100)
+        compare(dom, ref)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_fp32(kernel):
+    st, bed, man = syn.s_rough(64, 64, dtype=np.float32, manning=None)
+    dom, ref = make_pair(64, 64, st, bed, man, precision="f32", kernel=kernel, math_mode=hp.MATH_STRICT)
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    ref.run(100); dom.step_batch(100)
+    compare(dom, ref, precision="f32")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_sync_point_suspends_and_resumes(kernel):
+    """Target-time clipping: dt = t_sync - t, then negative dt = suspended (skipped iterations copy src->dst)."""
+    st, bed, man = syn.s_dam(64, 32)
+    dom, ref = make_pair(64, 32, st, bed, man, kernel=kernel)
+    dom.set_target_time(0.35); ref.set_target(0.35)
+    ref.run(40); dom.step_batch(40)
+    sc = dom.read_scalars()
+    assert sc["timestep"] < 0 and abs(sc["time"] - 0.35) < 1e-12 and sc["batch_skipped"] > 0
+    compare(dom, ref)
+    dom.set_target_time(0.8); ref.set_target(0.8)
+    dom.force_timestep(abs(sc["timestep"])); ref.force_dt(abs(ref.scalars()["dt"]))
+    dom.reset_counters(); ref.reset_counters()
+    ref.run(60); dom.step_batch(60)
+    compare(dom, ref)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_uniform_rain_and_gridded_rain_fixture(kernel):
+    g = load_golden("f9_rain_f64")
+    rows, cols = g["bed"].shape
+    for name in ("uniform", "gridded"):
+        dom = hp.Domain(cols, rows, kernel=kernel)
+        dom.upload(g["state"], g["bed"], g["manning"])
+        if name == "uniform":
+            dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, g["series"], 3600.0, 10800.0)
+            dom.add_uniform(hp.UNIFORM_LOSS_RATE, g["loss"], 10800.0, 10800.0)
+        else:
+            dom.add_gridded(hp.GRIDDED_RAIN_INTENSITY, g["grids"], 10.0, 0.0, 0.0, 20.0)
+        dom.set_target_time(1e9)
+        dom.step_batch(420)
+        out = dom.download()
+        dg = np.maximum(0, out[..., 0] - g["bed"])
+        dr = np.maximum(0, g[f"{name}_state"][..., 0] - g["bed"])
+        assert dr.max() > 1e-4
+        assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7, name
+        assert abs(dom.read_scalars()["time"] - float(g[f"{name}_t"])) < 1e-9
+
+
+def test_newcastle_shaped_rain_drainage():
+    g = load_golden("f10_newcastle_f64")
+    st, bed, man = syn.newcastle_like()
+    dom = hp.Domain(342, 195, dx=2.0, t_end=7200.0)
+    dom.upload(st, bed, man)
+    dom.add_uniform(hp.UNIFORM_LOSS_RATE, g["loss"], 10800.0, 10800.0)
+    dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, g["series"], 3600.0, 10800.0)
+    dom.set_target_time(1e9)
+    dom.step_batch(900)
+    out = dom.download()
+    dg = np.maximum(0, out[..., 0] - bed)
+    dr = np.maximum(0, g["z"] - bed)
+    assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
+    assert abs(dom.read_scalars()["time"] - float(g["t"])) < 1e-9
+
+
+def test_partial_transfers_and_busy_flag():
+    st, bed, man = syn.s_rough(48, 40, manning=None)
+    dom = hp.Domain(48, 40)
+    dom.upload(st, bed, man)
+    assert np.array_equal(dom.download(), st)
+    assert np.array_equal(dom.download(hp.ARRAY_BED, 3, 5), bed[3:8])
+    patch = st[10:12].copy(); patch[..., 0] += 0.25
+    dom.upload_rows(patch, 10)
+    assert np.array_equal(dom.download(hp.ARRAY_STATE, 10, 2), patch)
+    dom.sync()
+    assert dom.is_busy() is False
+
+
+# ---- BASELINE.json's full size: properties that need no oracle run ----
+def test_full_size_4096_mass_conservation_and_kernel_agreement():
+    n = 4096
+    st, bed, man = syn.s_dam(n, n)
+    d0 = np.maximum(0, st[..., 0] - bed).sum()
+    outs = []
+    for kernel in KERNELS:
+        dom = hp.Domain(n, n, kernel=kernel)
+        dom.upload(st, bed, man)
+        dom.set_target_time(1e9)
+        dom.step_batch(30)
+        out = dom.download()
+        outs.append(out)
+        d1 = np.maximum(0, out[..., 0] - bed).sum()
+        assert abs(d1 - d0) / d0 < 1e-12                       # closed basin: volume conserved
+        assert np.abs(out[:, :, 0] - out[::-1, :, 0]).max() < 1e-11   # north-south mirror symmetry of S-DAM
+        assert dom.read_scalars()["cells_calculated"] == 30 * n * n
+        dom.close()
+    assert np.abs(outs[0] - outs[1]).max() < 1e-9              # tuned kernel == basic kernel

@@ -1,0 +1,198 @@
+"""The C oracle against the golden fixtures produced by the reference's own kernels (tests/golden/generate.py).
+
+Bit-exact for the strict fixtures (both built with -ffp-contract=off); the "as shipped" (-cl-mad-enable)
+fixtures bracket the reference's own compiler-dependent spread.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_golden
+
+PRECISIONS = ["f64", "f32"]
+
+
+def same(a, b):
+    """Bitwise equality up to the sign of zero / NaN payloads."""
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_reconstruct_and_hllc(precision):
+    g = load_golden(f"f1_f2_reconstruct_hllc_{precision}")
+    f = oracle.OracleFunctions(precision, very_small=float(g["very_small"]))
+    n = g["sL"].shape[0]
+    regions = set()
+    for d in range(4):
+        for i in range(n):
+            oL, oR, stop = f.reconstruct(d, g["sL"][i], g["bL"][i], g["sR"][i], g["bR"][i])
+            assert same(oL, g["rec_L"][d, i]) and same(oR, g["rec_R"][d, i]) and stop == g["rec_stop"][d, i], (d, i)
+            F = f.hllc(d, oL, oR)
+            assert same(F, g["flux"][d, i]), (d, i, F, g["flux"][d, i])
+            regions.add((oL[1] < 1e-10, oR[1] < 1e-10))
+    assert len(regions) == 4            # wet-wet, dry-wet, wet-dry and dry-dry all exercised
+    assert (g["rec_stop"] > 0).any()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_friction(precision):
+    g = load_golden(f"f3_friction_{precision}")
+    f = oracle.OracleFunctions(precision)
+    for i in range(g["state"].shape[0]):
+        out = f.friction(g["state"][i], g["bed"][i], g["manning"][i], g["dt"][i])
+        assert same(out, g["out"][i]), i
+    assert (g["out"][:, 2:] != g["state"][:, 2:]).any()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_minmod_limiter(precision):
+    g = load_golden(f"f4_limiter_{precision}")
+    f = oracle.OracleFunctions(precision)
+    for i in range(g["sL"].shape[0]):
+        out = f.limiter(g["sL"][i], g["sC"][i], g["sR"][i], g["bL"][i], g["bC"][i], g["bR"][i])
+        assert same(out, g["out"][i]), i
+    assert (g["out"] != 0).any() and (g["out"] == 0).all(axis=1).any()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_muscl_predictor_and_reconstruct2(precision):
+    g = load_golden(f"f5_muscl_predict_{precision}")
+    f = oracle.OracleFunctions(precision)
+    m = g["states"].shape[0]
+    faces = np.zeros_like(g["faces"])
+    for i in range(m):
+        faces[i], first = f.mch_1st(g["dt"][i], g["states"][i].reshape(-1), g["beds"][i])
+        assert first == g["first"][i]
+    assert same(faces, g["faces"])
+    assert 0 < g["first"].sum() < m
+    perm = g["perm"]
+    for d in range(4):
+        for i in range(m):
+            j = perm[i]
+            eL, eR = (faces[i, d], faces[j, (d + 2) % 4]) if d < 2 else (faces[j, (d + 2) % 4], faces[i, d])
+            oL, oR, stop = f.reconstruct2(d, g["states"][i, 0], g["beds"][i, 0], g["states"][j, 0], g["beds"][j, 0], eL, eR)
+            assert same(oL, g["r2L"][d, i]) and same(oR, g["r2R"][d, i]) and stop == g["r2stop"][d, i], (d, i)
+
+
+def _run(sim, st, bed, man, n):
+    sim.upload(st, bed, man)
+    sim.set_target(1e9)
+    return sim.run(n)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_trajectories_rough_bed(precision):
+    g = load_golden(f"f6_f7_trajectories_{precision}")
+    st, bed, man = g["rough_state"], g["rough_bed"], g["rough_manning"]
+    cases = [(oracle.GODUNOV, "god", "q", oracle.QUIRKS_REFERENCE),
+             (oracle.GODUNOV, "god", "noq1", oracle.QUIRKS_REFERENCE & ~oracle.Q1_CFL_READS_PRIMARY),
+             (oracle.MUSCL, "mch", "q", oracle.QUIRKS_REFERENCE)]
+    for scheme, sname, qname, quirks in cases:
+        sim = oracle.OracleSim(64, 64, scheme=scheme, precision=precision, quirks=quirks)
+        sim.upload(st, bed, man)
+        sim.set_target(1e9)
+        t1 = sim.run(1)
+        assert same(sim.download(), g[f"{sname}_{qname}_state1"])
+        t2 = sim.run(199)
+        assert same(np.concatenate([t1, t2]), g[f"{sname}_{qname}_dt"])
+        assert same(sim.download(), g[f"{sname}_{qname}_state200"])
+        assert sim.scalars()["t"] == g[f"{sname}_{qname}_t"]
+    # quirk Q1 really changes the dt sequence
+    assert not same(g["god_q_dt"], g["god_noq1_dt"])
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_trajectories_dam_break(precision):
+    g = load_golden(f"f6_f7_trajectories_{precision}")
+    from hipims_mi import synthetic as syn
+    real = np.float64 if precision == "f64" else np.float32
+    for wet, key in ((True, "dam"), (False, "damdry")):
+        st, bed, man = syn.s_dam(96, 48, dtype=real, wet_right=wet)
+        for scheme, sname in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch")):
+            if key == "damdry" and sname == "mch":
+                continue
+            sim = oracle.OracleSim(96, 48, scheme=scheme, precision=precision)
+            dt = _run(sim, st, bed, man, 150)
+            assert same(dt, g[f"{key}_{sname}_dt"])
+            assert same(sim.download(), g[f"{key}_{sname}_state150"])
+
+
+def test_mad_bracket():
+    """FMA contraction (what the reference ships with) moves results by rounding only: this is the
+    reference's own spread and sets the scale of the tolerance used for the FAST kernels."""
+    a = load_golden("f6_f7_trajectories_f64")
+    b = load_golden("f6_f7_trajectories_f64_mad")
+    for key in ("dam_god_state150", "dam_mch_state150", "god_q_state200"):
+        diff = np.abs(a[key] - b[key]).max()
+        assert diff < 1e-9, (key, diff)
+    assert np.abs(a["dam_god_dt"] - b["dam_god_dt"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_time_control(precision):
+    g = load_golden(f"f8_time_control_{precision}")
+    sim = oracle.OracleSim(8, 8, precision=precision, end_time=float(g["end_time"]), dx=float(g["dx"]))
+    lib, creal = sim.lib, sim.creal
+    sc = sim.Scalars(t=0, dt=0.001, t_hydro=0, t_sync=5.0, batch_dt=0, batch_ok=0, batch_skipped=0)
+    import ctypes as C
+    saw_negative = False
+    for i, v in enumerate(g["speeds"]):
+        if i == 150:
+            sc.t_sync = 12.0
+        if i == 300:
+            sc.t_sync = 1e9
+        lib.orc_advance(C.byref(sim.p), C.byref(sc), creal(v))
+        row = g["advance"][i]
+        got = [sc.t, sc.dt, sc.t_hydro, sc.t_sync, sc.batch_dt, sc.batch_ok, sc.batch_skipped]
+        assert np.array_equal(np.array(got, np.float64), row), (i, got, row)
+        saw_negative |= sc.dt < 0
+    assert saw_negative                      # the "suspended at sync point" signal was exercised
+    for i in range(g["update_in"].shape[0]):
+        t, dt, ts, bdt, v = g["update_in"][i]
+        sc = sim.Scalars(t=t, dt=dt, t_hydro=0, t_sync=ts, batch_dt=bdt, batch_ok=0, batch_skipped=0)
+        lib.orc_update_timestep(C.byref(sim.p), C.byref(sc), creal(v))
+        assert np.array_equal(np.array([sc.dt, sc.batch_dt], np.float64), g["update_out"][i]), i
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_rain_boundaries(precision):
+    g = load_golden(f"f9_rain_{precision}")
+    cols, rows = g["bed"].shape[1], g["bed"].shape[0]
+    for name in ("uniform", "gridded"):
+        sim = oracle.OracleSim(cols, rows, precision=precision)
+        sim.upload(g["state"], g["bed"], g["manning"])
+        if name == "uniform":
+            sim.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, g["series"], 3600.0, 10800.0)
+            sim.add_uniform(oracle.UNIFORM_LOSS_RATE, g["loss"], 10800.0, 10800.0)
+        else:
+            sim.add_gridded(oracle.GRIDDED_RAIN_INTENSITY, g["grids"], 10.0, 0.0, 0.0, 20.0)
+        sim.set_target(1e9)
+        dt = sim.run(420)
+        assert same(dt, g[f"{name}_dt"])
+        assert same(sim.download(), g[f"{name}_state"])
+        assert sim.scalars()["t"] == g[f"{name}_t"]
+    # quirk Q9 (truncated boundary NDRange) is visible: covering the whole grid changes the answer
+    sim = oracle.OracleSim(cols, rows, precision=precision, quirks=oracle.QUIRKS_REFERENCE & ~oracle.Q9_BDY_TRUNCATED)
+    sim.upload(g["state"], g["bed"], g["manning"])
+    sim.add_gridded(oracle.GRIDDED_RAIN_INTENSITY, g["grids"], 10.0, 0.0, 0.0, 20.0)
+    sim.set_target(1e9)
+    sim.run(420)
+    full = sim.download()
+    assert (full[..., 0] - g["bed"]).sum() > (g["gridded_state"][..., 0] - g["bed"]).sum() > 0
+
+
+def test_newcastle_shape():
+    g = load_golden("f10_newcastle_f64")
+    from hipims_mi import synthetic as syn
+    st, bed, man = syn.newcastle_like()
+    sim = oracle.OracleSim(342, 195, dx=2.0, end_time=7200.0)
+    sim.upload(st, bed, man)
+    sim.add_uniform(oracle.UNIFORM_LOSS_RATE, g["loss"], 10800.0, 10800.0)
+    sim.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, g["series"], 3600.0, 10800.0)
+    sim.set_target(1e9)
+    dt = sim.run(900)
+    assert same(dt, g["dt"])
+    final = sim.download()
+    assert same(final[..., 0], g["z"])
+    assert sim.scalars()["t"] == g["t"]
+    assert g["depth"].max() > 1e-4

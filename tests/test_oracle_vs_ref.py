@@ -1,0 +1,53 @@
+"""The C oracle against the reference's own kernels, live (needs oracle/_ref/*.so, i.e. a container or
+GPU box that received the built objects).  Complements the committed fixtures with fresh seeds."""
+import numpy as np
+import pytest
+
+import oracle
+from hipims_mi import synthetic as syn
+
+pytestmark = pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("scheme", [oracle.GODUNOV, oracle.MUSCL])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_terrain_trajectory(precision, scheme, seed):
+    real = np.float64 if precision == "f64" else np.float32
+    st, bed, man = syn.s_rough(40, 33, dtype=real, seed=seed, manning=None, walls=bool(seed % 2))
+    a = oracle.OracleSim(40, 33, scheme=scheme, precision=precision, dx=1.5)
+    b = oracle.RefSim(40, 33, scheme=scheme, precision=precision, dx=1.5)
+    for s in (a, b):
+        s.upload(st, bed, man)
+        s.set_target(3.0)                 # reach the sync point inside the run -> negative-dt skips
+    ta, tb = a.run(160), b.run(160)
+    assert np.array_equal(ta, tb)
+    assert np.array_equal(a.download(), b.download(), equal_nan=True)
+    sa, sb = a.scalars(), b.scalars()
+    assert sa == {k: (type(sa[k])(v)) for k, v in sb.items()}
+    assert sa["batch_skipped"] > 0
+
+
+def test_threads_do_not_change_results():
+    st, bed, man = syn.s_rough(64, 48, manning=None)
+    outs = []
+    for threads in (1, 4):
+        s = oracle.OracleSim(64, 48, threads=threads)
+        s.upload(st, bed, man)
+        s.set_target(1e9)
+        s.run(50)
+        outs.append(s.download())
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_muscl_snapshot_equals_serial_when_wet():
+    """Quirk Q6 only matters at cells whose neighbours' Zmax crosses VERY_SMALL; an all-wet run is identical."""
+    st, bed, man = syn.s_dam(64, 32)
+    outs = []
+    for quirks in (oracle.QUIRKS_REFERENCE, oracle.QUIRKS_REFERENCE & ~oracle.Q6_MUSCL_SERIAL):
+        s = oracle.OracleSim(64, 32, scheme=oracle.MUSCL, quirks=quirks)
+        s.upload(st, bed, man)
+        s.set_target(1e9)
+        s.run(80)
+        outs.append(s.download())
+    assert np.array_equal(outs[0], outs[1])
