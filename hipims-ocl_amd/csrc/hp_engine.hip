@@ -7,6 +7,7 @@
 #include "hp_kernels.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,7 +49,11 @@ struct hp_domain {
 	void*            bed = nullptr;
 	void*            manning = nullptr;
 	void*            scalars = nullptr;               // Scalars<T> on the device
-	void*            cfl_slot = nullptr;              // one T: running max wave speed
+	void*            cfl_slot = nullptr;              // T[4]: running max | last used max | edge ring of [0] | of [1]
+	bool             need_full_reduce = true;         // the remembered maximum is stale (upload / link import)
+	bool             edge_dirty = true;               // edge-ring maxima must be re-priced
+	int              adv_fresh = 1;                   // does hp_step_end's advance kernel read a new maximum?
+	int              march_rseg = 16;                 // rows per wavefront tile of godunov_march
 	void*            host_scalars = nullptr;          // pinned mirror
 	int              use_alt = 0;                     // bUseAlternateKernel
 	bool             in_step = false;
@@ -119,16 +124,58 @@ template <typename T> int launch_reduce(hp_domain* d, const void* state, long ro
 	return HP_OK;
 }
 
-template <typename T, bool STRICT> int launch_flux(hp_domain* d, const void* src, void* dst)
+template <typename T> int price_edge_ring(hp_domain* d)
+{
+	const Params<T> p = make_params<T>(d);
+	HIP_TRY(hipMemsetAsync((T*)d->cfl_slot + 2, 0, 2 * sizeof(T), d->stream));
+	const long south = (d->desc.row_offset == 0) ? 0 : -1;
+	const long north = (d->desc.row_offset + d->desc.rows == d->desc.global_rows) ? d->desc.rows - 1 : -1;
+	// side columns of the owned rows, minus the rows already covered by south/north
+	const long lo = d->own_lo + (south >= 0 ? 1 : 0), hi = d->own_hi - (north >= 0 ? 1 : 0);
+	for (int b = 0; b < 2; ++b)
+		hipLaunchKernelGGL(cfl_edge_ring<T>, dim3(64), dim3(256), 0, d->stream, p, (const State4<T>*)d->state[b],
+		                   (const T*)d->bed, lo, hi, south, north, (T*)d->cfl_slot + 2 + b);
+	HIP_TRY(hipGetLastError());
+	d->edge_dirty = false;
+	return HP_OK;
+}
+
+template <typename T, bool STRICT, int CFL_MODE>
+int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer)
+{
+	const Params<T> p = make_params<T>(d);
+	const int rseg = d->march_rseg;
+	const int nstrips = (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS);
+	const int groups = (nstrips + 3) / 4;
+	const int nsegs = (int)((p.rows - 2 + rseg - 1) / rseg);
+	const int ntiles = groups * nsegs;
+	const unsigned blocks = (unsigned)((ntiles + 7) / 8) * 8;
+	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, d->stream, p,
+	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + 2 + edge_buffer, rseg, nstrips,
+	                   groups, ntiles);
+	HIP_TRY(hipGetLastError());
+	return HP_OK;
+}
+
+template <typename T, bool STRICT> int launch_flux(hp_domain* d, const void* src, void* dst, int cfl_mode)
 {
 	const Params<T> p = make_params<T>(d);
 	if (d->desc.scheme != HP_SCHEME_GODUNOV)
 		return fail(HP_ERR_UNSUPPORTED, "MUSCL-Hancock kernel not built yet");
-	const dim3 block(64, 4), grid = grid2d(p.cols, p.rows, block);
-	hipLaunchKernelGGL((godunov_basic<STRICT, T>), grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars,
-	                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning);
-	HIP_TRY(hipGetLastError());
-	return HP_OK;
+	if (d->desc.kernel == HP_KERNEL_BASIC) {
+		const dim3 block(64, 4), grid = grid2d(p.cols, p.rows, block);
+		hipLaunchKernelGGL((godunov_basic<STRICT, T>), grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars,
+		                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning);
+		HIP_TRY(hipGetLastError());
+		return HP_OK;
+	}
+	// ring of the buffer that is priced: mode 1 -> dst, mode 2 -> src (= primary)
+	switch (cfl_mode) {
+	case 1:  return launch_march<T, STRICT, 1>(d, src, dst, d->use_alt ^ 1);
+	case 2:  return launch_march<T, STRICT, 2>(d, src, dst, d->use_alt);
+	default: return launch_march<T, STRICT, 0>(d, src, dst, 0);
+	}
 }
 
 // boundaries -> flux -> local CFL maximum   (CSchemeGodunov.cpp:1637-1657)
@@ -137,8 +184,23 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	void* src = d->state[d->use_alt];
 	void* dst = d->state[d->use_alt ^ 1];
 	int rc;
-	if (!d->bdy.empty() && d->desc.scheme == HP_SCHEME_GODUNOV)          // MUSCL never applies them (Q8)
+	const bool has_bdy = !d->bdy.empty() && d->desc.scheme == HP_SCHEME_GODUNOV;   // MUSCL never applies them (Q8)
+	if (has_bdy)
 		if ((rc = apply_boundaries<T>(d, src)) != HP_OK) return rc;
+
+	// Which buffer does the CFL reduction price?  Q1: always the primary one (CSchemeGodunov.cpp:1629/:1634);
+	// otherwise what this iteration writes.
+	const bool q1 = (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0;
+	const bool basic = d->desc.kernel == HP_KERNEL_BASIC;
+	const bool dst_is_primary = d->use_alt == 1;
+	int cfl_mode = 0;                                    // fused epilogue of the tuned kernel
+	if (d->desc.dynamic_dt && !basic) {
+		if (!q1 || dst_is_primary) cfl_mode = 1;         // price what lands in dst
+		else if (has_bdy)          cfl_mode = 2;         // primary = source, changed in place by the boundaries
+		else                       cfl_mode = 0;         // primary untouched: last maximum still holds
+		if (cfl_mode != 0 && d->edge_dirty)
+			if ((rc = price_edge_ring<T>(d)) != HP_OK) return rc;
+	}
 
 	const bool sample = d->timing_stride > 0 && (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -147,16 +209,23 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		HIP_TRY(hipEventCreate(&e1));
 		HIP_TRY(hipEventRecord(e0, d->stream));
 	}
-	if ((rc = launch_flux<T, STRICT>(d, src, dst)) != HP_OK) return rc;
+	if ((rc = launch_flux<T, STRICT>(d, src, dst, cfl_mode)) != HP_OK) return rc;
 	if (sample) {
 		HIP_TRY(hipEventRecord(e1, d->stream));
 		d->timing_events.emplace_back(e0, e1);
 	}
 
+	d->adv_fresh = 0;
 	if (d->desc.dynamic_dt) {
-		// Q1: the reference's reduction always reads the primary buffer (CSchemeGodunov.cpp:1629/:1634)
-		const void* reduce_buf = (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) ? d->state[0] : dst;
-		if ((rc = launch_reduce<T>(d, reduce_buf, d->own_lo, d->own_hi)) != HP_OK) return rc;
+		if (cfl_mode != 0) {
+			d->adv_fresh = 1;
+			d->need_full_reduce = false;
+		} else if (basic || d->need_full_reduce) {
+			const void* reduce_buf = q1 ? d->state[0] : dst;
+			if ((rc = launch_reduce<T>(d, reduce_buf, d->own_lo, d->own_hi)) != HP_OK) return rc;
+			d->adv_fresh = 1;
+			d->need_full_reduce = false;
+		}
 	}
 	return HP_OK;
 }
@@ -165,7 +234,7 @@ template <typename T> int step_end_impl(hp_domain* d)
 {
 	const Params<T> p = make_params<T>(d);
 	hipLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, p, (Scalars<T>*)d->scalars,
-	                   (T*)d->cfl_slot);
+	                   (T*)d->cfl_slot, d->adv_fresh);
 	HIP_TRY(hipGetLastError());
 	d->use_alt ^= 1;                                                      // Threaded_runBatch :1300
 	d->cells_calculated += (uint64_t)d->desc.cols * (uint64_t)d->desc.rows;   // :1299
@@ -301,6 +370,10 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	d->own_hi = d->desc.rows - ((d->desc.row_offset + d->desc.rows < d->desc.global_rows) ? g : 0);
 	d->cells = (size_t)desc->cols * (size_t)desc->rows;
 	d->esize = (size_t)desc->precision;
+	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
+		const int v = std::atoi(e);
+		if (v >= 1 && v <= 4096) d->march_rseg = v;
+	}
 
 	auto cleanup = [&](int code) { hp_domain_destroy(d); return code; };
 #define HIP_TRY_C(expr)                                                                                \
@@ -362,10 +435,14 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 		HIP_TRY(hipMemcpyAsync(d->state[0], host, bytes, hipMemcpyHostToDevice, d->stream));
 		HIP_TRY(hipMemcpyAsync(d->state[1], host, bytes, hipMemcpyHostToDevice, d->stream));
 		d->use_alt = 0;                                                   // :1075
+		d->need_full_reduce = true;
+		d->edge_dirty = true;
 		return HP_OK;
 	case HP_ARRAY_BED:
 		if (bytes != d->cells * d->esize) return fail(HP_ERR_INVALID, "bed size mismatch");
 		HIP_TRY(hipMemcpyAsync(d->bed, host, bytes, hipMemcpyHostToDevice, d->stream));
+		d->need_full_reduce = true;
+		d->edge_dirty = true;
 		return HP_OK;
 	case HP_ARRAY_MANNING:
 		if (bytes != d->cells * d->esize) return fail(HP_ERR_INVALID, "manning size mismatch");
@@ -403,6 +480,8 @@ int hp_domain_upload_rows(hp_domain_t* d, const void* host, int64_t row0, int64_
 	const size_t per_row = (size_t)d->desc.cols * d->esize * 4;
 	HIP_TRY(hipMemcpyAsync((char*)d->state[d->use_alt] + (size_t)row0 * per_row, host, (size_t)nrows * per_row,
 	                       hipMemcpyHostToDevice, d->stream));
+	d->need_full_reduce = true;
+	d->edge_dirty = true;
 	return HP_OK;
 }
 
@@ -486,11 +565,11 @@ int hp_update_timestep(hp_domain_t* d)
 	if (d->desc.precision == 8) {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
 		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
-		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot);
+		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, 1);
 	} else {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
 		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
-		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot);
+		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, 1);
 	}
 	HIP_TRY(hipGetLastError());
 	return HP_OK;

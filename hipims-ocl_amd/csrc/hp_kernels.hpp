@@ -45,13 +45,175 @@ __global__ __launch_bounds__(256) void godunov_basic(const Params<T> p, const Sc
 	const Side<T> sS = make_side(cS.z, cS.qx, cS.qy, zS, p.vs);
 	const Side<T> sW = make_side(cW.z, cW.qx, cW.qy, zW, p.vs);
 
-	FaceFlux<T> fN, fE, fS, fW, unused;
-	face_solve<AXIS_Y, STRICT, true, false>(sC, sN, p.vs, fN, unused);
-	face_solve<AXIS_Y, STRICT, false, true>(sS, sC, p.vs, unused, fS);
-	face_solve<AXIS_X, STRICT, true, false>(sC, sE, p.vs, fE, unused);
-	face_solve<AXIS_X, STRICT, false, true>(sW, sC, p.vs, unused, fW);
+	const FaceFlux<T> fN = face_solve<AXIS_Y, STRICT, true, false>(sC, sN, p.vs).forL;
+	const FaceFlux<T> fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, p.vs).forR;
+	const FaceFlux<T> fE = face_solve<AXIS_X, STRICT, true, false>(sC, sE, p.vs).forL;
+	const FaceFlux<T> fW = face_solve<AXIS_X, STRICT, false, true>(sW, sC, p.vs).forR;
 
 	dst[id] = godunov_update<STRICT>(c, zb, n, dt, fN, fE, fS, fW, p.dx, p.vs, p.friction != 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// K1  godunov_march : the tuned Godunov + HLLC step.
+//
+//  * One wavefront owns a strip of 64 consecutive columns (lane = column, so every row of the strip is one
+//    coalesced 2 KiB state load + 512 B bed + 512 B Manning) and MARCHES north over `rseg` rows.
+//  * Every face is solved once: a lane solves the face to its EAST and the face to its NORTH (face_solve
+//    finishes each for both adjacent cells).  The west-face result arrives from lane-1 through a cross-lane
+//    move, the south-face result is carried in registers from the previous row.  Lanes 0 and 63 are halo lanes
+//    (62 updated columns per wave); the row below the segment costs one extra north-face solve per segment.
+//  * The 4-neighbour stencil therefore never re-reads a cell from memory inside a tile: W/E neighbours come
+//    from the wave's own registers via the LDS crossbar (ds_bpermute / DPP), N/S from the register pipeline.
+//  * CFL_MODE fuses tst_Reduce into the epilogue: 1 = speeds of what this launch leaves in `dst`
+//    (incl. the stale value of all-dry cells the reference does not write, Q3), 2 = speeds of the source
+//    state (after the boundary kernels), 0 = none.  Edge-ring cells are priced once at upload (edge_max).
+//  * blockIdx is remapped so that each XCD (blocks b, b+8, ... share one) works on a contiguous run of tiles
+//    and neighbouring tiles' halo rows/columns hit the same L2.
+// -------------------------------------------------------------------------------------------------
+constexpr int MARCH_COLS = 62;          // updated columns per wavefront (lanes 1..62)
+
+template <typename T> struct RowRegs { State4<T> c; T zb, n; };
+
+template <typename T>
+__device__ __forceinline__ Side<T> shfl_side(const Side<T>& s, const int src_lane)
+{
+	Side<T> r;
+	r.eta = __shfl(s.eta, src_lane, 64); r.zb = __shfl(s.zb, src_lane, 64);
+	r.qx = __shfl(s.qx, src_lane, 64);   r.qy = __shfl(s.qy, src_lane, 64);
+	r.u0 = __shfl(s.u0, src_lane, 64);   r.v0 = __shfl(s.v0, src_lane, 64);
+	return r;
+}
+
+template <bool STRICT, int CFL_MODE, typename T>
+__global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* __restrict__ sc,
+                                                     const T* __restrict__ bed, const State4<T>* __restrict__ src,
+                                                     State4<T>* __restrict__ dst, const T* __restrict__ manning,
+                                                     T* __restrict__ cfl_slot, const T* __restrict__ edge_max,
+                                                     const int rseg, const int nstrips, const int groups,
+                                                     const int ntiles)
+{
+	// XCD-aware tile order (grid is a multiple of 8 blocks)
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	if (tile >= (unsigned)ntiles) return;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const long strip = (long)(tile % (unsigned)groups) * 4 + wave;
+	const long seg = tile / (unsigned)groups;
+	if (strip >= nstrips) return;                                                  // wave-uniform
+
+	const long x = strip * MARCH_COLS + lane;
+	const long y0 = 1 + seg * rseg;
+	const long y1 = (y0 + rseg < p.rows - 1) ? (y0 + rseg) : (p.rows - 1);         // rows [y0, y1) are updated
+	const long xc = (x < p.cols) ? x : (p.cols - 1);                               // clamp halo lanes past the grid
+	const bool out_x = lane >= 1 && lane <= MARCH_COLS && x <= p.cols - 2;         // x >= 1 is implied
+	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
+
+	const T dt = sc->dt, vs = p.vs;
+	const bool skip_step = dt <= T(0);                                             // CLSchemeGodunov.clc:201-206
+	const bool with_friction = p.friction != 0;
+	T vmax = T(0);
+
+	auto load_row = [&](const long y) {
+		RowRegs<T> r;
+		const size_t id = (size_t)y * p.cols + xc;
+		r.c = src[id]; r.zb = bed[id]; r.n = manning[id];
+		return r;
+	};
+
+	// pipeline fill: row y0-1 (south of the segment) gives the first south face
+	RowRegs<T> rs = load_row(y0 - 1);
+	RowRegs<T> rc = load_row(y0);
+	Side<T> sS = make_side(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
+	Side<T> sC = make_side(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
+	bool dryS = (rs.c.z - rs.zb) < vs;
+	FaceFlux<T> fS;
+	if (!skip_step) fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
+
+	for (long y = y0; y < y1; ++y) {
+		const size_t id = (size_t)y * p.cols + xc;
+		const RowRegs<T> rn = load_row(y + 1);                                     // y+1 <= rows-1 always
+		State4<T> out = rc.c;
+		bool write = out_x, stale = false;
+
+		if (!skip_step) {
+			const Side<T> sN = make_side(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
+			const Side<T> sE = shfl_side(sC, lane_e);
+			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sC, sN, vs);
+			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sC, sE, vs);
+			const FaceFlux<T> fN = fy.forL, fS_next = fy.forR, fE = fx.forL, forW = fx.forR;
+			// hand the east face to the lane on its other side
+			FaceFlux<T> fW;
+			fW.f0 = __shfl(forW.f0, lane_w, 64); fW.fx = __shfl(forW.fx, lane_w, 64);
+			fW.fy = __shfl(forW.fy, lane_w, 64); fW.eta_nb = __shfl(forW.eta_nb, lane_w, 64);
+			fW.zb_nb = __shfl(forW.zb_nb, lane_w, 64);
+			const bool dryC = (rc.c.z - rc.zb) < vs;
+			const int flags = __shfl((int)forW.stop | ((int)dryC << 1), lane_w, 64);
+			fW.stop = (flags & 1) != 0;
+			const bool dryW = (flags & 2) != 0;
+			const bool dryE = (sE.eta - sE.zb) < vs;
+			const bool dryN = (rn.c.z - rn.zb) < vs;
+
+			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
+			const bool dry5 = dryC && dryN && dryE && dryS && dryW;                   // :248-255
+			if (!disabled) {
+				if (dry5) { write = false; stale = out_x; }                               // dst untouched (Q3)
+				else out = godunov_update<STRICT>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, vs, with_friction);
+			}
+			fS = fS_next;
+			dryS = dryC;
+			sC = sN;
+		}
+
+		if (write) dst[id] = out;
+		if (CFL_MODE == 1) {
+			if (stale) out = dst[id];
+			if (write || stale) {
+				const T s = cfl_speed(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
+				if (s > vmax) vmax = s;
+			}
+		} else if (CFL_MODE == 2) {
+			if (out_x) {
+				const T s = cfl_speed(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
+				if (s > vmax) vmax = s;
+			}
+		}
+		rc = rn;
+	}
+
+	if (CFL_MODE != 0) {
+		// the edge ring (never written, priced at upload) joins the maximum before any cross-rank all-reduce
+		if (tile == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
+		vmax = wave_max(vmax);
+		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
+	}
+}
+
+// max wave speed over the edge ring (cells no kernel ever writes): x = 0, x = cols-1 on rows [row_lo,row_hi)
+// plus whole rows `south`/`north` when >= 0.  Priced once per upload into *edge_max.
+template <typename T>
+__global__ __launch_bounds__(256) void cfl_edge_ring(const Params<T> p, const State4<T>* __restrict__ state,
+                                                     const T* __restrict__ bed, const long row_lo, const long row_hi,
+                                                     const long south, const long north, T* __restrict__ edge_max)
+{
+	const long n_side = row_hi - row_lo;
+	const long total = 2 * n_side + (south >= 0 ? p.cols : 0) + (north >= 0 ? p.cols : 0);
+	T m = T(0);
+	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+		long x, y;
+		if (i < n_side) { x = 0; y = row_lo + i; }
+		else if (i < 2 * n_side) { x = p.cols - 1; y = row_lo + (i - n_side); }
+		else {
+			long j = i - 2 * n_side;
+			if (south >= 0 && j < p.cols) { x = j; y = south; }
+			else { if (south >= 0) j -= p.cols; x = j; y = north; }
+		}
+		const size_t id = (size_t)y * p.cols + x;
+		const State4<T> c = state[id];
+		const T s = cfl_speed(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
+		if (s > m) m = s;
+	}
+	m = wave_max(m);
+	if ((threadIdx.x & 63) == 0 && m > T(0)) atomic_max_nonneg(edge_max, m);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -88,14 +250,23 @@ __global__ __launch_bounds__(256) void cfl_reduce(const Params<T> p, const State
 //     `slot` holds the (all-reduced) maximum wave speed; it is cleared for the next accumulation.
 //     UPDATE_ONLY = tst_UpdateTimestep (:255-317).
 // -------------------------------------------------------------------------------------------------
+//     slot[0] = running maximum of this iteration (all-reduced by the host across strips), cleared here;
+//     slot[1] = maximum last used (re-used when the primary buffer was not touched: `fresh` == 0, Q1);
+//     slot[2], slot[3] = edge-ring maxima of the two state buffers (read by godunov_march).
 template <bool UPDATE_ONLY, typename T>
-__global__ void advance_time(const Params<T> p, Scalars<T>* __restrict__ sc, T* __restrict__ slot)
+__global__ void advance_time(const Params<T> p, Scalars<T>* __restrict__ sc, T* __restrict__ slot, const int fresh)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	const T EARLY_LIMIT = T(0.1), EARLY_DURATION = T(60.0), START_MIN = T(1E-10), START_DURATION = T(1.0);
 	const T DT_MIN = T(1E-10), DT_MAX = T(15.0), HYDRO = T(1.0);                 // CLDynamicTimestep.clh:24-29
-	const T vmax = *slot;
-	*slot = T(0);
+	T vmax;
+	if (fresh) {
+		vmax = slot[0];
+		slot[1] = vmax;
+	} else {
+		vmax = slot[1];
+	}
+	slot[0] = T(0);
 
 	T t = sc->t, t_sync = sc->t_sync, batch = sc->batch_dt;
 	if (UPDATE_ONLY) {

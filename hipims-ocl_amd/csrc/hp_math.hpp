@@ -72,16 +72,84 @@ __device__ __forceinline__ Side<T> make_side(T z, T qx, T qy, T zb, T vs)
 // :323-325) and whether a stopping condition fired (:107-130).
 template <typename T> struct FaceFlux { T f0, fx, fy, eta_nb, zb_nb; bool stop; };
 
+// Shift-dependent tail of a face solve for the DRY-DRY case (CLSolverHLLC.clc:45-61): pressure-like term
+// only, left bed on both sides (Q4).  `s` is the vertical shift of the cell the face is finished for.
+template <int AXIS, typename T>
+__device__ __forceinline__ FaceFlux<T> finish_dry(const T etaL, const T etaR, const T zbm, const T s,
+                                                  const bool own_left, const bool stop)
+{
+	const T half_g = T(0.5) * gravity<T>();
+	const T a = etaL - s, b = etaR - s, zb = zbm - s;
+	const T p = half_g * (((a + b) / 2) * ((a + b) / 2) - zb * (a + b));
+	FaceFlux<T> o;
+	o.f0 = T(0);
+	o.fx = (AXIS == AXIS_X ? p : T(0));
+	o.fy = (AXIS == AXIS_Y ? p : T(0));
+	o.eta_nb = own_left ? b : a;
+	o.zb_nb = zb;
+	o.stop = stop;
+	return o;
+}
+
+// Everything of the HLLC solve that does not depend on the shift.
+template <typename T> struct FaceCore {
+	T etaL, etaR, zbm;            // reconstructed levels before the shift, common bed
+	T unL, unR, utL, utR;         // normal / tangential velocities
+	T qnL, qnR, qtL, qtR;         // normal / tangential discharges
+	T sL, sR, sLsR, inv_ds;       // wave speeds
+	bool bLeft, bRight, bMid1;
+};
+
+template <int AXIS, bool STRICT, typename T>
+__device__ __forceinline__ FaceFlux<T> finish_wet(const FaceCore<T>& k, const T s, const bool own_left, const bool stop)
+{
+	const T half_g = T(0.5) * gravity<T>();
+	const T a = k.etaL - s, b = k.etaR - s, zb = k.zbm - s;
+	// normal-momentum flux of each side in free-surface form, left bed on both sides (:146-157, Q4)
+	T fnL, fnR;
+	if (STRICT) {
+		fnL = k.unL * k.qnL + half_g * (a * a - 2 * zb * a);
+		fnR = k.unR * k.qnR + half_g * (b * b - 2 * zb * b);
+	} else {
+		fnL = fma_(k.unL, k.qnL, half_g * (a * (a - 2 * zb)));
+		fnR = fma_(k.unR, k.qnR, half_g * (b * (b - 2 * zb)));
+	}
+	T f0, fn, ft;
+	if (k.bLeft)       { f0 = k.qnL; fn = fnL; ft = k.unL * k.qtL; }
+	else if (k.bRight) { f0 = k.qnR; fn = fnR; ft = k.unR * k.qtR; }
+	else {
+		// HLL middle state (:200-224)
+		T f1m, f2m;
+		if (STRICT) {
+			f1m = (k.sR * k.qnL - k.sL * k.qnR + k.sLsR * (b - a)) / (k.sR - k.sL);
+			f2m = (k.sR * fnL - k.sL * fnR + k.sLsR * (k.qnR - k.qnL)) / (k.sR - k.sL);
+		} else {
+			f1m = fma_(k.sLsR, (b - a), fma_(k.sR, k.qnL, -(k.sL * k.qnR))) * k.inv_ds;
+			f2m = fma_(k.sLsR, (k.qnR - k.qnL), fma_(k.sR, fnL, -(k.sL * fnR))) * k.inv_ds;
+		}
+		f0 = f1m; fn = f2m; ft = f1m * (k.bMid1 ? k.utL : k.utR);
+	}
+	FaceFlux<T> o;
+	o.f0 = f0;
+	o.fx = (AXIS == AXIS_X ? fn : ft);
+	o.fy = (AXIS == AXIS_X ? ft : fn);
+	o.eta_nb = own_left ? b : a;
+	o.zb_nb = zb;
+	o.stop = stop;
+	return o;
+}
+
+template <typename T> struct FacePair { FaceFlux<T> forL, forR; };
+
 // Solve the face between cell L (west/south) and cell R (east/north).
 //   forL : the face as cell L sees it (its E or N face; "own" = left,  ucDirection < DOMAIN_DIR_S)
 //   forR : the face as cell R sees it (its W or S face; "own" = right)
 // Reference: reconstructInterface (CLSchemeGodunov.clc:27-159) + riemannSolver (CLSolverHLLC.clc:27-248).
 template <int AXIS, bool STRICT, bool WANT_L, bool WANT_R, typename T>
-__device__ __forceinline__ void face_solve(const Side<T>& L, const Side<T>& R, const T vs,
-                                           FaceFlux<T>& forL, FaceFlux<T>& forR)
+__device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T>& R, const T vs)
 {
 	const T g = gravity<T>();
-	const T half_g = T(0.5) * g;
+	FacePair<T> out;
 
 	// ---- reconstruction (:84-97) ----
 	const T zbm = (L.zb > R.zb ? L.zb : R.zb);
@@ -94,29 +162,17 @@ __device__ __forceinline__ void face_solve(const Side<T>& L, const Side<T>& R, c
 	T shR = zbm - R.eta; if (shR < T(0)) shR = T(0);          // shift when the RIGHT cell is own
 
 	// ---- stopping conditions (:101-133): first test is direction specific, the other two shared ----
-	{
-		const T vnL = (AXIS == AXIS_X ? L.u0 : L.v0), vnR = (AXIS == AXIS_X ? R.u0 : R.v0);
-		const T qrawL = (AXIS == AXIS_X ? L.qx : L.qy), qrawR = (AXIS == AXIS_X ? R.qx : R.qy);
-		const bool shared = (hR <= vs && vnL < T(0)) || (hL <= vs && vnR > T(0));
-		forL.stop = shared || (hL <= vs && qrawL > T(0));      // N / E case
-		forR.stop = shared || (hR <= vs && qrawR < T(0));      // S / W case
-	}
+	const T vnL = (AXIS == AXIS_X ? L.u0 : L.v0), vnR = (AXIS == AXIS_X ? R.u0 : R.v0);
+	const T qrawL = (AXIS == AXIS_X ? L.qx : L.qy), qrawR = (AXIS == AXIS_X ? R.qx : R.qy);
+	const bool shared = (hR <= vs && vnL < T(0)) || (hL <= vs && vnR > T(0));
+	const bool stopL = shared || (hL <= vs && qrawL > T(0));      // N / E case
+	const bool stopR = shared || (hR <= vs && qrawR < T(0));      // S / W case
 
 	// ---- HLLC ----
 	if (hL < vs && hR < vs) {
-		// both sides dry (CLSolverHLLC.clc:45-61): pressure-like term only, left bed on both (Q4)
-		auto finish = [&](const T s, FaceFlux<T>& o, const bool own_left) {
-			const T a = etaL - s, b = etaR - s, zb = zbm - s;
-			const T p = half_g * (((a + b) / 2) * ((a + b) / 2) - zb * (a + b));
-			o.f0 = T(0);
-			o.fx = (AXIS == AXIS_X ? p : T(0));
-			o.fy = (AXIS == AXIS_Y ? p : T(0));
-			o.eta_nb = own_left ? b : a;
-			o.zb_nb = zb;
-		};
-		if (WANT_L) finish(shL, forL, true);
-		if (WANT_R) finish(shR, forR, false);
-		return;
+		if (WANT_L) out.forL = finish_dry<AXIS>(etaL, etaR, zbm, shL, true, stopL);
+		if (WANT_R) out.forR = finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
+		return out;
 	}
 
 	// velocities (:87-92).  STRICT: recomputed from the reconstructed discharges as the reference does;
@@ -129,68 +185,44 @@ __device__ __forceinline__ void face_solve(const Side<T>& L, const Side<T>& R, c
 		uL = (hL < vs ? T(0) : L.u0); vL = (hL < vs ? T(0) : L.v0);
 		uR = (hR < vs ? T(0) : R.u0); vR = (hR < vs ? T(0) : R.v0);
 	}
-	const T unL = (AXIS == AXIS_X ? uL : vL), unR = (AXIS == AXIS_X ? uR : vR);       // dVel   (:95-98)
-	const T utL = (AXIS == AXIS_X ? vL : uL), utR = (AXIS == AXIS_X ? vR : uR);       // tangential velocity
-	const T qnL = (AXIS == AXIS_X ? qxL : qyL), qnR = (AXIS == AXIS_X ? qxR : qyR);   // dDis   (:99-102)
-	const T qtL = (AXIS == AXIS_X ? qyL : qxL), qtR = (AXIS == AXIS_X ? qyR : qxR);
+	FaceCore<T> k;
+	k.etaL = etaL; k.etaR = etaR; k.zbm = zbm;
+	k.unL = (AXIS == AXIS_X ? uL : vL); k.unR = (AXIS == AXIS_X ? uR : vR);           // dVel   (:95-98)
+	k.utL = (AXIS == AXIS_X ? vL : uL); k.utR = (AXIS == AXIS_X ? vR : uR);           // tangential velocity
+	k.qnL = (AXIS == AXIS_X ? qxL : qyL); k.qnR = (AXIS == AXIS_X ? qxR : qyR);       // dDis   (:99-102)
+	k.qtL = (AXIS == AXIS_X ? qyL : qxL); k.qtR = (AXIS == AXIS_X ? qyR : qxR);
 	const T aL = sqrt_(g * hL), aR = sqrt_(g * hR);                                   // dA     (:103-106)
 
 	// two-rarefaction star state and wave speeds (:123-142)
 	const T a_avg = (aL + aR) / 2;
-	const T tmp = a_avg + (unL - unR) / 4;
-	const T h_star = STRICT ? (tmp * tmp) / g : (tmp * tmp) * (T(1) / g);
-	const T u_star = (unL + unR) / 2 + aL - aR;
-	const T a_star = sqrt_(g * h_star);
+	const T tmp = a_avg + (k.unL - k.unR) / 4;
+	const T u_star = (k.unL + k.unR) / 2 + aL - aR;
+	T a_star;
+	if (STRICT) a_star = sqrt_(g * ((tmp * tmp) / g));
+	else        a_star = fabs_(tmp);                         // sqrt(g * tmp^2 / g)
 	T sL, sR;
-	if (hL < vs) sL = unR - 2 * aR;
-	else         sL = (((unL - aL) > (u_star - a_star)) ? (u_star - a_star) : (unL - aL));
-	if (hR < vs) sR = unL + 2 * aL;
-	else         sR = (((unR + aR) < (u_star + a_star)) ? (u_star + a_star) : (unR + aR));
-	const T sM = (sL * hR * (unR - sR) - sR * hL * (unL - sL)) / (hR * (unR - sR) - hL * (unL - sL));
+	if (hL < vs) sL = k.unR - 2 * aR;
+	else         sL = (((k.unL - aL) > (u_star - a_star)) ? (u_star - a_star) : (k.unL - aL));
+	if (hR < vs) sR = k.unL + 2 * aL;
+	else         sR = (((k.unR + aR) < (u_star + a_star)) ? (u_star + a_star) : (k.unR + aR));
+	k.sL = sL; k.sR = sR; k.sLsR = sL * sR;
 
-	// region selection (:174-177); NaN wave speeds fall through to "right" exactly as in the reference
-	const bool bLeft = sL >= T(0);
-	const bool bMid1 = sL < T(0) && sR >= T(0) && sM >= T(0);
-	const bool bMid2 = sL < T(0) && sR >= T(0) && !bMid1;
-	const bool bRight = !bLeft && !bMid1 && !bMid2;
+	// region selection (:174-177); NaN wave speeds fall through to "right" exactly as in the reference.
+	// s_M is only ever compared with zero: FAST decides the sign from numerator and denominator.
+	const T sm_num = sL * hR * (k.unR - sR) - sR * hL * (k.unL - sL);
+	const T sm_den = hR * (k.unR - sR) - hL * (k.unL - sL);
+	bool sm_nonneg;
+	if (STRICT) sm_nonneg = (sm_num / sm_den) >= T(0);
+	else        sm_nonneg = (sm_den < T(0)) ? (sm_num <= T(0)) : ((sm_num / sm_den) >= T(0));
+	k.bLeft = sL >= T(0);
+	k.bMid1 = sL < T(0) && sR >= T(0) && sm_nonneg;
+	const bool bMid2 = sL < T(0) && sR >= T(0) && !k.bMid1;
+	k.bRight = !k.bLeft && !k.bMid1 && !bMid2;
+	k.inv_ds = STRICT ? T(0) : T(1) / (sR - sL);
 
-	const T inv_ds = STRICT ? T(0) : T(1) / (sR - sL);
-	const T sLsR = sL * sR;
-
-	auto finish = [&](const T s, FaceFlux<T>& o, const bool own_left) {
-		const T a = etaL - s, b = etaR - s, zb = zbm - s;
-		// normal-momentum flux of each side in free-surface form, left bed on both sides (:146-157, Q4)
-		T fnL, fnR;
-		if (STRICT) {
-			fnL = unL * qnL + half_g * (a * a - 2 * zb * a);
-			fnR = unR * qnR + half_g * (b * b - 2 * zb * b);
-		} else {
-			fnL = fma_(unL, qnL, half_g * (a * (a - 2 * zb)));
-			fnR = fma_(unR, qnR, half_g * (b * (b - 2 * zb)));
-		}
-		T f0, fn, ft;
-		if (bLeft)       { f0 = qnL; fn = fnL; ft = unL * qtL; }
-		else if (bRight) { f0 = qnR; fn = fnR; ft = unR * qtR; }
-		else {
-			// HLL middle state (:200-224)
-			T f1m, f2m;
-			if (STRICT) {
-				f1m = (sR * qnL - sL * qnR + sLsR * (b - a)) / (sR - sL);
-				f2m = (sR * fnL - sL * fnR + sLsR * (qnR - qnL)) / (sR - sL);
-			} else {
-				f1m = fma_(sLsR, (b - a), fma_(sR, qnL, -(sL * qnR))) * inv_ds;
-				f2m = fma_(sLsR, (qnR - qnL), fma_(sR, fnL, -(sL * fnR))) * inv_ds;
-			}
-			f0 = f1m; fn = f2m; ft = f1m * (bMid1 ? utL : utR);
-		}
-		o.f0 = f0;
-		o.fx = (AXIS == AXIS_X ? fn : ft);
-		o.fy = (AXIS == AXIS_X ? ft : fn);
-		o.eta_nb = own_left ? b : a;
-		o.zb_nb = zb;
-	};
-	if (WANT_L) finish(shL, forL, true);
-	if (WANT_R) finish(shR, forR, false);
+	if (WANT_L) out.forL = finish_wet<AXIS, STRICT>(k, shL, true, stopL);
+	if (WANT_R) out.forR = finish_wet<AXIS, STRICT>(k, shR, false, stopR);
+	return out;
 }
 
 // Point-implicit Manning friction (Schemes/CLFriction.clc:26-72)

@@ -643,7 +643,9 @@ real orc_cfl_max_speed(const orc_params* p, const real* state, const real* bed)
 	const real QS = p->quite_small;
 	const size_t cells = (size_t)p->cols * (size_t)p->rows;
 	real dMaxSpeed = RC(0.0);
-	for (size_t i = 0; i < cells; ++i) {
+	long i;
+#pragma omp parallel for schedule(static) reduction(max : dMaxSpeed) num_threads(p->threads > 0 ? p->threads : 1)
+	for (i = 0; i < (long)cells; ++i) {
 		const real* s = state + 4 * i;
 		real dDepth = s[0] - bed[i];                                  /* :191 */
 		real dCellSpeed;
