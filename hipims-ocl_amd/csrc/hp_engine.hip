@@ -49,6 +49,7 @@ struct hp_domain {
 	void*            bed = nullptr;
 	void*            manning = nullptr;
 	void*            scalars = nullptr;               // Scalars<T> on the device
+	void*            sink = nullptr;                  // 64 State4 slots: where non-writing lanes of godunov_march store
 	void*            cfl_slot = nullptr;              // T[4]: running max | last used max | edge ring of [0] | of [1]
 	bool             need_full_reduce = true;         // the remembered maximum is stale (upload / link import)
 	bool             edge_dirty = true;               // edge-ring maxima must be re-priced
@@ -75,6 +76,7 @@ template <typename T> Params<T> make_params(const hp_domain* d)
 	p.cols = d->desc.cols; p.rows = d->desc.rows;
 	p.row_offset = d->desc.row_offset; p.global_rows = d->desc.global_rows;
 	p.dx = (T)d->desc.dx;
+	p.inv_dx = T(1) / p.dx;
 	p.vs = (T)d->desc.dry_threshold;
 	p.qs = (T)d->desc.dry_threshold * T(10);             // CSchemeGodunov.cpp:57, :523
 	p.courant = (T)d->desc.courant;
@@ -152,8 +154,8 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer)
 	const unsigned blocks = (unsigned)((ntiles + 7) / 8) * 8;
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, d->stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + 2 + edge_buffer, rseg, nstrips,
-	                   groups, ntiles);
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + 2 + edge_buffer,
+	                   (State4<T>*)d->sink, rseg, nstrips, groups, ntiles);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -372,7 +374,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	d->esize = (size_t)desc->precision;
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
-		if (v >= 1 && v <= 4096) d->march_rseg = v;
+		if (v >= 1 && v <= 32) d->march_rseg = v;
 	}
 
 	auto cleanup = [&](int code) { hp_domain_destroy(d); return code; };
@@ -389,6 +391,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	HIP_TRY_C(hipMalloc(&d->manning, d->cells * d->esize));
 	HIP_TRY_C(hipMalloc(&d->scalars, 256));
 	HIP_TRY_C(hipMalloc(&d->cfl_slot, 256));
+	HIP_TRY_C(hipMalloc(&d->sink, 64 * 32));
 	HIP_TRY_C(hipHostMalloc(&d->host_scalars, 512, hipHostMallocDefault));
 	HIP_TRY_C(hipMemset(d->state[0], 0, d->cells * 4 * d->esize));
 	HIP_TRY_C(hipMemset(d->state[1], 0, d->cells * 4 * d->esize));
@@ -413,7 +416,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	for (auto& b : d->bdy) hipFree(b.data);
 	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
-	hipFree(d->scalars); hipFree(d->cfl_slot);
+	hipFree(d->scalars); hipFree(d->cfl_slot); hipFree(d->sink);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
 	if (d->ev_stop) hipEventDestroy(d->ev_stop);

@@ -39,18 +39,18 @@ __global__ __launch_bounds__(256) void godunov_basic(const Params<T> p, const Sc
 	if (cW.z - zW < p.vs) dry++;
 	if (dry >= 5) return;                                                         // dst untouched (Q3)
 
-	const Side<T> sC = make_side(c.z, c.qx, c.qy, zb, p.vs);
-	const Side<T> sN = make_side(cN.z, cN.qx, cN.qy, zN, p.vs);
-	const Side<T> sE = make_side(cE.z, cE.qx, cE.qy, zE, p.vs);
-	const Side<T> sS = make_side(cS.z, cS.qx, cS.qy, zS, p.vs);
-	const Side<T> sW = make_side(cW.z, cW.qx, cW.qy, zW, p.vs);
+	const Side<T> sC = make_side<STRICT>(c.z, c.qx, c.qy, zb, p.vs);
+	const Side<T> sN = make_side<STRICT>(cN.z, cN.qx, cN.qy, zN, p.vs);
+	const Side<T> sE = make_side<STRICT>(cE.z, cE.qx, cE.qy, zE, p.vs);
+	const Side<T> sS = make_side<STRICT>(cS.z, cS.qx, cS.qy, zS, p.vs);
+	const Side<T> sW = make_side<STRICT>(cW.z, cW.qx, cW.qy, zW, p.vs);
 
 	const FaceFlux<T> fN = face_solve<AXIS_Y, STRICT, true, false>(sC, sN, p.vs).forL;
 	const FaceFlux<T> fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, p.vs).forR;
 	const FaceFlux<T> fE = face_solve<AXIS_X, STRICT, true, false>(sC, sE, p.vs).forL;
 	const FaceFlux<T> fW = face_solve<AXIS_X, STRICT, false, true>(sW, sC, p.vs).forR;
 
-	dst[id] = godunov_update<STRICT>(c, zb, n, dt, fN, fE, fS, fW, p.dx, p.vs, p.friction != 0);
+	dst[id] = godunov_update<STRICT>(c, zb, n, dt, fN, fE, fS, fW, p.dx, p.inv_dx, p.vs, p.friction != 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* __restrict__ cfl_slot, const T* __restrict__ edge_max,
-                                                     const int rseg, const int nstrips, const int groups,
-                                                     const int ntiles)
+                                                     State4<T>* __restrict__ sink, const int rseg, const int nstrips,
+                                                     const int groups, const int ntiles)
 {
 	// XCD-aware tile order (grid is a multiple of 8 blocks)
 	const unsigned per_xcd = gridDim.x >> 3;
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	const bool skip_step = dt <= T(0);                                             // CLSchemeGodunov.clc:201-206
 	const bool with_friction = p.friction != 0;
 	T vmax = T(0);
+	unsigned stale_rows = 0;       // bit i: row y0+i of this lane was left untouched (all-dry, Q3); rseg <= 32
 
 	auto load_row = [&](const long y) {
 		RowRegs<T> r;
@@ -120,28 +121,28 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		return r;
 	};
 
-	// pipeline fill: row y0-1 (south of the segment) gives the first south face
+	// pipeline fill: row y0-1 (south of the segment) gives the first south face; rows are fetched two ahead of
+	// the one being updated so a wave always has a 3 KiB row in flight behind ~400 VALU instructions of work
 	RowRegs<T> rs = load_row(y0 - 1);
 	RowRegs<T> rc = load_row(y0);
-	Side<T> sS = make_side(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
-	Side<T> sC = make_side(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
+	RowRegs<T> rn = load_row(y0 + 1);                                              // y0+1 <= rows-1 always
+	Side<T> sS = make_side<STRICT>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
+	Side<T> sC = make_side<STRICT>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
 	bool dryS = (rs.c.z - rs.zb) < vs;
-	FaceFlux<T> fS;
+	FaceFlux<T> fS = {};
 	if (!skip_step) fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
 
 	for (long y = y0; y < y1; ++y) {
 		const size_t id = (size_t)y * p.cols + xc;
-		const RowRegs<T> rn = load_row(y + 1);                                     // y+1 <= rows-1 always
+		const RowRegs<T> rnn = load_row((y + 2 < p.rows) ? (y + 2) : (p.rows - 1));   // prefetch (clamped)
 		State4<T> out = rc.c;
-		bool write = out_x, stale = false;
+		bool write = out_x;
 
 		if (!skip_step) {
-			const Side<T> sN = make_side(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
+			// east face first: its result has to travel to the next lane while the north face is solved
 			const Side<T> sE = shfl_side(sC, lane_e);
-			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sC, sN, vs);
 			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sC, sE, vs);
-			const FaceFlux<T> fN = fy.forL, fS_next = fy.forR, fE = fx.forL, forW = fx.forR;
-			// hand the east face to the lane on its other side
+			const FaceFlux<T> fE = fx.forL, forW = fx.forR;
 			FaceFlux<T> fW;
 			fW.f0 = __shfl(forW.f0, lane_w, 64); fW.fx = __shfl(forW.fx, lane_w, 64);
 			fW.fy = __shfl(forW.fy, lane_w, 64); fW.eta_nb = __shfl(forW.eta_nb, lane_w, 64);
@@ -153,31 +154,57 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			const bool dryE = (sE.eta - sE.zb) < vs;
 			const bool dryN = (rn.c.z - rn.zb) < vs;
 
+			const Side<T> sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
+			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sC, sN, vs);
+			const FaceFlux<T> fN = fy.forL;
+
 			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
 			const bool dry5 = dryC && dryN && dryE && dryS && dryW;                   // :248-255
+			const State4<T> upd = godunov_update<STRICT>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx, vs,
+			                                             with_friction);
 			if (!disabled) {
-				if (dry5) { write = false; stale = out_x; }                               // dst untouched (Q3)
-				else out = godunov_update<STRICT>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, vs, with_friction);
+				if (dry5) {                                                               // dst untouched (Q3)
+					write = false;
+					if (out_x) stale_rows |= 1u << (unsigned)(y - y0);
+				} else {
+					out = upd;
+				}
 			}
-			fS = fS_next;
+			fS = fy.forR;
 			dryS = dryC;
 			sC = sN;
 		}
 
-		if (write) dst[id] = out;
+		// One unconditional store per row: lanes that must not write (halo lanes, all-dry cells) aim at a sink
+		// line instead of branching around the store, which keeps the wave's vmcnt bookkeeping static so the
+		// wait for the prefetched row never has to drain the stores behind it.
+		State4<T>* const target = write ? (dst + id) : (sink + lane);
+		*target = out;
 		if (CFL_MODE == 1) {
-			if (stale) out = dst[id];
-			if (write || stale) {
-				const T s = cfl_speed(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
+			if (write) {
+				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
 				if (s > vmax) vmax = s;
 			}
 		} else if (CFL_MODE == 2) {
 			if (out_x) {
-				const T s = cfl_speed(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
+				const T s = cfl_speed<STRICT>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
 				if (s > vmax) vmax = s;
 			}
 		}
 		rc = rn;
+		rn = rnn;
+	}
+
+	if (CFL_MODE == 1 && __any(stale_rows != 0)) {
+		// cells the reference leaves untouched still hold their two-steps-old value in dst, and tst_Reduce prices it
+		for (long y = y0; y < y1; ++y) {
+			if (stale_rows & (1u << (unsigned)(y - y0))) {
+				const size_t id = (size_t)y * p.cols + xc;
+				const State4<T> c = dst[id];
+				const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
+				if (s > vmax) vmax = s;
+			}
+		}
 	}
 
 	if (CFL_MODE != 0) {
@@ -209,7 +236,7 @@ __global__ __launch_bounds__(256) void cfl_edge_ring(const Params<T> p, const St
 		}
 		const size_t id = (size_t)y * p.cols + x;
 		const State4<T> c = state[id];
-		const T s = cfl_speed(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
+		const T s = cfl_speed<true>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
 		if (s > m) m = s;
 	}
 	m = wave_max(m);
@@ -232,7 +259,7 @@ __global__ __launch_bounds__(256) void cfl_reduce(const Params<T> p, const State
 	for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last;
 	     i += (size_t)gridDim.x * blockDim.x) {
 		const State4<T> c = state[i];
-		const T s = cfl_speed(c.z, c.zmax, c.qx, c.qy, bed[i], p.qs);
+		const T s = cfl_speed<true>(c.z, c.zmax, c.qx, c.qy, bed[i], p.qs);
 		if (s > m) m = s;
 	}
 	m = wave_max(m);

@@ -21,7 +21,7 @@ enum : int { AXIS_X = 0, AXIS_Y = 1 };
 template <typename T> struct Params {
 	long cols, rows;             // local array size
 	long row_offset, global_rows;
-	T    dx, vs, qs, courant, t_end, dt_fixed;
+	T    dx, inv_dx, vs, qs, courant, t_end, dt_fixed;
 	int  friction, dynamic_dt;
 };
 
@@ -52,18 +52,71 @@ __device__ __forceinline__ float  fmin_(float a, float b)   { return __builtin_f
 __device__ __forceinline__ double floor_(double x) { return __builtin_floor(x); }
 __device__ __forceinline__ float  floor_(float x)  { return __builtin_floorf(x); }
 
+// ---- FAST-flavour primitives: hardware seed + Newton steps instead of the IEEE expansions ----
+// 1/x to about 1 ulp: v_rcp_f64 seed, two Newton-Raphson steps (the IEEE division adds scaling + fix-up).
+__device__ __forceinline__ double rcp_fast(double x)
+{
+	double r = __builtin_amdgcn_rcp(x);
+	double e = __builtin_fma(-x, r, 1.0);
+	r = __builtin_fma(r, e, r);
+	e = __builtin_fma(-x, r, 1.0);
+	return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float rcp_fast(float x)
+{
+	float r = __builtin_amdgcn_rcpf(x);
+	const float e = __builtin_fmaf(-x, r, 1.0f);
+	return __builtin_fmaf(r, e, r);
+}
+// sqrt(x), x >= 0, to about 1 ulp: v_rsq_f64 seed, Goldschmidt step + residual correction.  x is clamped away
+// from zero (sqrt(1e-300) = 1e-150 stands in for 0; depths below VERY_SMALL never reach a division by it).
+__device__ __forceinline__ double sqrt_fast(double x)
+{
+	x = __builtin_fmax(x, 1e-300);
+	const double y = __builtin_amdgcn_rsq(x);
+	double g = x * y, h = 0.5 * y;
+	const double r = __builtin_fma(-h, g, 0.5);
+	g = __builtin_fma(g, r, g);
+	h = __builtin_fma(h, r, h);
+	const double d = __builtin_fma(-g, g, x);
+	return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ float sqrt_fast(float x) { return __builtin_sqrtf(x); }
+// x^(-1/3), x > 0: fp32 exp2/log2 seed (relative error ~1e-6), two Newton steps y <- y + y(1 - x y^3)/3.
+__device__ __forceinline__ double rcbrt_fast(double x)
+{
+	const float xf = (float)x;
+	double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (-1.0f / 3.0f));
+	double e = __builtin_fma(-x * y, y * y, 1.0);
+	y = __builtin_fma(y * (1.0 / 3.0), e, y);
+	e = __builtin_fma(-x * y, y * y, 1.0);
+	return __builtin_fma(y * (1.0 / 3.0), e, y);
+}
+__device__ __forceinline__ float rcbrt_fast(float x)
+{
+	float y = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (-1.0f / 3.0f));
+	const float e = __builtin_fmaf(-x * y, y * y, 1.0f);
+	return __builtin_fmaf(y * (1.0f / 3.0f), e, y);
+}
+
 // One side of a face as the cell owner prepares it: raw state + the cell-centre velocities of
 // reconstructInterface (CLSchemeGodunov.clc:39-61): u0 = (Z - zb < VERY_SMALL) ? 0 : Qx / (Z - zb).
 template <typename T> struct Side { T eta, zb, qx, qy, u0, v0; };
 
-template <typename T>
+template <bool STRICT, typename T>
 __device__ __forceinline__ Side<T> make_side(T z, T qx, T qy, T zb, T vs)
 {
 	Side<T> s;
 	s.eta = z; s.zb = zb; s.qx = qx; s.qy = qy;
 	const T h0 = z - zb;
-	s.u0 = (h0 < vs ? T(0) : qx / h0);
-	s.v0 = (h0 < vs ? T(0) : qy / h0);
+	if (STRICT) {
+		s.u0 = (h0 < vs ? T(0) : qx / h0);
+		s.v0 = (h0 < vs ? T(0) : qy / h0);
+	} else {
+		const T inv = (h0 < vs ? T(0) : rcp_fast(h0));
+		s.u0 = qx * inv;
+		s.v0 = qy * inv;
+	}
 	return s;
 }
 
@@ -149,17 +202,25 @@ template <int AXIS, bool STRICT, bool WANT_L, bool WANT_R, typename T>
 __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T>& R, const T vs)
 {
 	const T g = gravity<T>();
-	FacePair<T> out;
 
 	// ---- reconstruction (:84-97) ----
-	const T zbm = (L.zb > R.zb ? L.zb : R.zb);
-	const T hL = (L.eta - zbm > T(0) ? (L.eta - zbm) : T(0));
-	const T hR = (R.eta - zbm > T(0) ? (R.eta - zbm) : T(0));
+	T zbm, hL, hR, shL, shR;
+	if (STRICT) {
+		zbm = (L.zb > R.zb ? L.zb : R.zb);
+		hL = (L.eta - zbm > T(0) ? (L.eta - zbm) : T(0));
+		hR = (R.eta - zbm > T(0) ? (R.eta - zbm) : T(0));
+		shL = zbm - L.eta; if (shL < T(0)) shL = T(0);        // shift when the LEFT cell is own (:85-86)
+		shR = zbm - R.eta; if (shR < T(0)) shR = T(0);        // shift when the RIGHT cell is own
+	} else {                                                  // same values through v_max_f64
+		zbm = fmax_(L.zb, R.zb);
+		hL = fmax_(L.eta - zbm, T(0));
+		hR = fmax_(R.eta - zbm, T(0));
+		shL = fmax_(zbm - L.eta, T(0));
+		shR = fmax_(zbm - R.eta, T(0));
+	}
 	const T etaL = hL + zbm, etaR = hR + zbm;
 	const T qxL = hL * L.u0, qyL = hL * L.v0;
 	const T qxR = hR * R.u0, qyR = hR * R.v0;
-	T shL = zbm - L.eta; if (shL < T(0)) shL = T(0);          // shift when the LEFT cell is own (:85-86)
-	T shR = zbm - R.eta; if (shR < T(0)) shR = T(0);          // shift when the RIGHT cell is own
 
 	// ---- stopping conditions (:101-133): first test is direction specific, the other two shared ----
 	const T vnL = (AXIS == AXIS_X ? L.u0 : L.v0), vnR = (AXIS == AXIS_X ? R.u0 : R.v0);
@@ -169,59 +230,77 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 	const bool stopR = shared || (hR <= vs && qrawR < T(0));      // S / W case
 
 	// ---- HLLC ----
+	FaceFlux<T> oL, oR;
 	if (hL < vs && hR < vs) {
-		if (WANT_L) out.forL = finish_dry<AXIS>(etaL, etaR, zbm, shL, true, stopL);
-		if (WANT_R) out.forR = finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
-		return out;
-	}
-
-	// velocities (:87-92).  STRICT: recomputed from the reconstructed discharges as the reference does;
-	// FAST: h*u0/h == u0 up to rounding, so the four divisions are dropped.
-	T uL, vL, uR, vR;
-	if (STRICT) {
-		uL = (hL < vs ? T(0) : qxL / hL); vL = (hL < vs ? T(0) : qyL / hL);
-		uR = (hR < vs ? T(0) : qxR / hR); vR = (hR < vs ? T(0) : qyR / hR);
+		oL = finish_dry<AXIS>(etaL, etaR, zbm, shL, true, stopL);
+		oR = finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
 	} else {
-		uL = (hL < vs ? T(0) : L.u0); vL = (hL < vs ? T(0) : L.v0);
-		uR = (hR < vs ? T(0) : R.u0); vR = (hR < vs ? T(0) : R.v0);
+		// velocities (:87-92).  STRICT: recomputed from the reconstructed discharges as the reference does;
+		// FAST: h*u0/h == u0 up to rounding, so the four divisions are dropped.
+		T uL, vL, uR, vR;
+		if (STRICT) {
+			uL = (hL < vs ? T(0) : qxL / hL); vL = (hL < vs ? T(0) : qyL / hL);
+			uR = (hR < vs ? T(0) : qxR / hR); vR = (hR < vs ? T(0) : qyR / hR);
+		} else {
+			uL = (hL < vs ? T(0) : L.u0); vL = (hL < vs ? T(0) : L.v0);
+			uR = (hR < vs ? T(0) : R.u0); vR = (hR < vs ? T(0) : R.v0);
+		}
+		FaceCore<T> k;
+		k.etaL = etaL; k.etaR = etaR; k.zbm = zbm;
+		k.unL = (AXIS == AXIS_X ? uL : vL); k.unR = (AXIS == AXIS_X ? uR : vR);           // dVel   (:95-98)
+		k.utL = (AXIS == AXIS_X ? vL : uL); k.utR = (AXIS == AXIS_X ? vR : uR);           // tangential velocity
+		k.qnL = (AXIS == AXIS_X ? qxL : qyL); k.qnR = (AXIS == AXIS_X ? qxR : qyR);       // dDis   (:99-102)
+		k.qtL = (AXIS == AXIS_X ? qyL : qxL); k.qtR = (AXIS == AXIS_X ? qyR : qxR);
+		const T aL = STRICT ? sqrt_(g * hL) : sqrt_fast(g * hL);                          // dA     (:103-106)
+		const T aR = STRICT ? sqrt_(g * hR) : sqrt_fast(g * hR);
+
+		// two-rarefaction star state and wave speeds (:123-142)
+		const T a_avg = (aL + aR) / 2;
+		const T tmp = a_avg + (k.unL - k.unR) / 4;
+		const T u_star = (k.unL + k.unR) / 2 + aL - aR;
+		T a_star;
+		if (STRICT) a_star = sqrt_(g * ((tmp * tmp) / g));
+		else        a_star = fabs_(tmp);                         // sqrt(g * tmp^2 / g)
+		T sL, sR;
+		if (STRICT) {
+			if (hL < vs) sL = k.unR - 2 * aR;
+			else         sL = (((k.unL - aL) > (u_star - a_star)) ? (u_star - a_star) : (k.unL - aL));
+			if (hR < vs) sR = k.unL + 2 * aL;
+			else         sR = (((k.unR + aR) < (u_star + a_star)) ? (u_star + a_star) : (k.unR + aR));
+		} else {
+			sL = (hL < vs) ? (k.unR - 2 * aR) : fmin_(k.unL - aL, u_star - a_star);
+			sR = (hR < vs) ? (k.unL + 2 * aL) : fmax_(k.unR + aR, u_star + a_star);
+		}
+		k.sL = sL; k.sR = sR; k.sLsR = sL * sR;
+
+		// region selection (:174-177); NaN wave speeds fall through to "right" exactly as in the reference.
+		// s_M is only ever compared with zero: FAST decides the sign from numerator and denominator.
+		const T sm_num = sL * hR * (k.unR - sR) - sR * hL * (k.unL - sL);
+		const T sm_den = hR * (k.unR - sR) - hL * (k.unL - sL);
+		bool sm_nonneg;
+		if (STRICT) sm_nonneg = (sm_num / sm_den) >= T(0);
+		else        sm_nonneg = (sm_den < T(0)) ? (sm_num <= T(0)) : ((sm_num / sm_den) >= T(0));
+		k.bLeft = sL >= T(0);
+		k.bMid1 = sL < T(0) && sR >= T(0) && sm_nonneg;
+		const bool bMid2 = sL < T(0) && sR >= T(0) && !k.bMid1;
+		k.bRight = !k.bLeft && !k.bMid1 && !bMid2;
+		k.inv_ds = STRICT ? T(0) : rcp_fast(sR - sL);
+
+		oL = finish_wet<AXIS, STRICT>(k, shL, true, stopL);
+		// The two finishes differ only through the shift, which is non-zero only where a cell's level lies below
+		// its neighbour's bed.  FAST reuses the first result where the shifts agree (bit-identical by construction).
+		if (!STRICT && WANT_L && WANT_R) {
+			oR = oL;
+			if (shL != shR) oR = finish_wet<AXIS, STRICT>(k, shR, false, stopR);   // rare, skipped wave-wide
+			oR.eta_nb = etaL - shR;
+			oR.stop = stopR;
+		} else {
+			oR = finish_wet<AXIS, STRICT>(k, shR, false, stopR);
+		}
 	}
-	FaceCore<T> k;
-	k.etaL = etaL; k.etaR = etaR; k.zbm = zbm;
-	k.unL = (AXIS == AXIS_X ? uL : vL); k.unR = (AXIS == AXIS_X ? uR : vR);           // dVel   (:95-98)
-	k.utL = (AXIS == AXIS_X ? vL : uL); k.utR = (AXIS == AXIS_X ? vR : uR);           // tangential velocity
-	k.qnL = (AXIS == AXIS_X ? qxL : qyL); k.qnR = (AXIS == AXIS_X ? qxR : qyR);       // dDis   (:99-102)
-	k.qtL = (AXIS == AXIS_X ? qyL : qxL); k.qtR = (AXIS == AXIS_X ? qyR : qxR);
-	const T aL = sqrt_(g * hL), aR = sqrt_(g * hR);                                   // dA     (:103-106)
-
-	// two-rarefaction star state and wave speeds (:123-142)
-	const T a_avg = (aL + aR) / 2;
-	const T tmp = a_avg + (k.unL - k.unR) / 4;
-	const T u_star = (k.unL + k.unR) / 2 + aL - aR;
-	T a_star;
-	if (STRICT) a_star = sqrt_(g * ((tmp * tmp) / g));
-	else        a_star = fabs_(tmp);                         // sqrt(g * tmp^2 / g)
-	T sL, sR;
-	if (hL < vs) sL = k.unR - 2 * aR;
-	else         sL = (((k.unL - aL) > (u_star - a_star)) ? (u_star - a_star) : (k.unL - aL));
-	if (hR < vs) sR = k.unL + 2 * aL;
-	else         sR = (((k.unR + aR) < (u_star + a_star)) ? (u_star + a_star) : (k.unR + aR));
-	k.sL = sL; k.sR = sR; k.sLsR = sL * sR;
-
-	// region selection (:174-177); NaN wave speeds fall through to "right" exactly as in the reference.
-	// s_M is only ever compared with zero: FAST decides the sign from numerator and denominator.
-	const T sm_num = sL * hR * (k.unR - sR) - sR * hL * (k.unL - sL);
-	const T sm_den = hR * (k.unR - sR) - hL * (k.unL - sL);
-	bool sm_nonneg;
-	if (STRICT) sm_nonneg = (sm_num / sm_den) >= T(0);
-	else        sm_nonneg = (sm_den < T(0)) ? (sm_num <= T(0)) : ((sm_num / sm_den) >= T(0));
-	k.bLeft = sL >= T(0);
-	k.bMid1 = sL < T(0) && sR >= T(0) && sm_nonneg;
-	const bool bMid2 = sL < T(0) && sR >= T(0) && !k.bMid1;
-	k.bRight = !k.bLeft && !k.bMid1 && !bMid2;
-	k.inv_ds = STRICT ? T(0) : T(1) / (sR - sL);
-
-	if (WANT_L) out.forL = finish_wet<AXIS, STRICT>(k, shL, true, stopL);
-	if (WANT_R) out.forR = finish_wet<AXIS, STRICT>(k, shR, false, stopR);
+	FacePair<T> out;
+	out.forL = oL;
+	out.forR = oR;
 	return out;
 }
 
@@ -230,7 +309,7 @@ template <bool STRICT, typename T>
 __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, const T n, const T dt, const T vs)
 {
 	const T g = gravity<T>();
-	const T q = sqrt_(qx * qx + qy * qy);
+	const T q = STRICT ? sqrt_(qx * qx + qy * qy) : sqrt_fast(fma_(qx, qx, qy * qy));
 	const T h = z - zb;
 	if (h < vs || q < vs) return;
 	if (STRICT) {
@@ -245,17 +324,17 @@ __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, co
 		qx = qx + dt * fx;
 		qy = qy + dt * fy;
 	} else {
-		// k = g n^2 / h^(7/3); S = -k q Q; D = 1 + dt k (2q^2 + p^2)/Q; clamp dt*S/D to [-|q|, |q|]-side
-		const T k    = (g * n * n) / (cbrt_(h) * h * h);
-		const T kq   = k * q, dtk_q = dt * k / q;
+		// A = dt g n^2 h^(-7/3);  dt Fx = -A Q^2 qx / (Q + A (2 qx^2 + qy^2))   [Q = |q|], no division by Q
+		const T rc = rcbrt_fast(h);                          // h^(-1/3)
+		const T rc2 = rc * rc, rc4 = rc2 * rc2;
+		const T A = (dt * g) * (n * n) * (rc4 * rc2 * rc);   // h^(-7/3)
 		const T qx2 = qx * qx, qy2 = qy * qy;
-		const T ddx = fma_(dtk_q, fma_(T(2), qx2, qy2), T(1));
-		const T ddy = fma_(dtk_q, fma_(T(2), qy2, qx2), T(1));
-		T dqx = -(dt * kq) * qx / ddx;            // dt * Fx
-		T dqy = -(dt * kq) * qy / ddy;
+		const T num = -A * (qx2 + qy2);
+		T dqx = num * qx * rcp_fast(fma_(A, fma_(T(2), qx2, qy2), q));
+		T dqy = num * qy * rcp_fast(fma_(A, fma_(T(2), qy2, qx2), q));
 		// friction can stop the flow, not reverse it (:52-65): dt*Fx limited to -qx
-		if (qx >= T(0)) { if (dqx < -qx) dqx = -qx; } else { if (dqx > -qx) dqx = -qx; }
-		if (qy >= T(0)) { if (dqy < -qy) dqy = -qy; } else { if (dqy > -qy) dqy = -qy; }
+		if (qx >= T(0)) dqx = fmax_(dqx, -qx); else dqx = fmin_(dqx, -qx);
+		if (qy >= T(0)) dqy = fmax_(dqy, -qy); else dqy = fmin_(dqy, -qy);
 		qx += dqx;
 		qy += dqy;
 	}
@@ -273,16 +352,26 @@ template <bool STRICT, typename T>
 __device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, const T n, const T dt,
                                                     const FaceFlux<T>& fN, const FaceFlux<T>& fE,
                                                     const FaceFlux<T>& fS, const FaceFlux<T>& fW,
-                                                    const T dx, const T vs, const bool with_friction)
+                                                    const T dx, const T inv_dx, const T vs, const bool with_friction)
 {
 	const T g = gravity<T>();
-	// bed-slope source from the neighbour-side reconstructed values (:323-325)
-	const T sx = -1 * g * ((fE.eta_nb + fW.eta_nb) / 2) * ((fE.zb_nb - fW.zb_nb) / dx);
-	const T sy = -1 * g * ((fN.eta_nb + fS.eta_nb) / 2) * ((fN.zb_nb - fS.zb_nb) / dx);
-
-	T d0 = (fE.f0 - fW.f0) / dx + (fN.f0 - fS.f0) / dx - T(0);      // :328-336
-	T d2 = (fE.fx - fW.fx) / dx + (fN.fx - fS.fx) / dx - sx;
-	T d3 = (fE.fy - fW.fy) / dx + (fN.fy - fS.fy) / dx - sy;
+	T d0, d2, d3;
+	if (STRICT) {
+		// bed-slope source from the neighbour-side reconstructed values (:323-325)
+		const T sx = -1 * g * ((fE.eta_nb + fW.eta_nb) / 2) * ((fE.zb_nb - fW.zb_nb) / dx);
+		const T sy = -1 * g * ((fN.eta_nb + fS.eta_nb) / 2) * ((fN.zb_nb - fS.zb_nb) / dx);
+		d0 = (fE.f0 - fW.f0) / dx + (fN.f0 - fS.f0) / dx - T(0);      // :328-336
+		d2 = (fE.fx - fW.fx) / dx + (fN.fx - fS.fx) / dx - sx;
+		d3 = (fE.fy - fW.fy) / dx + (fN.fy - fS.fy) / dx - sy;
+	} else {
+		// dx == dy: one multiplication by 1/dx per component instead of eight divisions
+		const T hg = T(0.5) * g;
+		const T sxd = hg * (fE.eta_nb + fW.eta_nb) * (fE.zb_nb - fW.zb_nb);      // = -sx * dx
+		const T syd = hg * (fN.eta_nb + fS.eta_nb) * (fN.zb_nb - fS.zb_nb);
+		d0 = ((fE.f0 - fW.f0) + (fN.f0 - fS.f0)) * inv_dx;
+		d2 = ((fE.fx - fW.fx) + (fN.fx - fS.fx) + sxd) * inv_dx;
+		d3 = ((fE.fy - fW.fy) + (fN.fy - fS.fy) + syd) * inv_dx;
+	}
 	d0 = small_to_zero(d0, vs);
 	d2 = small_to_zero(d2, vs);
 	d3 = small_to_zero(d3, vs);
@@ -301,17 +390,22 @@ __device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, con
 }
 
 // Wave speed of one cell for the CFL reduction (CLDynamicTimestep.clc:185-216)
-template <typename T>
+template <bool STRICT, typename T>
 __device__ __forceinline__ T cfl_speed(const T z, const T zmax, const T qx, const T qy, const T zb, const T qs)
 {
 	const T h = z - zb;
 	if (h > qs && zmax > T(-9999.0)) {
-		T vx = qx / h, vy = qy / h;
-		if (vx < T(0)) vx = -vx;
-		if (vy < T(0)) vy = -vy;
-		const T a = sqrt_(gravity<T>() * h);
-		vx += a; vy += a;
-		return (vx < vy) ? vy : vx;
+		if (STRICT) {
+			T vx = qx / h, vy = qy / h;
+			if (vx < T(0)) vx = -vx;
+			if (vy < T(0)) vy = -vy;
+			const T a = sqrt_(gravity<T>() * h);
+			vx += a; vy += a;
+			return (vx < vy) ? vy : vx;
+		} else {
+			const T inv = rcp_fast(h);
+			return fmax_(fabs_(qx), fabs_(qy)) * inv + sqrt_fast(gravity<T>() * h);
+		}
 	}
 	return T(0);
 }
