@@ -36,11 +36,41 @@ def grid_for(n_gpus, cols, rows):
     return 4096, 4096 * n_gpus
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the flux kernel from the newest committed PMC summary (profiles/*_pmc.json,
+    produced by tools/profile_bench.sh + tools/summarize_profile.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        vals = [k["hbm_bytes_per_launch"] for name, k in d.get("kernels", {}).items()
+                if kernel_substr in name and "hbm_bytes_per_launch" in k]
+        if vals:
+            best = (sum(vals) / len(vals), os.path.basename(f))
+    return best
+
+
+def usable_cores():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota
+    (the GPU boxes expose 256 hardware threads behind a 16-CPU quota; oversubscribing it is 10x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(cols, precision, scheme, budget_s=12.0):
     """Plain-C oracle (kind "port"), OpenMP over rows on all host cores, on a bounded strip of the same workload."""
     import oracle
     from hipims_mi import synthetic as syn
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     rows = 512
     real = np.float64 if precision == "f64" else np.float32
     st, bed, man = syn.s_dam(cols, rows, dtype=real)
@@ -104,7 +134,7 @@ def main():
 
     runner.step(args.warmup)
     runner.barrier()
-    runner.domain.kernel_timing(max(1, args.steps // 50))
+    runner.domain.kernel_timing(max(1, args.steps // 50) | 1)      # odd stride: both CFL flavours of the kernel get sampled
     t0 = time.perf_counter()
     runner.step(args.steps)
     runner.barrier()
@@ -133,6 +163,14 @@ def main():
                          "kernel": runner.flux_kernel_name, "avg_launch_ms": k_ms, "launches_sampled": k_n,
                          "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": cells_per_launch},
         }
+        default_cfg = (cols, rows) == (4096, 4096) and args.precision == "f64" and args.kernel == "auto" \
+            and args.math == "fast" and world == 1
+        if default_cfg:
+            tr = pmc_traffic("godunov_march<false" if args.scheme == "godunov" else "muscl_march<false")
+            if tr:
+                out["roofline"]["traffic"] = tr[0] / 1e9 / (k_ms * 1e-3) if k_ms > 0 else None   # GB/s, same unit as achieved
+                out["roofline"]["traffic_bytes_per_launch"] = tr[0]
+                out["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cols, args.precision,
                                                0 if args.scheme == "godunov" else 1)
