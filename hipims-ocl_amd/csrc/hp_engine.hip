@@ -55,6 +55,7 @@ struct hp_domain {
 	bool             edge_dirty = true;               // edge-ring maxima must be re-priced
 	int              adv_fresh = 1;                   // does hp_step_end's advance kernel read a new maximum?
 	int              march_rseg = 16;                 // rows per wavefront tile of godunov_march
+	int              muscl_rseg = 32;                 // ... of muscl_march (two warm-up rows per tile)
 	void*            host_scalars = nullptr;          // pinned mirror
 	int              use_alt = 0;                     // bUseAlternateKernel
 	bool             in_step = false;
@@ -130,15 +131,36 @@ template <typename T> int price_edge_ring(hp_domain* d)
 {
 	const Params<T> p = make_params<T>(d);
 	HIP_TRY(hipMemsetAsync((T*)d->cfl_slot + 2, 0, 2 * sizeof(T), d->stream));
-	const long south = (d->desc.row_offset == 0) ? 0 : -1;
-	const long north = (d->desc.row_offset + d->desc.rows == d->desc.global_rows) ? d->desc.rows - 1 : -1;
+	const int w = (d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK) ? 2 : 1;
+	const bool at_south = d->desc.row_offset == 0;
+	const bool at_north = d->desc.row_offset + d->desc.rows == d->desc.global_rows;
+	const long south = at_south ? 0 : -1;
+	const long north = at_north ? d->desc.rows - w : -1;
 	// side columns of the owned rows, minus the rows already covered by south/north
-	const long lo = d->own_lo + (south >= 0 ? 1 : 0), hi = d->own_hi - (north >= 0 ? 1 : 0);
+	const long lo = d->own_lo + (at_south ? w : 0), hi = d->own_hi - (at_north ? w : 0);
 	for (int b = 0; b < 2; ++b)
 		hipLaunchKernelGGL(cfl_edge_ring<T>, dim3(64), dim3(256), 0, d->stream, p, (const State4<T>*)d->state[b],
-		                   (const T*)d->bed, lo, hi, south, north, (T*)d->cfl_slot + 2 + b);
+		                   (const T*)d->bed, lo, hi, south, north, w, (T*)d->cfl_slot + 2 + b);
 	HIP_TRY(hipGetLastError());
 	d->edge_dirty = false;
+	return HP_OK;
+}
+
+template <typename T, bool STRICT, int CFL_MODE>
+int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer)
+{
+	const Params<T> p = make_params<T>(d);
+	const int rseg = d->muscl_rseg;
+	const int nstrips = (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS);
+	const int groups = (nstrips + 3) / 4;
+	const int nsegs = (int)((p.rows - 4 + rseg - 1) / rseg);
+	const int ntiles = groups * nsegs;
+	const unsigned blocks = (unsigned)((ntiles + 7) / 8) * 8;
+	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, d->stream, p,
+	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + 2 + edge_buffer,
+	                   (State4<T>*)d->sink, rseg, nstrips, groups, ntiles);
+	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
 
@@ -163,8 +185,11 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer)
 template <typename T, bool STRICT> int launch_flux(hp_domain* d, const void* src, void* dst, int cfl_mode)
 {
 	const Params<T> p = make_params<T>(d);
-	if (d->desc.scheme != HP_SCHEME_GODUNOV)
-		return fail(HP_ERR_UNSUPPORTED, "MUSCL-Hancock kernel not built yet");
+	if (d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK) {
+		if (p.cols < 5 || p.rows < 5) return fail(HP_ERR_INVALID, "MUSCL-Hancock needs at least a 5x5 grid");
+		return cfl_mode ? launch_muscl<T, STRICT, 1>(d, src, dst, d->use_alt ^ 1)
+		                : launch_muscl<T, STRICT, 0>(d, src, dst, 0);
+	}
 	if (d->desc.kernel == HP_KERNEL_BASIC) {
 		const dim3 block(64, 4), grid = grid2d(p.cols, p.rows, block);
 		hipLaunchKernelGGL((godunov_basic<STRICT, T>), grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars,
@@ -193,11 +218,14 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	// Which buffer does the CFL reduction price?  Q1: always the primary one (CSchemeGodunov.cpp:1629/:1634);
 	// otherwise what this iteration writes.
 	const bool q1 = (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0;
-	const bool basic = d->desc.kernel == HP_KERNEL_BASIC;
+	const bool muscl = d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK;
+	const bool basic = d->desc.kernel == HP_KERNEL_BASIC && !muscl;
 	const bool dst_is_primary = d->use_alt == 1;
 	int cfl_mode = 0;                                    // fused epilogue of the tuned kernel
 	if (d->desc.dynamic_dt && !basic) {
-		if (!q1 || dst_is_primary) cfl_mode = 1;         // price what lands in dst
+		// MUSCL-Hancock has ONE state buffer in the reference (updated in place), so its reduction always sees
+		// the new state: here that is dst, whichever physical buffer it is
+		if (muscl || !q1 || dst_is_primary) cfl_mode = 1; // price what lands in dst
 		else if (has_bdy)          cfl_mode = 2;         // primary = source, changed in place by the boundaries
 		else                       cfl_mode = 0;         // primary untouched: last maximum still holds
 		if (cfl_mode != 0 && d->edge_dirty)
@@ -375,6 +403,10 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 32) d->march_rseg = v;
+	}
+	if (const char* e = std::getenv("HP_MUSCL_RSEG")) {
+		const int v = std::atoi(e);
+		if (v >= 1 && v <= 4096) d->muscl_rseg = v;
 	}
 
 	auto cleanup = [&](int code) { hp_domain_destroy(d); return code; };

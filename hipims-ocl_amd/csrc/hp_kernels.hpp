@@ -215,24 +215,169 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	}
 }
 
-// max wave speed over the edge ring (cells no kernel ever writes): x = 0, x = cols-1 on rows [row_lo,row_hi)
-// plus whole rows `south`/`north` when >= 0.  Priced once per upload into *edge_max.
+// -------------------------------------------------------------------------------------------------
+// K2  muscl_march : MUSCL-Hancock (MINMOD) predictor + HLLC corrector in ONE pass, double buffered.
+//
+//  Replaces mch_1st_cacheNone/cachePrediction + mch_2nd_cacheNone / mch_cacheMaximum
+//  (CLSchemeMUSCLHancock.clc:28-296, :533-1114) and their four 32 B/cell face buffers: the predictor's face states
+//  live only in registers.  Same wavefront-marching scheme as K1 with a 2-cell halo: lanes 0,1,62,63 are halo
+//  lanes (60 updated columns per wave), the predictor runs one row ahead of the corrector, and each segment starts
+//  with two extra predictor rows.  Each corrector face is solved once and finished for both adjacent cells.
+//  Unlike the reference's in-place corrector (whose result depends on work-item order, quirk Q6) the update reads
+//  `src` and writes `dst`; cells the reference leaves untouched are copied.
+// -------------------------------------------------------------------------------------------------
+constexpr int MUSCL_COLS = 60;
+
+template <typename T>
+__device__ __forceinline__ Raw<T> raw_of(const RowRegs<T>& r) { return Raw<T>{r.c.z, r.c.zmax, r.c.qx, r.c.qy, r.zb}; }
+
+template <typename T>
+__device__ __forceinline__ Raw<T> shfl_raw(const Raw<T>& r, const int src_lane)
+{
+	return Raw<T>{__shfl(r.z, src_lane, 64), __shfl(r.zmax, src_lane, 64), __shfl(r.qx, src_lane, 64),
+	              __shfl(r.qy, src_lane, 64), __shfl(r.zb, src_lane, 64)};
+}
+
+template <bool STRICT, int CFL_MODE, typename T>
+__global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scalars<T>* __restrict__ sc,
+                                                   const T* __restrict__ bed, const State4<T>* __restrict__ src,
+                                                   State4<T>* __restrict__ dst, const T* __restrict__ manning,
+                                                   T* __restrict__ cfl_slot, const T* __restrict__ edge_max,
+                                                   State4<T>* __restrict__ sink, const int rseg, const int nstrips,
+                                                   const int groups, const int ntiles)
+{
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	if (tile >= (unsigned)ntiles) return;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const long strip = (long)(tile % (unsigned)groups) * 4 + wave;
+	const long seg = tile / (unsigned)groups;
+	if (strip >= nstrips) return;
+
+	const long x = strip * MUSCL_COLS + lane;
+	const long y0 = 2 + seg * rseg;                                                // corrector domain 2..n-3 (:569-573)
+	const long y1 = (y0 + rseg < p.rows - 2) ? (y0 + rseg) : (p.rows - 2);
+	const long xc = (x < p.cols) ? x : (p.cols - 1);
+	const bool out_x = lane >= 2 && lane <= MUSCL_COLS + 1 && x <= p.cols - 3;
+	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
+
+	const T dt = sc->dt, vs = p.vs;
+	const bool skip_step = dt <= T(0);                                             // :576-577, :69-70
+	const bool with_friction = p.friction != 0;
+	T vmax = T(0);
+
+	auto load_row = [&](const long y) {
+		RowRegs<T> r;
+		const size_t id = (size_t)y * p.cols + xc;
+		r.c = src[id]; r.zb = bed[id]; r.n = manning[id];
+		return r;
+	};
+	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w) {
+		const Raw<T> c = raw_of(mid);
+		const Raw<T> e = shfl_raw(c, lane_e), w = shfl_raw(c, lane_w);
+		dry_e = e.zmax < vs;                                                       // :633 tests Zmax, not depth (Q6)
+		dry_w = w.zmax < vs;
+		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs);
+	};
+
+	RowRegs<T> rs2 = load_row(y0 - 2);
+	RowRegs<T> rs = load_row(y0 - 1);
+	RowRegs<T> rc = load_row(y0);
+	RowRegs<T> rn = load_row(y0 + 1);                                              // y0+1 <= rows-2
+	RowRegs<T> rnn = load_row((y0 + 2 < p.rows) ? (y0 + 2) : (p.rows - 1));
+
+	Faces<T> pc = {};
+	FaceFlux<T> fS = {};
+	bool dryE = false, dryW = false;
+	if (!skip_step) {
+		bool de, dw;
+		const Faces<T> ps = predict(rs2, rs, rc, de, dw);
+		pc = predict(rs, rc, rn, dryE, dryW);
+		const Side<T> sS = side_from_face<STRICT>(ps.n, rs.c.qx, rs.c.qy, vs);
+		const Side<T> sC = side_from_face<STRICT>(pc.s, rc.c.qx, rc.c.qy, vs);
+		fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
+	}
+	bool dryS = rs.c.zmax < vs;
+
+	for (long y = y0; y < y1; ++y) {
+		const size_t id = (size_t)y * p.cols + xc;
+		const RowRegs<T> rn3 = load_row((y + 3 < p.rows) ? (y + 3) : (p.rows - 1));   // prefetch (clamped)
+		State4<T> out = rc.c;
+
+		if (!skip_step) {
+			// predictor of the next row (needs rows y, y+1, y+2)
+			bool dryE_n, dryW_n;
+			const Faces<T> pn = predict(rc, rn, rnn, dryE_n, dryW_n);
+
+			// east face: my E-face state against the east neighbour's W-face state
+			const Side<T> sE_mine = side_from_face<STRICT>(pc.e, rc.c.qx, rc.c.qy, vs);
+			const Side<T> sW_mine = side_from_face<STRICT>(pc.w, rc.c.qx, rc.c.qy, vs);
+			const Side<T> sE_nb = shfl_side(sW_mine, lane_e);
+			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sE_mine, sE_nb, vs);
+			const FaceFlux<T> fE = fx.forL, forW = fx.forR;
+			FaceFlux<T> fW;
+			fW.f0 = __shfl(forW.f0, lane_w, 64); fW.fx = __shfl(forW.fx, lane_w, 64);
+			fW.fy = __shfl(forW.fy, lane_w, 64); fW.eta_nb = __shfl(forW.eta_nb, lane_w, 64);
+			fW.zb_nb = __shfl(forW.zb_nb, lane_w, 64);
+			fW.stop = __shfl((int)forW.stop, lane_w, 64) != 0;
+
+			// north face: my N-face state against the north neighbour's S-face state
+			const Side<T> sN_mine = side_from_face<STRICT>(pc.n, rc.c.qx, rc.c.qy, vs);
+			const Side<T> sN_nb = side_from_face<STRICT>(pn.s, rn.c.qx, rn.c.qy, vs);
+			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sN_mine, sN_nb, vs);
+			const FaceFlux<T> fN = fy.forL;
+
+			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :594-595
+			const bool dryC = (rc.c.z - rc.zb) < vs;                                  // :597-598
+			const bool dryN = rn.c.zmax < vs;
+			const bool dry5 = dryC && dryN && dryE && dryS && dryW;                   // :638
+			const State4<T> upd = godunov_update<STRICT, true>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx,
+			                                                    vs, with_friction);
+			if (!disabled && !dry5) out = upd;
+
+			fS = fy.forR;
+			dryS = rc.c.zmax < vs;
+			dryE = dryE_n; dryW = dryW_n;
+			pc = pn;
+		}
+
+		State4<T>* const target = out_x ? (dst + id) : (sink + lane);
+		*target = out;
+		if (CFL_MODE == 1 && out_x) {
+			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
+			if (s > vmax) vmax = s;
+		}
+		rs = rc; rc = rn; rn = rnn; rnn = rn3;
+	}
+
+	if (CFL_MODE != 0) {
+		if (tile == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
+		vmax = wave_max(vmax);
+		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
+	}
+}
+
+// max wave speed over the edge ring (cells no kernel ever writes): the `w` outermost columns on rows
+// [row_lo,row_hi) plus the `w` outermost rows at the global south / north end when this strip holds them
+// (south / north = first such local row, or -1).  w = 1 (Godunov) or 2 (MUSCL-Hancock).  Priced once per upload.
 template <typename T>
 __global__ __launch_bounds__(256) void cfl_edge_ring(const Params<T> p, const State4<T>* __restrict__ state,
                                                      const T* __restrict__ bed, const long row_lo, const long row_hi,
-                                                     const long south, const long north, T* __restrict__ edge_max)
+                                                     const long south, const long north, const int w,
+                                                     T* __restrict__ edge_max)
 {
-	const long n_side = row_hi - row_lo;
-	const long total = 2 * n_side + (south >= 0 ? p.cols : 0) + (north >= 0 ? p.cols : 0);
+	const long n_side = (row_hi - row_lo) * w;
+	const long n_row = (long)w * p.cols;
+	const long total = 2 * n_side + (south >= 0 ? n_row : 0) + (north >= 0 ? n_row : 0);
 	T m = T(0);
 	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
 		long x, y;
-		if (i < n_side) { x = 0; y = row_lo + i; }
-		else if (i < 2 * n_side) { x = p.cols - 1; y = row_lo + (i - n_side); }
+		if (i < n_side) { x = i % w; y = row_lo + i / w; }
+		else if (i < 2 * n_side) { const long j = i - n_side; x = p.cols - 1 - (j % w); y = row_lo + j / w; }
 		else {
 			long j = i - 2 * n_side;
-			if (south >= 0 && j < p.cols) { x = j; y = south; }
-			else { if (south >= 0) j -= p.cols; x = j; y = north; }
+			if (south >= 0 && j < n_row) { x = j % p.cols; y = south + j / p.cols; }
+			else { if (south >= 0) j -= n_row; x = j % p.cols; y = north + j / p.cols; }
 		}
 		const size_t id = (size_t)y * p.cols + x;
 		const State4<T> c = state[id];

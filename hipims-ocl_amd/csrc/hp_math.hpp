@@ -348,7 +348,7 @@ __device__ __forceinline__ T small_to_zero(const T v, const T vs)
 
 // Godunov cell update from its four finished faces (CLSchemeGodunov.clc:321-383).
 // Returns the new state; `c` holds {Z, Zmax, Qx, Qy} of the cell before the step.
-template <bool STRICT, typename T>
+template <bool STRICT, bool CLAMP_FIRST = false, typename T>
 __device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, const T n, const T dt,
                                                     const FaceFlux<T>& fN, const FaceFlux<T>& fE,
                                                     const FaceFlux<T>& fS, const FaceFlux<T>& fW,
@@ -384,9 +384,134 @@ __device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, con
 
 	if (with_friction) friction<STRICT>(c.qx, c.qy, c.z, zb, n, dt, vs);          // :362-372
 
-	if (c.z > c.zmax && c.zmax > T(-9990.0)) c.zmax = c.z;           // :375-376
-	if (c.z - zb < vs) c.z = zb;                                     // :379-380
+	if (CLAMP_FIRST) {                                               // mch_2nd_cacheNone order (MUSCL :791-796)
+		if (c.z - zb < vs) c.z = zb;
+		if (c.z > c.zmax && c.zmax > T(-9990.0)) c.zmax = c.z;
+	} else {
+		if (c.z > c.zmax && c.zmax > T(-9990.0)) c.zmax = c.z;       // :375-376
+		if (c.z - zb < vs) c.z = zb;                                 // :379-380
+	}
 	return c;
+}
+
+// =================================================================================================
+//  MUSCL-Hancock (Schemes/CLSchemeMUSCLHancock.clc, Schemes/Limiters/CLSlopeLimiterMINMOD.clc)
+// =================================================================================================
+template <typename T> struct Face4 { T z, h, qx, qy; };              // extrapolated face state {Z, H, Qx, Qy}
+template <typename T> struct Faces { Face4<T> n, e, s, w; };
+template <typename T> struct Raw { T z, zmax, qx, qy, zb; };         // what a neighbour contributes
+
+// calculateLimitedSlope (CLSlopeLimiterMINMOD.clc:51-72), MINBEE_BETA = 1 -> MINMOD
+template <bool STRICT, typename T>
+__device__ __forceinline__ T limited_slope(const T l, const T c, const T r)
+{
+	const T dL = c - l, dR = r - c;
+	if (STRICT) {
+		const T rr = (fabs_(dL) <= T(0) ? T(0) : (dR / dL));
+		return fmax_(fmax_(T(0), fmin_(T(1) * rr, T(1))), fmin_(rr, T(1))) * dL;
+	}
+	// clamp(dR/dL, 0, 1) * dL without the division: 0 if the differences disagree in sign, else the smaller one
+	return (dL * dR <= T(0)) ? T(0) : ((fabs_(dR) < fabs_(dL)) ? dR : dL);
+}
+
+// slopeLimiter (:26-46): no slopes on a wet-dry front
+template <bool STRICT, typename T>
+__device__ __forceinline__ Face4<T> limiter(const Raw<T>& l, const Raw<T>& c, const Raw<T>& r, const T vs)
+{
+	Face4<T> s;
+	if ((l.z - l.zb) < vs || (r.z - r.zb) < vs) { s.z = s.h = s.qx = s.qy = T(0); return s; }
+	s.z  = limited_slope<STRICT>(l.z, c.z, r.z);
+	s.h  = limited_slope<STRICT>(l.z - l.zb, c.z - c.zb, r.z - r.zb);
+	s.qx = limited_slope<STRICT>(l.qx, c.qx, r.qx);
+	s.qy = limited_slope<STRICT>(l.qy, c.qy, r.qy);
+	return s;
+}
+
+// faceExtrapolate (CLSchemeMUSCLHancock.clc:389-403); `c.h` is unused: H is rebuilt from Z - zb
+template <typename T>
+__device__ __forceinline__ Face4<T> face_extrapolate(const T zb, const Face4<T>& c, const Face4<T>& slope, const T coef)
+{
+	Face4<T> f;
+	f.z = c.z + coef * slope.z;
+	f.h = (c.z - zb) + coef * slope.h;
+	f.qx = c.qx + coef * slope.qx;
+	f.qy = c.qy + coef * slope.qy;
+	return f;
+}
+
+// mch_1st (:301-382): limited slopes, face extrapolation, half-step evolution, re-extrapolation
+template <bool STRICT, typename T>
+__device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>& n, const Raw<T>& e, const Raw<T>& s,
+                                                  const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs)
+{
+	const T g = gravity<T>();
+	Face4<T> cc; cc.z = c.z; cc.h = c.z - c.zb; cc.qx = c.qx; cc.qy = c.qy;           // :333
+	Faces<T> f; f.n = cc; f.e = cc; f.s = cc; f.w = cc;
+	const bool first = (c.z - c.zb < T(1E-5)) || n.zmax <= T(-9998.0) || e.zmax <= T(-9998.0) ||
+	                   s.zmax <= T(-9998.0) || w.zmax <= T(-9998.0);                    // :325-330
+	if (first) return f;
+
+	const Face4<T> sx = limiter<STRICT>(w, c, e, vs), sy = limiter<STRICT>(s, c, n, vs);   // :343-346
+	f.n = face_extrapolate(c.zb, cc, sy, T(+0.5));                                         // :349-352
+	f.e = face_extrapolate(c.zb, cc, sx, T(+0.5));
+	f.s = face_extrapolate(c.zb, cc, sy, T(-0.5));
+	f.w = face_extrapolate(c.zb, cc, sx, T(-0.5));
+
+	// estimateFluxVectorX / Y (:420-471): FSL form with zb = Z - H
+	auto press = [&](const Face4<T>& a) { return T(0.5) * g * ((a.z * a.z) - 2 * (a.z - a.h) * a.z); };
+	auto vel = [&](const T q, const T h) { return STRICT ? (h < vs ? T(0) : q / h) : (h < vs ? T(0) : q * rcp_fast(h)); };
+	const T uE = vel(f.e.qx, f.e.h), uW = vel(f.w.qx, f.w.h), vN = vel(f.n.qy, f.n.h), vS = vel(f.s.qy, f.s.h);
+	const T FE0 = f.e.qx, FE1 = uE * f.e.qx + press(f.e), FE2 = uE * f.e.qy;
+	const T FW0 = f.w.qx, FW1 = uW * f.w.qx + press(f.w), FW2 = uW * f.w.qy;
+	const T FN0 = f.n.qy, FN1 = vN * f.n.qx, FN2 = vN * f.n.qy + press(f.n);
+	const T FS0 = f.s.qy, FS1 = vS * f.s.qx, FS2 = vS * f.s.qy + press(f.s);
+
+	// evolveCellState (:476-526)
+	T d0, d2, d3;
+	if (STRICT) {
+		const T s1 = -1 * g * ((f.e.z + f.w.z) / 2) * (((f.e.z - f.e.h) - (f.w.z - f.w.h)) / dx);
+		const T s2 = -1 * g * ((f.n.z + f.s.z) / 2) * (((f.n.z - f.n.h) - (f.s.z - f.s.h)) / dx);
+		d0 = (FE0 - FW0) / dx + (FN0 - FS0) / dx - T(0);
+		d2 = (FE1 - FW1) / dx + (FN1 - FS1) / dx - s1;
+		d3 = (FE2 - FW2) / dx + (FN2 - FS2) / dx - s2;
+	} else {
+		const T hg = T(0.5) * g;
+		const T s1d = hg * (f.e.z + f.w.z) * ((f.e.z - f.e.h) - (f.w.z - f.w.h));
+		const T s2d = hg * (f.n.z + f.s.z) * ((f.n.z - f.n.h) - (f.s.z - f.s.h));
+		d0 = ((FE0 - FW0) + (FN0 - FS0)) * inv_dx;
+		d2 = ((FE1 - FW1) + (FN1 - FS1) + s1d) * inv_dx;
+		d3 = ((FE2 - FW2) + (FN2 - FS2) + s2d) * inv_dx;
+	}
+	d0 = small_to_zero(d0, vs);
+	d2 = small_to_zero(d2, vs);
+	d3 = small_to_zero(d3, vs);
+	cc.z  = cc.z  - T(0.5) * dt * d0;
+	cc.qx = cc.qx - T(0.5) * dt * d2;
+	cc.qy = cc.qy - T(0.5) * dt * d3;
+
+	f.n = face_extrapolate(c.zb, cc, sy, T(+0.5));                                         // :376-379
+	f.e = face_extrapolate(c.zb, cc, sx, T(+0.5));
+	f.s = face_extrapolate(c.zb, cc, sy, T(-0.5));
+	f.w = face_extrapolate(c.zb, cc, sx, T(-0.5));
+	return f;
+}
+
+// One side of a corrector face: the extrapolated face state + the RAW cell discharges the stopping conditions
+// test (2nd-order reconstructInterface, CLSchemeMUSCLHancock.clc:1119-1230; note `<=` in the velocity guard)
+template <bool STRICT, typename T>
+__device__ __forceinline__ Side<T> side_from_face(const Face4<T>& f, const T qx_raw, const T qy_raw, const T vs)
+{
+	Side<T> s;
+	s.eta = f.z; s.zb = f.z - f.h; s.qx = qx_raw; s.qy = qy_raw;
+	if (STRICT) {
+		s.u0 = (f.h <= vs ? T(0) : f.qx / f.h);
+		s.v0 = (f.h <= vs ? T(0) : f.qy / f.h);
+	} else {
+		const T inv = (f.h <= vs ? T(0) : rcp_fast(f.h));
+		s.u0 = f.qx * inv;
+		s.v0 = f.qy * inv;
+	}
+	return s;
 }
 
 // Wave speed of one cell for the CFL reduction (CLDynamicTimestep.clc:185-216)
