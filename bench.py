@@ -104,12 +104,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import hipims_mi as hp
-    from hipims_mi import synthetic as syn
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        # single GPU needs no collectives: keep torch (and its bundled, older HIP runtime) out of the process
+        os.environ.setdefault("HIPIMS_MI_NO_TORCH", "1")
+    import hipims_mi as hp
+    from hipims_mi import synthetic as syn
+
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cols, rows = grid_for(world, args.cols, args.rows)

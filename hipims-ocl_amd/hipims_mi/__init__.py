@@ -69,6 +69,16 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # One HIP runtime per process.  torch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's): if
+    # torch initialises AFTER this library has pulled in the system runtime, the process ends up with two
+    # runtimes and torch sees no GPU.  Loading torch first makes the dynamic loader bind this library to torch's
+    # copy, so device pointers and streams can be shared with torch.distributed (RCCL).  Set
+    # HIPIMS_MI_NO_TORCH=1 for a torch-free process (then the system runtime is used).
+    if os.environ.get("HIPIMS_MI_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise HipimsError(f"{path} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           f"(make -C hipims-ocl_amd/csrc); there is no CPU fallback")

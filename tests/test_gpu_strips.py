@@ -1,0 +1,116 @@
+"""Strip decomposition on real hardware (one GPU): two/three strip domains of ONE grid live on the same device, the
+StripRunner protocol is driven by hand with device-to-device copies standing in for RCCL send/recv, and the result
+must be bit-identical to the single-domain run.  Also exercises the torch plumbing the multi-GPU bench relies on
+(zero-copy tensor views of the engine's buffers, ExternalStream ordering, a 1-rank NCCL all-reduce)."""
+import os
+
+import numpy as np
+import pytest
+
+import hipims_mi as hp
+from hipims_mi import strips, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def run_strips(cols, rows, nstrips, scheme, steps, st, bed, man, rain=None, **kw):
+    import torch
+    g = strips.ghost_rows(scheme)
+    parts = strips.partition(rows, nstrips, g)
+    engines = []
+    for own_lo, own_hi, lo, hi in parts:
+        e = strips.HipEngine(cols, hi - lo, rows, lo, scheme=scheme, **kw)
+        e.upload(st[lo:hi], bed[lo:hi], man[lo:hi])
+        if rain is not None:
+            e.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, *rain)
+        e.set_target_time(1e9)
+        engines.append(e)
+    for _ in range(steps):
+        for e in engines:
+            e.step_begin()
+        for e in engines:
+            e.sync()
+        # halo: what StripRunner._exchange_halo sends/receives, as plain device copies
+        for k in range(nstrips - 1):
+            south, north = engines[k].new_state(), engines[k + 1].new_state()
+            n_s = south.shape[0]
+            north[0:g].copy_(south[n_s - 2 * g:n_s - g])
+            south[n_s - g:n_s].copy_(north[g:2 * g])
+        # all-reduce(MAX) of the wave speed
+        vmax = torch.stack([e.cfl_slot() for e in engines]).max()
+        for e in engines:
+            e.cfl_slot().fill_(vmax)
+        torch.cuda.synchronize()
+        for e in engines:
+            e.step_end()
+    out = np.concatenate([e.download()[own_lo - lo:own_hi - lo] for e, (own_lo, own_hi, lo, hi) in zip(engines, parts)])
+    sc = engines[0].scalars()
+    for e in engines:
+        assert e.scalars() == sc
+        e.close()
+    return out, sc
+
+
+@pytest.mark.parametrize("scheme,nstrips", [(hp.SCHEME_GODUNOV, 2), (hp.SCHEME_GODUNOV, 3), (hp.SCHEME_MUSCL_HANCOCK, 2)])
+def test_strips_are_bit_identical_to_single_domain(scheme, nstrips):
+    cols, rows, steps = 200, 96, 60
+    st, bed, man = syn.s_rough(cols, rows, manning=None)
+    single = hp.Domain(cols, rows, scheme=scheme)
+    single.upload(st, bed, man)
+    single.set_target_time(1e9)
+    single.step_batch(steps)
+    ref, sref = single.download(), single.read_scalars()
+    out, sc = run_strips(cols, rows, nstrips, scheme, steps, st, bed, man)
+    assert np.array_equal(out, ref)
+    assert sc["t"] == sref["time"] and sc["dt"] == sref["timestep"]
+
+
+def test_strips_with_gridded_rain_match_single_domain():
+    cols, rows, steps = 120, 90, 260
+    st, bed, man = syn.s_rough(cols, rows, pool_level=-10.0, amplitude=0.2, walls=False)
+    st[..., 2:] = 0
+    grids = np.random.default_rng(5).uniform(0, 120, (3, 6, 8))
+    rain = (grids, 16.0, 0.0, 0.0, 20.0)
+    single = hp.Domain(cols, rows)
+    single.upload(st, bed, man)
+    single.add_gridded(hp.GRIDDED_RAIN_INTENSITY, *rain)
+    single.set_target_time(1e9)
+    single.step_batch(steps)
+    ref = single.download()
+    assert (ref[..., 0] - bed).max() > 1e-5
+    out, _ = run_strips(cols, rows, 2, hp.SCHEME_GODUNOV, steps, st, bed, man, rain=rain)
+    assert np.array_equal(out, ref)
+
+
+def test_single_rank_nccl_runner_matches_batch_call():
+    """StripRunner over a 1-rank RCCL group: process-group init, ExternalStream, tensor views, all_reduce on the
+    engine's own CFL slot -- everything the N-GPU bench does except a second rank."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cols, rows, steps = 256, 128, 40
+    st, bed, man = syn.s_dam(cols, rows)
+    r = strips.StripRunner(cols, rows, rank=0, world=1)
+    try:
+        r.upload_global(st, bed, man)
+        r.set_target_time(1e9)
+        for _ in range(steps):                       # StripRunner.step with the collective forced on
+            r.engine.step_begin()
+            r._exchange_halo()
+            dist.all_reduce(r.engine.cfl_slot(), op=dist.ReduceOp.MAX)
+            r.engine.step_end()
+        r.barrier()
+        out = r.gather_owned()
+        assert r.max_over_ranks(1.5) == 1.5
+    finally:
+        r.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    single = hp.Domain(cols, rows)
+    single.upload(st, bed, man)
+    single.set_target_time(1e9)
+    single.step_batch(steps)
+    assert np.array_equal(out, single.download())
