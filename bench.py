@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--math", choices=["fast", "strict"], default="fast")
     ap.add_argument("--kernel", choices=["auto", "basic"], default="auto")
+    ap.add_argument("--workload", choices=["s-dam", "s-rain"], default="s-dam",
+                    help="s-dam: BASELINE configs[1..3]; s-rain: configs[4] (initially dry terrain + gridded rainfall, dx = 2 m)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,17 +123,24 @@ def main():
     kernel = hp.KERNEL_AUTO if args.kernel == "auto" else hp.KERNEL_BASIC
     real = np.float64 if args.precision == "f64" else np.float32
 
+    dx = 2.0 if args.workload == "s-rain" else 1.0
     if world == 1:
         from hipims_mi.strips import SingleRunner as Runner
-        runner = Runner(cols, rows, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
+        runner = Runner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
                         device=local_rank)
     else:
         from hipims_mi.strips import StripRunner as Runner
-        runner = Runner(cols, rows, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
+        runner = Runner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
                         device=local_rank, rank=rank, world=world)
 
-    st, bed, man = syn.s_dam(cols, runner.local_rows_total, dtype=real) if world == 1 else runner.make_s_dam(real)
-    runner.upload(st, bed, man)
+    if args.workload == "s-rain":
+        st, bed, man, rain = syn.s_rain_rows(cols, rows, runner.local_lo, runner.local_hi, dx=dx, dtype=real)
+        runner.upload(st, bed, man)
+        runner.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"],
+                                  rain["off_y"], rain["interval"])
+    else:
+        st, bed, man = syn.s_dam(cols, runner.local_rows_total, dtype=real) if world == 1 else runner.make_s_dam(real)
+        runner.upload(st, bed, man)
     del st, bed, man
     runner.set_target_time(1e9)
 
@@ -157,7 +166,8 @@ def main():
             "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"S-DAM flat-DEM dam-break {cols}x{rows}, {args.scheme}+HLLC, friction fused, "
+            "config": {"workload": f"{'S-RAIN gridded-rainfall on dry terrain' if args.workload == 's-rain' else 'S-DAM flat-DEM dam-break'} "
+                                   f"{cols}x{rows}, {args.scheme}+HLLC, friction fused, "
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
                        "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}",
                        "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},
@@ -167,6 +177,7 @@ def main():
                          "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": cells_per_launch},
         }
         default_cfg = (cols, rows) == (4096, 4096) and args.precision == "f64" and args.kernel == "auto" \
+            and args.workload == "s-dam" \
             and args.math == "fast" and world == 1
         if default_cfg:
             tr = pmc_traffic("godunov_march<false" if args.scheme == "godunov" else "muscl_march<false")

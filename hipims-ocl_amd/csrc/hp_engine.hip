@@ -97,7 +97,8 @@ template <typename T> int apply_boundaries(hp_domain* d, void* target)
 {
 	const Params<T> p = make_params<T>(d);
 	const bool truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
-	const dim3 block(64, 4), grid = grid2d(p.cols, p.rows, block);
+	size_t want = ((size_t)p.cols * p.rows + 255) / 256;
+	const dim3 block(256), grid((unsigned)(want < 1024 ? want : 1024));
 	for (const Boundary& b : d->bdy) {
 		if (b.kind == 0) {
 			UniformBdy<T> u{(const T*)b.data, (uint32_t)b.entries, b.definition, (T)b.interval, (T)b.length};

@@ -507,6 +507,9 @@ __device__ __forceinline__ bool bdy_in_range(const Params<T>& p, const long x, c
 	return true;
 }
 
+// Both kernels run on a small grid-stride grid: the hydrological gate (t_hydro >= 1 s, a device scalar the host
+// cannot see without a sync) is closed on most iterations, and a launch whose every wave exits after reading three
+// scalars must cost microseconds, not a 16 M-thread dispatch.
 template <typename T>
 __global__ __launch_bounds__(256) void bdy_uniform(const Params<T> p, const Scalars<T>* __restrict__ sc,
                                                    const UniformBdy<T> b, State4<T>* __restrict__ state,
@@ -515,17 +518,19 @@ __global__ __launch_bounds__(256) void bdy_uniform(const Params<T> p, const Scal
 	const T t = sc->t, dt_real = sc->dt, dt = sc->t_hydro;
 	if (dt < T(1.0) || dt_real <= T(0)) return;                                  // :165-166 (uniform over the grid)
 	if (t >= b.length) return;                                                    // :168
-	const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const long y = (long)blockIdx.y * blockDim.y + threadIdx.y;
-	if (y >= p.rows || !bdy_in_range(p, x, y + p.row_offset, truncated)) return;
-	const size_t id = (size_t)y * p.cols + x;
-	State4<T> c = state[id];
-	if (c.zmax <= T(-9999.0)) return;                                             // :168-169
 	const unsigned long ts = (unsigned long)floor_(t / b.interval);               // :172-173
 	const T rate = b.series[2 * ts + 1];
-	if (b.definition == 0) c.z += rate / T(3600000.0) * dt;                       // :176-177
-	if (b.definition == 1) c.z = fmax_(bed[id], c.z - rate / T(3600000.0) * dt);  // :179-180
-	state[id] = c;
+	const T amount = rate / T(3600000.0) * dt;
+	const size_t cells = (size_t)p.cols * p.rows;
+	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x) {
+		const long y = (long)(id / p.cols), x = (long)(id - (size_t)y * p.cols);
+		if (!bdy_in_range(p, x, y + p.row_offset, truncated)) continue;
+		State4<T> c = state[id];
+		if (c.zmax <= T(-9999.0)) continue;                                       // :168-169
+		if (b.definition == 0) c.z += amount;                                     // :176-177
+		if (b.definition == 1) c.z = fmax_(bed[id], c.z - amount);                // :179-180
+		state[id] = c;
+	}
 }
 
 template <typename T>
@@ -535,22 +540,23 @@ __global__ __launch_bounds__(256) void bdy_gridded(const Params<T> p, const Scal
 {
 	const T t = sc->t, dt = sc->t_hydro;
 	if (dt < T(1.0)) return;                                                      // :224-225
-	const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const long y = (long)blockIdx.y * blockDim.y + threadIdx.y;
-	const long gy = y + p.row_offset;
-	if (y >= p.rows || !bdy_in_range(p, x, gy, truncated)) return;
-	const size_t id = (size_t)y * p.cols + x;
-	State4<T> c = state[id];
-	if (c.zmax <= T(-9999.0) || c.z == T(-9999.0)) return;                        // :220-221
 	unsigned long ts = (unsigned long)floor_(t / b.interval);                     // :228
 	if (ts >= b.entries) ts = b.entries - 1;          // reference reads one slice past the end here (:229)
-	const T col = floor_((((T)x * p.dx) - b.off_x) / b.resolution);               // :231-232
-	const T row = floor_((((T)gy * p.dx) - b.off_y) / b.resolution);
-	const unsigned long cell = (b.grows * b.gcols) * ts + (b.gcols * (unsigned long)row) + (unsigned long)col;
-	const T rate = b.grids[cell];
-	if (b.definition == 0) c.z += rate / T(3600000.0) * dt;                       // :238-239
-	if (b.definition == 2) c.z += rate / (p.dx * p.dx) * dt;                      // :241-242
-	state[id] = c;
+	const size_t cells = (size_t)p.cols * p.rows;
+	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x) {
+		const long y = (long)(id / p.cols), x = (long)(id - (size_t)y * p.cols);
+		const long gy = y + p.row_offset;
+		if (!bdy_in_range(p, x, gy, truncated)) continue;
+		State4<T> c = state[id];
+		if (c.zmax <= T(-9999.0) || c.z == T(-9999.0)) continue;                  // :220-221
+		const T col = floor_((((T)x * p.dx) - b.off_x) / b.resolution);           // :231-232
+		const T row = floor_((((T)gy * p.dx) - b.off_y) / b.resolution);
+		const unsigned long cell = (b.grows * b.gcols) * ts + (b.gcols * (unsigned long)row) + (unsigned long)col;
+		const T rate = b.grids[cell];
+		if (b.definition == 0) c.z += rate / T(3600000.0) * dt;                   // :238-239
+		if (b.definition == 2) c.z += rate / (p.dx * p.dx) * dt;                  // :241-242
+		state[id] = c;
+	}
 }
 
 } // namespace hp

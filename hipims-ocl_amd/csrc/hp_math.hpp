@@ -330,8 +330,10 @@ __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, co
 		const T A = (dt * g) * (n * n) * (rc4 * rc2 * rc);   // h^(-7/3)
 		const T qx2 = qx * qx, qy2 = qy * qy;
 		const T num = -A * (qx2 + qy2);
-		T dqx = num * qx * rcp_fast(fma_(A, fma_(T(2), qx2, qy2), q));
-		T dqy = num * qy * rcp_fast(fma_(A, fma_(T(2), qy2, qx2), q));
+		const T denx = fma_(A, fma_(T(2), qx2, qy2), q), deny = fma_(A, fma_(T(2), qy2, qx2), q);
+		const T rxy = rcp_fast(denx * deny);                 // 1/denx = rxy*deny, 1/deny = rxy*denx
+		T dqx = num * qx * (rxy * deny);
+		T dqy = num * qy * (rxy * denx);
 		// friction can stop the flow, not reverse it (:52-65): dt*Fx limited to -qx
 		if (qx >= T(0)) dqx = fmax_(dqx, -qx); else dqx = fmin_(dqx, -qx);
 		if (qy >= T(0)) dqy = fmax_(dqy, -qy); else dqy = fmin_(dqy, -qy);
@@ -340,10 +342,11 @@ __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, co
 	}
 }
 
-template <typename T>
+template <bool STRICT = true, typename T>
 __device__ __forceinline__ T small_to_zero(const T v, const T vs)
 {
-	return ((v > T(0) && v < vs) || (v < T(0) && v > -vs)) ? T(0) : v;      // CLSchemeGodunov.clc:340-348
+	if (STRICT) return ((v > T(0) && v < vs) || (v < T(0) && v > -vs)) ? T(0) : v;      // CLSchemeGodunov.clc:340-348
+	return (fabs_(v) < vs) ? T(0) : v;                                   // same set of values, one compare
 }
 
 // Godunov cell update from its four finished faces (CLSchemeGodunov.clc:321-383).
@@ -372,9 +375,9 @@ __device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, con
 		d2 = ((fE.fx - fW.fx) + (fN.fx - fS.fx) + sxd) * inv_dx;
 		d3 = ((fE.fy - fW.fy) + (fN.fy - fS.fy) + syd) * inv_dx;
 	}
-	d0 = small_to_zero(d0, vs);
-	d2 = small_to_zero(d2, vs);
-	d3 = small_to_zero(d3, vs);
+	d0 = small_to_zero<STRICT>(d0, vs);
+	d2 = small_to_zero<STRICT>(d2, vs);
+	d3 = small_to_zero<STRICT>(d3, vs);
 
 	if (fN.stop || fE.stop || fS.stop || fW.stop) { c.qx = T(0); c.qy = T(0); }   // :351-355
 
@@ -482,9 +485,9 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 		d2 = ((FE1 - FW1) + (FN1 - FS1) + s1d) * inv_dx;
 		d3 = ((FE2 - FW2) + (FN2 - FS2) + s2d) * inv_dx;
 	}
-	d0 = small_to_zero(d0, vs);
-	d2 = small_to_zero(d2, vs);
-	d3 = small_to_zero(d3, vs);
+	d0 = small_to_zero<STRICT>(d0, vs);
+	d2 = small_to_zero<STRICT>(d2, vs);
+	d3 = small_to_zero<STRICT>(d3, vs);
 	cc.z  = cc.z  - T(0.5) * dt * d0;
 	cc.qx = cc.qx - T(0.5) * dt * d2;
 	cc.qy = cc.qy - T(0.5) * dt * d3;

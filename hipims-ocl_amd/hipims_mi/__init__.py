@@ -68,7 +68,7 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("HIPIMS_MI_LIB") or LIB_PATH       # HIPIMS_MI_LIB: kernel-variant experiments
     # One HIP runtime per process.  torch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's): if
     # torch initialises AFTER this library has pulled in the system runtime, the process ends up with two
     # runtimes and torch sees no GPU.  Loading torch first makes the dynamic loader bind this library to torch's

@@ -102,6 +102,7 @@ class SingleRunner:
     def __init__(self, cols, rows, **kw):
         self.domain = Domain(cols, rows, **kw)
         self.local_rows_total = rows
+        self.local_lo, self.local_hi = 0, rows
         self.flux_kernel_name = "hp::godunov_*"
 
     def upload(self, st, bed, man):

@@ -86,3 +86,25 @@ def newcastle_like(cols=342, rows=195, dtype=np.float64, seed=342195):
     state[..., 0] = bed
     state[..., 1] = bed
     return state.astype(dtype), bed.astype(dtype), np.full((rows, cols), 0.03, dtype)
+
+
+def s_rain_rows(cols, rows, row_lo, row_hi, dx=2.0, dtype=np.float32, seed=7, grid_cells=64, slices=13, interval=300.0):
+    """Rows [row_lo, row_hi) of S-RAIN for a `cols x rows` grid (strip-wise construction for large grids)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[row_lo:row_hi, 0:cols].astype(np.float64)
+    bed = round4(5.0 * 0.5 * np.sin(2 * np.pi * x / 37.0) * np.cos(2 * np.pi * y / 29.0)) + 10.0
+    n = row_hi - row_lo
+    state = np.zeros((n, cols, 4), np.float64)
+    state[..., 0] = bed
+    state[..., 1] = bed
+    bed[:, 0] = bed[:, -1] = WALL_BED
+    state[:, 0] = 0.0
+    state[:, -1] = 0.0
+    if row_lo == 0:
+        bed[0] = WALL_BED; state[0] = 0.0
+    if row_hi == rows:
+        bed[-1] = WALL_BED; state[-1] = 0.0
+    resolution = dx * max(cols, rows) / grid_cells
+    grids = rng.uniform(0.0, 120.0, (slices, grid_cells, grid_cells))
+    rain = dict(grids=grids.astype(dtype), resolution=resolution, off_x=0.0, off_y=0.0, interval=interval)
+    return state.astype(dtype), bed.astype(dtype), np.full((n, cols), 0.03, dtype), rain
