@@ -403,7 +403,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	d->esize = (size_t)desc->precision;
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
-		if (v >= 1 && v <= 32) d->march_rseg = v;
+		if (v >= 1 && v <= 128) d->march_rseg = v;
 	}
 	if (const char* e = std::getenv("HP_MUSCL_RSEG")) {
 		const int v = std::atoi(e);
@@ -574,6 +574,14 @@ int hp_set_target_time(hp_domain_t* d, double t)
 	                              : set_scalar_field<float>(d, offsetof(Scalars<float>, t_sync), t);
 }
 
+int hp_set_time(hp_domain_t* d, double t)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	return d->desc.precision == 8 ? set_scalar_field<double>(d, offsetof(Scalars<double>, t), t)
+	                              : set_scalar_field<float>(d, offsetof(Scalars<float>, t), t);
+}
+
 int hp_force_timestep(hp_domain_t* d, double dt)
 {
 	int rc = check_domain(d);
@@ -618,6 +626,14 @@ int hp_step_begin(hp_domain_t* d)
 	if (d->in_step) return fail(HP_ERR_STATE, "hp_step_begin called twice");
 	if ((rc = dispatch_begin(d)) != HP_OK) return rc;
 	d->in_step = true;
+	return HP_OK;
+}
+
+int hp_step_needs_reduction(hp_domain_t* d, int* needed)
+{
+	if (!d || !needed) return fail(HP_ERR_INVALID, "null argument");
+	if (!d->in_step) return fail(HP_ERR_STATE, "hp_step_needs_reduction outside a split step");
+	*needed = d->adv_fresh;
 	return HP_OK;
 }
 

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	const bool skip_step = dt <= T(0);                                             // CLSchemeGodunov.clc:201-206
 	const bool with_friction = p.friction != 0;
 	T vmax = T(0);
-	unsigned stale_rows = 0;       // bit i: row y0+i of this lane was left untouched (all-dry, Q3); rseg <= 32
+	unsigned long long stale_lo = 0, stale_hi = 0;   // bit i: row y0+i of this lane was left untouched (all-dry, Q3); rseg <= 128
 
 	auto load_row = [&](const long y) {
 		RowRegs<T> r;
@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			if (!disabled) {
 				if (dry5) {                                                               // dst untouched (Q3)
 					write = false;
-					if (out_x) stale_rows |= 1u << (unsigned)(y - y0);
+					if (out_x) {
+						const unsigned bit = (unsigned)(y - y0);
+						if (bit < 64) stale_lo |= 1ull << bit; else stale_hi |= 1ull << (bit - 64);
+					}
 				} else {
 					out = upd;
 				}
@@ -195,10 +198,11 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		rn = rnn;
 	}
 
-	if (CFL_MODE == 1 && __any(stale_rows != 0)) {
+	if (CFL_MODE == 1 && __any((stale_lo | stale_hi) != 0)) {
 		// cells the reference leaves untouched still hold their two-steps-old value in dst, and tst_Reduce prices it
 		for (long y = y0; y < y1; ++y) {
-			if (stale_rows & (1u << (unsigned)(y - y0))) {
+			const unsigned bit = (unsigned)(y - y0);
+			if ((bit < 64 ? (stale_lo >> bit) : (stale_hi >> (bit - 64))) & 1ull) {
 				const size_t id = (size_t)y * p.cols + xc;
 				const State4<T> c = dst[id];
 				const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);

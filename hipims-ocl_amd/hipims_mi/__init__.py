@@ -28,9 +28,9 @@ PTR_STATE_NEXT_SRC, PTR_STATE_OTHER, PTR_BED, PTR_MANNING, PTR_CFL_MAX, PTR_SCAL
 EXPORTS = [
     "hp_abi_version", "hp_device_count", "hp_device_info", "hp_last_error", "hp_domain_desc_default",
     "hp_domain_create", "hp_domain_destroy", "hp_domain_upload", "hp_domain_download", "hp_domain_upload_rows",
-    "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_clear", "hp_set_target_time",
+    "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_clear", "hp_set_target_time", "hp_set_time",
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
-    "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_device_ptr", "hp_stream", "hp_timer_start",
+    "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_timer_start",
     "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read",
 ]
 
@@ -97,6 +97,7 @@ def load_library(path: str | None = None):
     lib.hp_boundary_clear.argtypes = [C.c_void_p]
     lib.hp_set_target_time.argtypes = [C.c_void_p, C.c_double]
     lib.hp_force_timestep.argtypes = [C.c_void_p, C.c_double]
+    lib.hp_set_time.argtypes = [C.c_void_p, C.c_double]
     lib.hp_reset_counters.argtypes = [C.c_void_p]
     lib.hp_update_timestep.argtypes = [C.c_void_p]
     lib.hp_step_batch.argtypes = [C.c_void_p, C.c_uint32]
@@ -105,6 +106,7 @@ def load_library(path: str | None = None):
     lib.hp_is_busy.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.hp_step_begin.argtypes = [C.c_void_p]
     lib.hp_step_end.argtypes = [C.c_void_p]
+    lib.hp_step_needs_reduction.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.hp_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.hp_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.hp_timer_start.argtypes = [C.c_void_p]
@@ -244,6 +246,9 @@ class Domain:
 
     set_target = set_target_time
 
+    def set_time(self, t):
+        _check(self.lib, self.lib.hp_set_time(self.h, t), "hp_set_time")
+
     def force_timestep(self, dt):
         _check(self.lib, self.lib.hp_force_timestep(self.h, dt), "hp_force_timestep")
 
@@ -261,6 +266,11 @@ class Domain:
 
     def step_end(self):
         _check(self.lib, self.lib.hp_step_end(self.h), "hp_step_end")
+
+    def step_needs_reduction(self):
+        f = C.c_int(0)
+        _check(self.lib, self.lib.hp_step_needs_reduction(self.h, C.byref(f)), "hp_step_needs_reduction")
+        return bool(f.value)
 
     def run(self, n):
         """Run n iterations and return the timestep USED by each (one blocking read per iteration: tests only)."""

@@ -69,6 +69,9 @@ class HipEngine:
     def step_end(self):
         self.domain.step_end()
 
+    def needs_reduction(self):
+        return self.domain.step_needs_reduction()
+
     def new_state(self):
         """Buffer the iteration in flight has just written (valid between step_begin and step_end)."""
         return self._view(PTR_STATE_OTHER)
@@ -204,7 +207,9 @@ class StripRunner:
         for _ in range(n):
             self.engine.step_begin()
             self._exchange_halo()
-            if self.world > 1:
+            # the scalar is new only when the reduction priced a buffer that changed (every iteration without
+            # quirk Q1, every other one with it); the decision is identical on all ranks (same iteration parity)
+            if self.world > 1 and self.engine.needs_reduction():
                 dist.all_reduce(self.engine.cfl_slot(), op=dist.ReduceOp.MAX)
             self.engine.step_end()
 

@@ -1,0 +1,236 @@
+// hp_scheme.cpp -- see hp_scheme.hpp.  Behaviour follows src/Schemes/CSchemeGodunov.cpp of the reference; the
+// detached worker thread (runBatchThread, :1116-1139) is not reproduced: hp_step_batch is asynchronous on the
+// domain's HIP stream and the blocking read at the end of a batch is hp_read_scalars (clFinish + five reads there).
+#include "hp_scheme.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace hipims_mi {
+
+void DomainArrays::closeEdges()
+{
+	for (long x = 0; x < cols; ++x) { bedElevations[x] = 9999.9; bedElevations[(size_t)(rows - 1) * cols + x] = 9999.9; }
+	for (long y = 0; y < rows; ++y) { bedElevations[(size_t)y * cols] = 9999.9; bedElevations[(size_t)y * cols + cols - 1] = 9999.9; }
+}
+
+double DomainArrays::volume() const
+{
+	double v = 0.0;
+	for (size_t i = 0; i < cellCount(); ++i) {
+		const double h = cellStates[4 * i] - bedElevations[i];
+		if (h > 0.0 && bedElevations[i] < 9999.0) v += h * resolution * resolution;
+	}
+	return v;
+}
+
+CSchemeMI::CSchemeMI(unsigned char schemeType, DomainArrays* domain, int deviceNumber)
+	: pDomain(domain), ucScheme(schemeType), iDevice(deviceNumber) {}
+
+CSchemeMI::~CSchemeMI() { cleanupSimulation(); }
+
+bool CSchemeMI::check(int rc, const char* what)
+{
+	if (rc == HP_OK) return true;
+	sLastError = std::string(what) + ": " + hp_last_error();      // model::doError(..., kLevelModelStop) in the reference
+	bReady = false;
+	return false;
+}
+
+void CSchemeMI::addBoundaryUniform(int definition, const std::vector<double>& pairs, double interval, double length)
+{
+	boundaries.push_back({0, definition, pairs, pairs.size() / 2, 0, 0, interval, length, 0, 0, 0});
+}
+
+void CSchemeMI::addBoundaryGridded(int definition, const std::vector<double>& grids, uint64_t entries, uint64_t gridRows,
+                                   uint64_t gridCols, double resolution, double offsetX, double offsetY, double interval)
+{
+	boundaries.push_back({1, definition, grids, entries, gridRows, gridCols, interval, 0, resolution, offsetX, offsetY});
+}
+
+// prepare1OExecDimensions / Constants / Code / Memory / Kernels / Boundaries collapse into one descriptor
+void CSchemeMI::prepareAll()
+{
+	hp_domain_desc_t desc;
+	hp_domain_desc_default(&desc);
+	desc.device = iDevice - 1;                                        // deviceNumber is 1-based (CDomainManager.cpp:203-220)
+	desc.cols = pDomain->cols; desc.rows = pDomain->rows; desc.dx = pDomain->resolution;
+	desc.precision = 8;
+	desc.scheme = (ucScheme == schemeTypes::kMUSCLHancock) ? HP_SCHEME_MUSCL_HANCOCK : HP_SCHEME_GODUNOV;
+	desc.courant = dCourantNumber;
+	desc.dry_threshold = dThresholdVerySmall;
+	desc.friction = bFrictionEffects ? 1 : 0;
+	desc.dynamic_dt = bDynamicTimestep ? 1 : 0;
+	desc.dt_fixed = dTimestep; desc.dt_initial = dTimestep;           // CSchemeGodunov.cpp:862-867
+	desc.t_end = dSimulationLength;
+	desc.math_mode = iMathMode;
+	if (!check(hp_domain_create(&desc, &hpDomain), "hp_domain_create")) return;
+	for (const PendingBoundary& b : boundaries) {
+		const int rc = b.kind == 0
+			? hp_boundary_add_uniform(hpDomain, b.definition, b.data.data(), (uint32_t)b.entries, b.interval, b.length)
+			: hp_boundary_add_gridded(hpDomain, b.definition, b.data.data(), b.entries, b.rows, b.cols, b.resolution,
+			                          b.offx, b.offy, b.interval);
+		if (!check(rc, "hp_boundary_add")) return;
+	}
+	dCurrentTimestep = dTimestep;
+	bReady = true;
+}
+
+void CSchemeMI::prepareSimulation()
+{
+	if (!bReady) return;
+	const size_t n = pDomain->cellCount();
+	if (!check(hp_domain_upload(hpDomain, HP_ARRAY_BED, pDomain->bedElevations.data(), n * 8), "upload bed")) return;
+	if (!check(hp_domain_upload(hpDomain, HP_ARRAY_MANNING, pDomain->manningValues.data(), n * 8), "upload manning")) return;
+	if (!check(hp_domain_upload(hpDomain, HP_ARRAY_STATE, pDomain->cellStates.data(), n * 32), "upload state")) return;
+	check(hp_sync(hpDomain), "hp_sync");                              // blockUntilFinished (:1071)
+	bOverrideTimestep = false; bUseForcedTimeAdvance = true; bCellStatesSynced = true;
+	dBatchStartedTime = 0.0; ulCurrentCellsCalculated = 0; uiIterationsSinceSync = 0; dLastSyncTime = 0.0;
+	bRunning = false;
+}
+
+void CSchemeMI::setTargetTime(double t)
+{
+	if (t == dTargetTime) return;
+	dTargetTime = t;
+	bUpdateTargetTime = true;
+}
+
+void CSchemeMI::forceTimestep(double dt)
+{
+	if (dt == dCurrentTimestep) return;
+	dCurrentTimestep = dt;
+	bOverrideTimestep = true;
+}
+
+void CSchemeMI::runSimulation(double dTarget, double dRealTime)
+{
+	if (!bReady || bRunning) return;
+	int busy = 0;
+	if (hp_is_busy(hpDomain, &busy) != HP_OK || busy) return;         // :1377-1378
+	if (dTargetTime != dTarget) setTargetTime(dTarget);               // :1381-1382
+	if (dTarget <= 0.0) return;                                       // :1385-1386
+	if (dCurrentTime > dTarget + 1E-5) return;                        // :1389-1407 (warning in the reference)
+
+	// batch size: aim for about a second of work, no silly jumps, never beyond the rollback limit (:1420-1448)
+	if (bAutomaticQueue && dRealTime > 1E-5 && ucSyncMethod != syncMethod::kSyncTimestep) {
+		const double dBatchDuration = dRealTime - dBatchStartedTime;
+		const unsigned int uiOld = uiQueueAdditionSize;
+		uiQueueAdditionSize = std::max(1u, std::min(uiBatchRate * 3,
+			(unsigned int)std::ceil(1.0 / (dBatchDuration / (double)uiQueueAdditionSize))));
+		if (uiQueueAdditionSize > uiOld * 2 && uiQueueAdditionSize > 40)
+			uiQueueAdditionSize = std::min(uiBatchRate * 3, uiOld * 2);
+		if (uiQueueAdditionSize > uiRollbackLimit - uiIterationsSinceSync)
+			uiQueueAdditionSize = uiRollbackLimit - uiIterationsSinceSync;
+		if (uiQueueAdditionSize < 1) uiQueueAdditionSize = 1;
+	}
+	dBatchStartedTime = dRealTime;
+	bRunning = true;
+
+	// ---- Threaded_runBatch (:1147-1372), one pass ----
+	if (bUpdateTargetTime) {                                          // :1163-1209
+		bUpdateTargetTime = false;
+		check(hp_set_target_time(hpDomain, dTargetTime), "hp_set_target_time");
+		bCellStatesSynced = false;
+		uiIterationsSinceSync = 0;
+		bUseForcedTimeAdvance = true;
+		if (dCurrentTimestep <= 0.0 && ucSyncMethod == syncMethod::kSyncForecast)
+			check(hp_update_timestep(hpDomain), "hp_update_timestep");   // tst_Reduce + tst_UpdateTimestep
+		if (dCurrentTime + dCurrentTimestep > dTargetTime + 1E-5) {
+			dCurrentTimestep = dTargetTime - dCurrentTime;
+			bOverrideTimestep = true;
+		}
+	}
+	if (dCurrentTime < dTargetTime && bOverrideTimestep) {            // :1213-1232
+		check(hp_force_timestep(hpDomain, dCurrentTimestep), "hp_force_timestep");
+		bOverrideTimestep = false;
+	}
+	unsigned int uiQueueAmount = uiQueueAdditionSize;
+	if (ucSyncMethod == syncMethod::kSyncTimestep) uiQueueAmount = 1; // :1274-1276
+	if (uiIterationsSinceSync < uiRollbackLimit && dCurrentTime < dTargetTime) {   // :1285-1304
+		check(hp_step_batch(hpDomain, uiQueueAmount), "hp_step_batch");
+		uiIterationsSinceSync += uiQueueAmount;
+		bCellStatesSynced = false;
+	}
+	readKeyStatistics();                                              // :1309-1313 + blockUntilFinished + :1350
+	bRunning = false;
+}
+
+void CSchemeMI::readKeyStatistics()
+{
+	const unsigned int uiLast = uiBatchSuccessful;
+	hp_scalars_t s;
+	if (!check(hp_read_scalars(hpDomain, &s), "hp_read_scalars")) return;
+	dCurrentTimestep = s.timestep; dCurrentTime = s.time; dBatchTimesteps = s.batch_timesteps;
+	uiBatchSuccessful = s.batch_successful; uiBatchSkipped = s.batch_skipped;
+	uiBatchRate = uiBatchSuccessful > uiLast ? (uiBatchSuccessful - uiLast) : 1;   // :1834
+	ulCurrentCellsCalculated = s.cells_calculated;
+}
+
+void CSchemeMI::readDomainAll()
+{
+	if (!hpDomain) return;
+	check(hp_domain_download(hpDomain, HP_ARRAY_STATE, pDomain->cellStates.data(), 0, pDomain->rows), "hp_domain_download");
+	check(hp_sync(hpDomain), "hp_sync");
+}
+
+void CSchemeMI::saveCurrentState()
+{
+	readDomainAll();
+	uiIterationsSinceSync = 0;
+	bCellStatesSynced = true;
+}
+
+void CSchemeMI::rollbackSimulation(double dTime, double dTarget)
+{
+	check(hp_sync(hpDomain), "hp_sync");
+	uiIterationsSinceSync = 0;
+	dCurrentTime = dTime; dTargetTime = dTarget;
+	check(hp_set_time(hpDomain, dTime), "hp_set_time");
+	check(hp_set_target_time(hpDomain, dTarget), "hp_set_target_time");
+	check(hp_domain_upload(hpDomain, HP_ARRAY_STATE, pDomain->cellStates.data(), pDomain->cellCount() * 32), "upload state");
+	if (ucSyncMethod != syncMethod::kSyncTimestep) check(hp_update_timestep(hpDomain), "hp_update_timestep");
+	bUseForcedTimeAdvance = true;
+	check(hp_reset_counters(hpDomain), "hp_reset_counters");
+	check(hp_sync(hpDomain), "hp_sync");
+	readKeyStatistics();
+}
+
+bool CSchemeMI::isSimulationFailure(double dExpected)
+{
+	if (bRunning) return false;
+	if (ucSyncMethod == syncMethod::kSyncForecast && uiBatchSuccessful >= uiRollbackLimit && dExpected - dCurrentTime > 1E-5) return true;
+	if (ucSyncMethod == syncMethod::kSyncTimestep && uiBatchSuccessful > uiRollbackLimit) return true;
+	if (dCurrentTime > dExpected + 1E-5) return true;
+	return false;
+}
+
+bool CSchemeMI::isSimulationSyncReady(double dExpected)
+{
+	if (bRunning) return false;
+	if (ucSyncMethod != syncMethod::kSyncTimestep && dExpected - dCurrentTime > 1E-5) return false;
+	if (ucSyncMethod == syncMethod::kSyncTimestep && uiIterationsSinceSync < uiRollbackLimit - 1 &&
+	    dExpected - dCurrentTime > 1E-5 && dCurrentTime > 0.0) return false;
+	return true;
+}
+
+double CSchemeMI::proposeSyncPoint(double dTime)
+{
+	double dProposal = dTime + std::fabs(dTimestep);
+	if (dTime > 1E-5 && uiBatchSuccessful > 0) {
+		dProposal = dTime + std::max(std::fabs(dTimestep),
+			uiRollbackLimit * (dBatchTimesteps / uiBatchSuccessful) * (((double)uiRollbackLimit - 3.0) / uiRollbackLimit));
+		if (uiBatchSuccessful >= uiRollbackLimit) dProposal = dTime + dBatchTimesteps * 0.95;
+	} else if (dProposal - dTime < 1E-5) {
+		dProposal = dTime + std::fabs(dTimestep);
+	}
+	return dProposal;
+}
+
+void CSchemeMI::cleanupSimulation()
+{
+	if (hpDomain) { hp_domain_destroy(hpDomain); hpDomain = nullptr; }
+	bRunning = false; bReady = false; dBatchStartedTime = 0.0;
+}
+
+} // namespace hipims_mi

@@ -1,0 +1,132 @@
+// hp_scheme.hpp -- C++ host side of the path above the C ABI: the part of HiPIMS's `CScheme` surface
+// (src/Schemes/CScheme.h:82-129) that `CModel` and `CDomain*` call to drive a domain, re-implemented over
+// libhipims_mi.so.  Method names, argument meaning and the batch / sync-point behaviour follow
+// CSchemeGodunov (src/Schemes/CSchemeGodunov.cpp); file parsing, logging and the OpenCL executor are not here.
+//
+// This is what INTEGRATION.md's adapter looks like when it does not depend on the rest of HiPIMS (boost, GDAL,
+// TinyXML): host arrays in the reference's layout stand in for CDomain (src/Domain/CDomain.cpp:143-191).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/hipims_mi.h"
+
+namespace hipims_mi {
+
+// CDomain's host arrays for one Cartesian domain (CDomain.h:26-33, CDomain.cpp:171-180): fp64 only here.
+struct DomainArrays {
+	long cols = 0, rows = 0;
+	double resolution = 1.0;
+	std::vector<double> cellStates;      // cols*rows x {Z, Zmax, Qx, Qy}, row 0 = south
+	std::vector<double> bedElevations;   // cols*rows
+	std::vector<double> manningValues;   // cols*rows
+	void resize(long c, long r) {
+		cols = c; rows = r;
+		cellStates.assign((size_t)c * r * 4, 0.0);
+		bedElevations.assign((size_t)c * r, 0.0);
+		manningValues.assign((size_t)c * r, 0.0);
+	}
+	size_t cellCount() const { return (size_t)cols * rows; }
+	// CDomainCartesian::imposeBoundaryModification (Cartesian/CDomainCartesian.cpp:773-799): closed edges
+	void closeEdges();
+	// CDomain::getVolume
+	double volume() const;
+};
+
+namespace schemeTypes { enum : unsigned char { kGodunov = 0, kMUSCLHancock = 1 }; }           // CScheme.h:40-46
+namespace timestepMode { enum : unsigned char { kCFL = 0, kFixed = 1 }; }                       // CScheme.h:48-52
+namespace syncMethod { enum : unsigned char { kSyncTimestep = 0, kSyncForecast = 1 }; }        // CScheme.h:57-62
+
+class CSchemeMI {
+public:
+	CSchemeMI(unsigned char schemeType, DomainArrays* domain, int deviceNumber = 1);
+	~CSchemeMI();
+
+	// ---- configuration (CScheme::setupFromConfig, CScheme.cpp:60-135; CSchemeGodunov.cpp:128-333) ----
+	void   setCourantNumber(double c)        { dCourantNumber = c; }
+	double getCourantNumber() const          { return dCourantNumber; }
+	void   setTimestepMode(unsigned char m)  { bDynamicTimestep = (m == timestepMode::kCFL); }
+	void   setTimestep(double dt)            { dTimestep = dt; }
+	void   setFrictionStatus(bool b)         { bFrictionEffects = b; }
+	void   setDryThreshold(double d)         { dThresholdVerySmall = d; }
+	void   setQueueMode(bool automatic)      { bAutomaticQueue = automatic; }
+	void   setQueueSize(unsigned int n)      { uiQueueAdditionSize = n; }
+	void   setSimulationLength(double t)     { dSimulationLength = t; }
+	void   setSyncMethod(unsigned char m)    { ucSyncMethod = m; }
+	void   setRollbackLimit(unsigned int n)  { uiRollbackLimit = n; }
+	void   setMathMode(int m)                { iMathMode = m; }
+	// CBoundaryUniform / CBoundaryGridded (atmospheric time series)
+	void   addBoundaryUniform(int definition, const std::vector<double>& timeValuePairs, double interval, double length);
+	void   addBoundaryGridded(int definition, const std::vector<double>& grids, uint64_t entries, uint64_t gridRows,
+	                          uint64_t gridCols, double resolution, double offsetX, double offsetY, double interval);
+
+	// ---- the CScheme virtuals CModel drives (CScheme.h:82-129) ----
+	bool   isReady() const                   { return bReady; }
+	bool   isRunning() const                 { return bRunning; }
+	void   prepareAll();                                         // CSchemeGodunov::prepareAll (:386-470)
+	void   prepareSimulation();                                  // :1053-1092
+	void   setTargetTime(double t);                              // :1741-1753
+	double getTargetTime() const             { return dTargetTime; }
+	void   forceTimestep(double dt);                             // :1803-1811
+	void   forceTimeAdvance()                { bUseForcedTimeAdvance = true; }
+	void   runSimulation(double dTargetTime, double dRealTime);  // :1374-1453 + Threaded_runBatch (:1147-1372)
+	void   readKeyStatistics();                                  // :1817-1835
+	void   readDomainAll();                                      // :1671-1679
+	void   saveCurrentState();                                   // :1720-1736
+	void   rollbackSimulation(double dCurrentTime, double dTargetTime);   // :1474-1518
+	bool   isSimulationFailure(double dExpectedTargetTime);      // :1523-1555
+	bool   isSimulationSyncReady(double dExpectedTargetTime);    // :1568-1612
+	double proposeSyncPoint(double dCurrentTime);                // :1758-1790
+	void   cleanupSimulation();                                  // :1458-1469
+
+	double             getCurrentTime() const          { return dCurrentTime; }
+	double             getCurrentTimestep() const      { return dCurrentTimestep; }
+	bool               getCurrentSuspendedState() const{ return dCurrentTimestep < 0.0; }
+	double             getAverageTimestep() const      { return uiBatchSuccessful < 1 ? 0.0 : dBatchTimesteps / uiBatchSuccessful; }
+	unsigned long long getCellsCalculated() const      { return ulCurrentCellsCalculated; }
+	unsigned int       getBatchSize() const            { return uiQueueAdditionSize; }
+	unsigned int       getIterationsSuccessful() const { return uiBatchSuccessful; }
+	unsigned int       getIterationsSkipped() const    { return uiBatchSkipped; }
+	const std::string& lastError() const               { return sLastError; }
+	hp_domain_t*       handle()                        { return hpDomain; }
+
+private:
+	bool check(int rc, const char* what);
+
+	DomainArrays* pDomain;
+	hp_domain_t*  hpDomain = nullptr;
+	unsigned char ucScheme;
+	int           iDevice;
+	int           iMathMode = HP_MATH_FAST;
+	std::string   sLastError;
+
+	// CScheme.cpp:46-55 / CSchemeGodunov.cpp:42-75 defaults
+	bool         bReady = false, bRunning = false;
+	bool         bAutomaticQueue = true;
+	unsigned int uiQueueAdditionSize = 1;
+	double       dCourantNumber = 0.5;
+	double       dTimestep = 0.001;
+	bool         bDynamicTimestep = true;
+	bool         bFrictionEffects = true;
+	double       dThresholdVerySmall = 1e-10;
+	double       dSimulationLength = 1e30;
+	unsigned char ucSyncMethod = syncMethod::kSyncForecast;      // CDomainManager.cpp:64-100 default
+	unsigned int uiRollbackLimit = 999999999;                    // single domain: CDomainBase.cpp:163-174
+
+	double       dTargetTime = 0.0, dCurrentTime = 0.0, dCurrentTimestep = 0.001;
+	double       dBatchTimesteps = 0.0, dBatchStartedTime = 0.0, dLastSyncTime = 0.0;
+	unsigned int uiBatchSuccessful = 0, uiBatchSkipped = 0, uiBatchRate = 1;
+	unsigned int uiIterationsSinceSync = 0;
+	unsigned long long ulCurrentCellsCalculated = 0;
+	bool         bUpdateTargetTime = false, bOverrideTimestep = false, bUseForcedTimeAdvance = true;
+	bool         bCellStatesSynced = true;
+
+	struct PendingBoundary { int kind, definition; std::vector<double> data; uint64_t entries, rows, cols;
+	                         double interval, length, resolution, offx, offy; };
+	std::vector<PendingBoundary> boundaries;
+};
+
+} // namespace hipims_mi

@@ -149,6 +149,7 @@ int hp_boundary_clear(hp_domain_t* d);
 
 /* ---- time control ---- */
 int hp_set_target_time(hp_domain_t* d, double t);     /* CScheme::setTargetTime -> "Target time (sync)" buffer (:1166-1176) */
+int hp_set_time(hp_domain_t* d, double t);            /* rewrite the "Time" buffer: rollbackSimulation (:1480-1494) */
 int hp_force_timestep(hp_domain_t* d, double dt);     /* CSchemeGodunov::forceTimestep (:1803-1811) + write (:1213-1232) */
 int hp_reset_counters(hp_domain_t* d);                /* tst_ResetCounters (CLDynamicTimestep.clc:151-161) */
 int hp_update_timestep(hp_domain_t* d);               /* tst_Reduce + tst_UpdateTimestep (:1189-1195, :1254-1260) */
@@ -183,6 +184,9 @@ int hp_step_begin(hp_domain_t* d);
 /* ... then, after the host has all-reduced (MAX) the 8-byte value at hp_device_ptr(HP_PTR_CFL_MAX),
  * the time advance (tst_Advance_Normal) and the ping-pong flip. */
 int hp_step_end(hp_domain_t* d);
+/* Between hp_step_begin and hp_step_end: does this iteration carry a NEW local maximum that has to be all-reduced?
+ * (0 on iterations whose reduction re-reads an unchanged buffer -- quirk Q1 -- and in fixed-timestep mode.) */
+int hp_step_needs_reduction(hp_domain_t* d, int* needed);
 
 enum {
 	HP_PTR_STATE_NEXT_SRC = 0,   /* state buffer the next iteration reads (ghost rows are written here) */

@@ -67,6 +67,9 @@ class OracleStripEngine:
         self._written = dst
         self.slot[0] = self._owned_max(reduce_buf)
 
+    def needs_reduction(self):
+        return True
+
     def new_state(self):
         return torch.from_numpy(self._written)
 
