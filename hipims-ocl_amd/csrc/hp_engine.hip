@@ -131,7 +131,7 @@ template <typename T> int launch_reduce(hp_domain* d, const void* state, long ro
 template <typename T> int price_edge_ring(hp_domain* d)
 {
 	const Params<T> p = make_params<T>(d);
-	HIP_TRY(hipMemsetAsync((T*)d->cfl_slot + 2, 0, 2 * sizeof(T), d->stream));
+	HIP_TRY(hipMemsetAsync((T*)d->cfl_slot + SLOT_EDGE, 0, 2 * sizeof(T), d->stream));
 	const int w = (d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK) ? 2 : 1;
 	const bool at_south = d->desc.row_offset == 0;
 	const bool at_north = d->desc.row_offset + d->desc.rows == d->desc.global_rows;
@@ -141,7 +141,7 @@ template <typename T> int price_edge_ring(hp_domain* d)
 	const long lo = d->own_lo + (at_south ? w : 0), hi = d->own_hi - (at_north ? w : 0);
 	for (int b = 0; b < 2; ++b)
 		hipLaunchKernelGGL(cfl_edge_ring<T>, dim3(64), dim3(256), 0, d->stream, p, (const State4<T>*)d->state[b],
-		                   (const T*)d->bed, lo, hi, south, north, w, (T*)d->cfl_slot + 2 + b);
+		                   (const T*)d->bed, lo, hi, south, north, w, (T*)d->cfl_slot + SLOT_EDGE + b);
 	HIP_TRY(hipGetLastError());
 	d->edge_dirty = false;
 	return HP_OK;
@@ -159,7 +159,7 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer)
 	const unsigned blocks = (unsigned)((ntiles + 7) / 8) * 8;
 	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, d->stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + 2 + edge_buffer,
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer,
 	                   (State4<T>*)d->sink, rseg, nstrips, groups, ntiles);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
@@ -177,7 +177,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer)
 	const unsigned blocks = (unsigned)((ntiles + 7) / 8) * 8;
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, d->stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + 2 + edge_buffer,
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer,
 	                   (State4<T>*)d->sink, rseg, nstrips, groups, ntiles);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
@@ -423,14 +423,15 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	HIP_TRY_C(hipMalloc(&d->bed, d->cells * d->esize));
 	HIP_TRY_C(hipMalloc(&d->manning, d->cells * d->esize));
 	HIP_TRY_C(hipMalloc(&d->scalars, 256));
-	HIP_TRY_C(hipMalloc(&d->cfl_slot, 256));
+	HIP_TRY_C(hipMalloc(&d->cfl_slot, 1024));
 	HIP_TRY_C(hipMalloc(&d->sink, 64 * 32));
+
 	HIP_TRY_C(hipHostMalloc(&d->host_scalars, 512, hipHostMallocDefault));
 	HIP_TRY_C(hipMemset(d->state[0], 0, d->cells * 4 * d->esize));
 	HIP_TRY_C(hipMemset(d->state[1], 0, d->cells * 4 * d->esize));
 	HIP_TRY_C(hipMemset(d->bed, 0, d->cells * d->esize));
 	HIP_TRY_C(hipMemset(d->manning, 0, d->cells * d->esize));
-	HIP_TRY_C(hipMemset(d->cfl_slot, 0, 256));
+	HIP_TRY_C(hipMemset(d->cfl_slot, 0, 1024));
 	HIP_TRY_C(hipMemset(d->scalars, 0, 256));
 	HIP_TRY_C(hipEventCreate(&d->ev_start));
 	HIP_TRY_C(hipEventCreate(&d->ev_stop));

@@ -54,6 +54,84 @@ __global__ __launch_bounds__(256) void godunov_basic(const Params<T> p, const Sc
 }
 
 // -------------------------------------------------------------------------------------------------
+// K4  advance_time : tst_Advance_Normal (CLDynamicTimestep.clc:27-146), one lane.
+//     `slot` holds the (all-reduced) maximum wave speed; it is cleared for the next accumulation.
+//     UPDATE_ONLY = tst_UpdateTimestep (:255-317).
+// -------------------------------------------------------------------------------------------------
+//     slot[0] = running maximum of this iteration (all-reduced by the host across strips), cleared here;
+//     slot[SLOT_SAVED] = maximum last used (re-used when the primary buffer was not touched: `fresh` == 0, Q1);
+//     slot[SLOT_EDGE], slot[SLOT_EDGE+1] = edge-ring maxima of the two state buffers (read by the march kernels).
+template <bool UPDATE_ONLY, typename T>
+__device__ __forceinline__ void advance_body(const Params<T>& p, Scalars<T>* sc, T* slot, const int fresh)
+{
+	const T EARLY_LIMIT = T(0.1), EARLY_DURATION = T(60.0), START_MIN = T(1E-10), START_DURATION = T(1.0);
+	const T DT_MIN = T(1E-10), DT_MAX = T(15.0), HYDRO = T(1.0);                 // CLDynamicTimestep.clh:24-29
+	// slot[0] is only ever touched by agent-scope atomics (performed at the memory side, so no XCD's L2 holds a
+	// stale copy); the remembered maximum lives one cache line further (SLOT_SAVED)
+	T vmax;
+	if (fresh) {
+		vmax = atomic_exchange_zero(slot);
+		slot[SLOT_SAVED] = vmax;
+	} else {
+		vmax = slot[SLOT_SAVED];
+	}
+
+	T t = sc->t, t_sync = sc->t_sync, batch = sc->batch_dt;
+	if (UPDATE_ONLY) {
+		const T dt_orig = fabs_(sc->dt);                                          // :264
+		T dt = T(0);
+		if (p.dynamic_dt) {
+			T tmin = p.dx / vmax;
+			if (t < START_DURATION && tmin < START_MIN) tmin = START_MIN;
+			dt = p.courant * tmin;
+		}
+		dt = fmin_(dt, dt_orig);                                                  // :297-298
+		batch = batch - dt_orig + dt;
+		if (t < EARLY_DURATION && dt > EARLY_LIMIT) dt = EARLY_LIMIT;             // :301-302
+		if ((t + dt) >= t_sync) dt = fmax_(T(0), t_sync - t);                     // :305-306
+		if (dt > DT_MAX) dt = DT_MAX;                                             // :309-310
+		sc->dt = dt;
+		sc->batch_dt = batch;
+		return;
+	}
+
+	T dt = fmax_(T(0), sc->dt);                                                   // :42
+	T t_hydro = sc->t_hydro;
+	uint32_t ok = sc->batch_ok, skipped = sc->batch_skipped;
+	t += dt;                                                                      // :50-51
+	batch += dt;
+	if (dt > T(0)) ok++; else skipped++;                                          // :53-58
+	if (t_hydro > HYDRO) t_hydro = dt; else t_hydro += dt;                        // :61-66
+
+	if (p.dynamic_dt) {                                                           // :68-92
+		T tmin = p.dx / vmax;
+		if (t < START_DURATION && tmin < START_MIN) tmin = START_MIN;
+		dt = p.courant * tmin;
+	} else {
+		dt = p.dt_fixed;                                                          // :93-97
+	}
+	if (dt > T(0) && dt < DT_MIN) dt = DT_MIN;                                    // :112-113
+	if ((t + dt) >= t_sync) {                                                     // :118-124
+		const T dt_in = dt;
+		if (t_sync - t > p.vs)  dt = t_sync - t;
+		if (t_sync - t <= p.vs) dt = -dt_in;
+	}
+	if (t < EARLY_DURATION && dt > EARLY_LIMIT) dt = EARLY_LIMIT;                 // :128-129
+	if ((t + dt) > p.t_end) dt = p.t_end - t;                                     // :132-133
+	if (dt > DT_MAX) dt = DT_MAX;                                                 // :136-137
+
+	sc->t = t; sc->dt = dt; sc->t_hydro = t_hydro; sc->batch_dt = batch;          // :140-145
+	sc->batch_ok = ok; sc->batch_skipped = skipped;
+}
+
+template <bool UPDATE_ONLY, typename T>
+__global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const int fresh)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	advance_body<UPDATE_ONLY>(p, sc, slot, fresh);
+}
+
+// -------------------------------------------------------------------------------------------------
 // K1  godunov_march : the tuned Godunov + HLLC step.
 //
 //  * One wavefront owns a strip of 64 consecutive columns (lane = column, so every row of the strip is one
@@ -85,21 +163,20 @@ __device__ __forceinline__ Side<T> shfl_side(const Side<T>& s, const int src_lan
 }
 
 template <bool STRICT, int CFL_MODE, typename T>
-__global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* __restrict__ sc,
+__global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
-                                                     T* __restrict__ cfl_slot, const T* __restrict__ edge_max,
+                                                     T* cfl_slot, const T* __restrict__ edge_max,
                                                      State4<T>* __restrict__ sink, const int rseg, const int nstrips,
                                                      const int groups, const int ntiles)
 {
 	// XCD-aware tile order (grid is a multiple of 8 blocks)
 	const unsigned per_xcd = gridDim.x >> 3;
 	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-	if (tile >= (unsigned)ntiles) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const long strip = (long)(tile % (unsigned)groups) * 4 + wave;
 	const long seg = tile / (unsigned)groups;
-	if (strip >= nstrips) return;                                                  // wave-uniform
+	if (tile < (unsigned)ntiles && strip < nstrips) {                              // wave-uniform
 
 	const long x = strip * MARCH_COLS + lane;
 	const long y0 = 1 + seg * rseg;
@@ -217,6 +294,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		vmax = wave_max(vmax);
 		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
+	}   // tile / strip guard
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -243,20 +321,19 @@ __device__ __forceinline__ Raw<T> shfl_raw(const Raw<T>& r, const int src_lane)
 }
 
 template <bool STRICT, int CFL_MODE, typename T>
-__global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scalars<T>* __restrict__ sc,
+__global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scalars<T>* sc,
                                                    const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                    State4<T>* __restrict__ dst, const T* __restrict__ manning,
-                                                   T* __restrict__ cfl_slot, const T* __restrict__ edge_max,
+                                                   T* cfl_slot, const T* __restrict__ edge_max,
                                                    State4<T>* __restrict__ sink, const int rseg, const int nstrips,
                                                    const int groups, const int ntiles)
 {
 	const unsigned per_xcd = gridDim.x >> 3;
 	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-	if (tile >= (unsigned)ntiles) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const long strip = (long)(tile % (unsigned)groups) * 4 + wave;
 	const long seg = tile / (unsigned)groups;
-	if (strip >= nstrips) return;
+	if (tile < (unsigned)ntiles && strip < nstrips) {
 
 	const long x = strip * MUSCL_COLS + lane;
 	const long y0 = 2 + seg * rseg;                                                // corrector domain 2..n-3 (:569-573)
@@ -359,6 +436,7 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 		vmax = wave_max(vmax);
 		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
+	}   // tile / strip guard
 }
 
 // max wave speed over the edge ring (cells no kernel ever writes): the `w` outermost columns on rows
@@ -419,77 +497,6 @@ __global__ __launch_bounds__(256) void cfl_reduce(const Params<T> p, const State
 		for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (wave_part[w] > m) m = wave_part[w];
 		if (m > T(0)) atomic_max_nonneg(slot, m);
 	}
-}
-
-// -------------------------------------------------------------------------------------------------
-// K4  advance_time : tst_Advance_Normal (CLDynamicTimestep.clc:27-146), one lane.
-//     `slot` holds the (all-reduced) maximum wave speed; it is cleared for the next accumulation.
-//     UPDATE_ONLY = tst_UpdateTimestep (:255-317).
-// -------------------------------------------------------------------------------------------------
-//     slot[0] = running maximum of this iteration (all-reduced by the host across strips), cleared here;
-//     slot[1] = maximum last used (re-used when the primary buffer was not touched: `fresh` == 0, Q1);
-//     slot[2], slot[3] = edge-ring maxima of the two state buffers (read by godunov_march).
-template <bool UPDATE_ONLY, typename T>
-__global__ void advance_time(const Params<T> p, Scalars<T>* __restrict__ sc, T* __restrict__ slot, const int fresh)
-{
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	const T EARLY_LIMIT = T(0.1), EARLY_DURATION = T(60.0), START_MIN = T(1E-10), START_DURATION = T(1.0);
-	const T DT_MIN = T(1E-10), DT_MAX = T(15.0), HYDRO = T(1.0);                 // CLDynamicTimestep.clh:24-29
-	T vmax;
-	if (fresh) {
-		vmax = slot[0];
-		slot[1] = vmax;
-	} else {
-		vmax = slot[1];
-	}
-	slot[0] = T(0);
-
-	T t = sc->t, t_sync = sc->t_sync, batch = sc->batch_dt;
-	if (UPDATE_ONLY) {
-		const T dt_orig = fabs_(sc->dt);                                          // :264
-		T dt = T(0);
-		if (p.dynamic_dt) {
-			T tmin = p.dx / vmax;
-			if (t < START_DURATION && tmin < START_MIN) tmin = START_MIN;
-			dt = p.courant * tmin;
-		}
-		dt = fmin_(dt, dt_orig);                                                  // :297-298
-		batch = batch - dt_orig + dt;
-		if (t < EARLY_DURATION && dt > EARLY_LIMIT) dt = EARLY_LIMIT;             // :301-302
-		if ((t + dt) >= t_sync) dt = fmax_(T(0), t_sync - t);                     // :305-306
-		if (dt > DT_MAX) dt = DT_MAX;                                             // :309-310
-		sc->dt = dt;
-		sc->batch_dt = batch;
-		return;
-	}
-
-	T dt = fmax_(T(0), sc->dt);                                                   // :42
-	T t_hydro = sc->t_hydro;
-	uint32_t ok = sc->batch_ok, skipped = sc->batch_skipped;
-	t += dt;                                                                      // :50-51
-	batch += dt;
-	if (dt > T(0)) ok++; else skipped++;                                          // :53-58
-	if (t_hydro > HYDRO) t_hydro = dt; else t_hydro += dt;                        // :61-66
-
-	if (p.dynamic_dt) {                                                           // :68-92
-		T tmin = p.dx / vmax;
-		if (t < START_DURATION && tmin < START_MIN) tmin = START_MIN;
-		dt = p.courant * tmin;
-	} else {
-		dt = p.dt_fixed;                                                          // :93-97
-	}
-	if (dt > T(0) && dt < DT_MIN) dt = DT_MIN;                                    // :112-113
-	if ((t + dt) >= t_sync) {                                                     // :118-124
-		const T dt_in = dt;
-		if (t_sync - t > p.vs)  dt = t_sync - t;
-		if (t_sync - t <= p.vs) dt = -dt_in;
-	}
-	if (t < EARLY_DURATION && dt > EARLY_LIMIT) dt = EARLY_LIMIT;                 // :128-129
-	if ((t + dt) > p.t_end) dt = p.t_end - t;                                     // :132-133
-	if (dt > DT_MAX) dt = DT_MAX;                                                 // :136-137
-
-	sc->t = t; sc->dt = dt; sc->t_hydro = t_hydro; sc->batch_dt = batch;          // :140-145
-	sc->batch_ok = ok; sc->batch_skipped = skipped;
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -548,6 +548,18 @@ __device__ __forceinline__ void atomic_max_nonneg(float* slot, float v)
 	atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(v));
 }
 
+// layout of the CFL slot block (elements of T): [0] running max | [SLOT_SAVED] last max used | [SLOT_EDGE..+1] ring maxima
+constexpr int SLOT_SAVED = 32, SLOT_EDGE = 64;          // separate 256-B apart so line [0] only ever sees atomics
+
+__device__ __forceinline__ double atomic_exchange_zero(double* slot)
+{
+	return __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(slot), 0ull));
+}
+__device__ __forceinline__ float atomic_exchange_zero(float* slot)
+{
+	return __uint_as_float(atomicExch(reinterpret_cast<unsigned int*>(slot), 0u));
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_max(T v)
 {
