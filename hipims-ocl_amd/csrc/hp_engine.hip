@@ -32,8 +32,11 @@ int fail(int code, const std::string& msg)
 	} while (0)
 
 struct Boundary {
-	int      kind;         // 0 uniform, 1 gridded
+	int      kind;         // 0 uniform, 1 gridded, 2 cell
 	int      definition;
+	int      discharge_def;
+	void*    cells;        // device: global cell ids (cell boundaries)
+	uint64_t count;
 	void*    data;         // device
 	uint64_t entries, grows, gcols;
 	double   interval, length, resolution, off_x, off_y;
@@ -100,7 +103,12 @@ template <typename T> int apply_boundaries(hp_domain* d, void* target)
 	size_t want = ((size_t)p.cols * p.rows + 255) / 256;
 	const dim3 block(256), grid((unsigned)(want < 1024 ? want : 1024));
 	for (const Boundary& b : d->bdy) {
-		if (b.kind == 0) {
+		if (b.kind == 2) {
+			CellBdy<T> c{(const unsigned long long*)b.cells, b.count, (const T*)b.data, b.entries, b.definition,
+			             b.discharge_def, (T)b.interval, (T)b.length};
+			hipLaunchKernelGGL(bdy_cell<T>, dim3((unsigned)((b.count + 63) / 64)), dim3(64), 0, d->stream, p,
+			                   (const Scalars<T>*)d->scalars, c, (State4<T>*)target, (const T*)d->bed);
+		} else if (b.kind == 0) {
 			UniformBdy<T> u{(const T*)b.data, (uint32_t)b.entries, b.definition, (T)b.interval, (T)b.length};
 			hipLaunchKernelGGL(bdy_uniform<T>, grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars, u,
 			                   (State4<T>*)target, (const T*)d->bed, truncated);
@@ -175,7 +183,8 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer)
 	const int nsegs = (int)((p.rows - 2 + rseg - 1) / rseg);
 	const int ntiles = groups * nsegs;
 	const unsigned blocks = (unsigned)((ntiles + 7) / 8) * 8;
-	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, d->stream, p,
+	static const int dbg_lds = std::getenv("HP_DEBUG_LDS") ? std::atoi(std::getenv("HP_DEBUG_LDS")) : 0;   // occupancy experiments
+	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), dbg_lds, d->stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer,
 	                   (State4<T>*)d->sink, rseg, nstrips, groups, ntiles);
@@ -447,7 +456,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	if (!d) return HP_OK;
 	hipSetDevice(d->desc.device);
 	if (d->stream) hipStreamSynchronize(d->stream);
-	for (auto& b : d->bdy) hipFree(b.data);
+	for (auto& b : d->bdy) { hipFree(b.data); hipFree(b.cells); }
 	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
 	hipFree(d->scalars); hipFree(d->cfl_slot); hipFree(d->sink);
@@ -557,12 +566,37 @@ int hp_boundary_add_gridded(hp_domain_t* d, int definition, const void* grids, u
 	return HP_OK;
 }
 
+int hp_boundary_add_cell(hp_domain_t* d, int depth_definition, int discharge_definition, const uint64_t* cells,
+                         uint64_t count, const void* series, uint64_t entries, double interval, double length)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!cells || count == 0 || !series || entries < 2 || !(interval > 0)) return fail(HP_ERR_INVALID, "bad cell boundary");
+	if (depth_definition < 0 || depth_definition > 3 || discharge_definition < 0 || discharge_definition > 3)
+		return fail(HP_ERR_INVALID, "unknown cell boundary definition");
+	const uint64_t global_cells = (uint64_t)d->desc.cols * (uint64_t)d->desc.global_rows;
+	for (uint64_t i = 0; i < count; ++i)
+		if (cells[i] >= global_cells) return fail(HP_ERR_INVALID, "cell boundary id outside the grid");
+	if (length > (double)(entries - 1) * interval + 1e-9)
+		return fail(HP_ERR_INVALID, "cell boundary series shorter than its length (interpolation reads entry n+1)");
+	Boundary b{};
+	b.kind = 2; b.definition = depth_definition; b.discharge_def = discharge_definition; b.count = count;
+	b.entries = entries; b.interval = interval; b.length = length;
+	HIP_TRY(hipMalloc(&b.cells, count * sizeof(uint64_t)));
+	HIP_TRY(hipMemcpy(b.cells, cells, count * sizeof(uint64_t), hipMemcpyHostToDevice));
+	const size_t bytes = (size_t)entries * 4 * d->esize;
+	HIP_TRY(hipMalloc(&b.data, bytes));
+	HIP_TRY(hipMemcpy(b.data, series, bytes, hipMemcpyHostToDevice));
+	d->bdy.push_back(b);
+	return HP_OK;
+}
+
 int hp_boundary_clear(hp_domain_t* d)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	HIP_TRY(hipStreamSynchronize(d->stream));
-	for (auto& b : d->bdy) hipFree(b.data);
+	for (auto& b : d->bdy) { hipFree(b.data); hipFree(b.cells); }
 	d->bdy.clear();
 	return HP_OK;
 }

@@ -570,4 +570,51 @@ __global__ __launch_bounds__(256) void bdy_gridded(const Params<T> p, const Scal
 	}
 }
 
+// bdy_Cell (Boundaries/CLBoundaries.clc:23-128): imposed depth / level / discharge / velocity / volume on a list of
+// cells with linear interpolation in time.  Cell ids are global; a strip applies the ones it stores (ghost rows too).
+template <typename T> struct CellBdy {
+	const unsigned long long* cells; unsigned long long count;
+	const T* series; unsigned long long entries; int depth_def, discharge_def; T interval, length;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void bdy_cell(const Params<T> p, const Scalars<T>* __restrict__ sc, const CellBdy<T> b,
+                                               State4<T>* __restrict__ state, const T* __restrict__ bed)
+{
+	const T t = sc->t, dt = sc->dt;
+	const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= b.count || t >= b.length || dt <= T(0)) return;                       // :38-39
+	const unsigned long long gid = b.cells[r];
+	const long gy = (long)(gid / (unsigned long long)p.cols), x = (long)(gid - (unsigned long long)gy * p.cols);
+	const long y = gy - p.row_offset;
+	if (y < 0 || y >= p.rows) return;                                              // not stored by this strip
+	const size_t id = (size_t)y * p.cols + x;
+	const unsigned long long base = (unsigned long long)floor_(t / b.interval), next = base + 1;   // :41-42
+	State4<T> c = state[id];
+	const T zb = bed[id];
+	const T w = fmod_(t, b.interval) / b.interval;                                 // :50
+	T ts[4];
+	for (int k = 0; k < 4; ++k) ts[k] = b.series[4 * base + k] + (b.series[4 * next + k] - b.series[4 * base + k]) * w;
+
+	const T g = gravity<T>();
+	if (b.depth_def == 2) {                                                        // depth is fixed (:53-59)
+		c.z = zb + ts[1];
+	} else if (b.depth_def == 1) {                                                 // level is fixed (:60-66)
+		c.z = fmax_(zb, ts[1]);
+	} else if (fabs_(ts[2]) > p.vs || fabs_(ts[3]) > p.vs || b.discharge_def == 3) {   // :67-98
+		T depth = (fabs_(ts[2]) * dt) / p.dx + (fabs_(ts[3]) * dt) / p.dx;
+		T crit = fmax_(pow_(pow_(ts[2], T(2.0)) / g, T(T(1.0) / T(3.0))), pow_(pow_(ts[3], T(2.0)) / g, T(T(1.0) / T(3.0))));
+		if (b.discharge_def == 3) {                                                // volume: no direction, no scaling
+			depth = (fabs_(ts[2]) * dt) / (p.dx * p.dx);
+			crit = T(0);
+			ts[2] = T(0);
+			ts[3] = T(0);
+		}
+		c.z = fmax_(zb + crit, c.z + depth);
+	}
+	if (b.discharge_def == 1) { c.qx = ts[2]; c.qy = ts[3]; }                      // :100-118
+	else if (b.discharge_def == 2) { c.qx = ts[2] * (c.z - zb); c.qy = ts[3] * (c.z - zb); }
+	state[id] = c;
+}
+
 } // namespace hp

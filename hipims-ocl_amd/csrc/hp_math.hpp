@@ -49,6 +49,8 @@ __device__ __forceinline__ double fmax_(double a, double b) { return __builtin_f
 __device__ __forceinline__ float  fmax_(float a, float b)   { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double fmin_(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ float  fmin_(float a, float b)   { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double fmod_(double a, double b) { return fmod(a, b); }
+__device__ __forceinline__ float  fmod_(float a, float b)   { return fmodf(a, b); }
 __device__ __forceinline__ double floor_(double x) { return __builtin_floor(x); }
 __device__ __forceinline__ float  floor_(float x)  { return __builtin_floorf(x); }
 

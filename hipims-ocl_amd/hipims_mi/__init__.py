@@ -23,12 +23,14 @@ MATH_FAST, MATH_STRICT = 0, 1
 KERNEL_AUTO, KERNEL_BASIC = 0, 1
 UNIFORM_RAIN_INTENSITY, UNIFORM_LOSS_RATE = 0, 1
 GRIDDED_RAIN_INTENSITY, GRIDDED_RAIN_ACCUMUL, GRIDDED_MASS_FLUX = 0, 1, 2
+DEPTH_IGNORE, DEPTH_IS_FSL, DEPTH_IS_DEPTH, DEPTH_IS_CRITICAL = 0, 1, 2, 3
+DISCHARGE_IGNORE, DISCHARGE_IS_DISCHARGE, DISCHARGE_IS_VELOCITY, DISCHARGE_IS_VOLUME = 0, 1, 2, 3
 PTR_STATE_NEXT_SRC, PTR_STATE_OTHER, PTR_BED, PTR_MANNING, PTR_CFL_MAX, PTR_SCALARS = range(6)
 
 EXPORTS = [
     "hp_abi_version", "hp_device_count", "hp_device_info", "hp_last_error", "hp_domain_desc_default",
     "hp_domain_create", "hp_domain_destroy", "hp_domain_upload", "hp_domain_download", "hp_domain_upload_rows",
-    "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_clear", "hp_set_target_time", "hp_set_time",
+    "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_add_cell", "hp_boundary_clear", "hp_set_target_time", "hp_set_time",
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
     "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_timer_start",
     "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read",
@@ -94,6 +96,8 @@ def load_library(path: str | None = None):
     lib.hp_boundary_add_uniform.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_double, C.c_double]
     lib.hp_boundary_add_gridded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                             C.c_double, C.c_double, C.c_double, C.c_double]
+    lib.hp_boundary_add_cell.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                         C.c_double, C.c_double]
     lib.hp_boundary_clear.argtypes = [C.c_void_p]
     lib.hp_set_target_time.argtypes = [C.c_void_p, C.c_double]
     lib.hp_force_timestep.argtypes = [C.c_void_p, C.c_double]
@@ -239,6 +243,14 @@ class Domain:
         _check(self.lib, self.lib.hp_boundary_add_gridded(self.h, definition, g.ctypes.data_as(C.c_void_p), g.shape[0],
                                                           g.shape[1], g.shape[2], resolution, off_x, off_y, interval),
                "hp_boundary_add_gridded")
+
+    def add_cell(self, depth_def, discharge_def, cells, series, interval, length):
+        rel = np.ascontiguousarray(cells, dtype=np.uint64)
+        ser = np.ascontiguousarray(series, dtype=self.real)
+        assert ser.ndim == 2 and ser.shape[1] == 4
+        _check(self.lib, self.lib.hp_boundary_add_cell(self.h, depth_def, discharge_def, rel.ctypes.data_as(C.c_void_p),
+                                                       rel.size, ser.ctypes.data_as(C.c_void_p), ser.shape[0], interval,
+                                                       length), "hp_boundary_add_cell")
 
     # ---- time control / stepping ----
     def set_target_time(self, t):

@@ -145,6 +145,13 @@ int hp_boundary_add_uniform(hp_domain_t* d, int definition, const void* series, 
 int hp_boundary_add_gridded(hp_domain_t* d, int definition, const void* grids, uint64_t entries,
                             uint64_t grid_rows, uint64_t grid_cols, double resolution,
                             double offset_x, double offset_y, double interval);
+/* CBoundaryCell::prepareBoundary (Boundaries/CBoundaryCell.cpp:300-445) -- "next" row N2 of SURVEY.md 8(f).
+ * cells: flat ids y*cols + x in the GLOBAL grid (CDomainCartesian::getCellID); series: `entries` x {time, depth or
+ * level, Qx, Qy}, already divided by the cell count for "total" discharges as the reference's packer does (:398-402). */
+enum { HP_DEPTH_IGNORE = 0, HP_DEPTH_IS_FSL = 1, HP_DEPTH_IS_DEPTH = 2, HP_DEPTH_IS_CRITICAL = 3 };       /* CLBoundaries.clh:34-37 */
+enum { HP_DISCHARGE_IGNORE = 0, HP_DISCHARGE_IS_DISCHARGE = 1, HP_DISCHARGE_IS_VELOCITY = 2, HP_DISCHARGE_IS_VOLUME = 3 };   /* :39-42 */
+int hp_boundary_add_cell(hp_domain_t* d, int depth_definition, int discharge_definition, const uint64_t* cells,
+                         uint64_t count, const void* series, uint64_t entries, double interval, double length);
 int hp_boundary_clear(hp_domain_t* d);
 
 /* ---- time control ---- */

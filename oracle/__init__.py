@@ -28,6 +28,8 @@ Q1_CFL_READS_PRIMARY, Q9_BDY_TRUNCATED, Q6_MUSCL_SERIAL = 1, 2, 4
 QUIRKS_REFERENCE = 7
 UNIFORM_RAIN_INTENSITY, UNIFORM_LOSS_RATE = 0, 1
 GRIDDED_RAIN_INTENSITY, GRIDDED_RAIN_ACCUMUL, GRIDDED_MASS_FLUX = 0, 1, 2
+DEPTH_IGNORE, DEPTH_IS_FSL, DEPTH_IS_DEPTH, DEPTH_IS_CRITICAL = 0, 1, 2, 3
+DISCHARGE_IGNORE, DISCHARGE_IS_DISCHARGE, DISCHARGE_IS_VELOCITY, DISCHARGE_IS_VOLUME = 0, 1, 2, 3
 DIR_N, DIR_E, DIR_S, DIR_W = 0, 1, 2, 3
 
 
@@ -234,6 +236,14 @@ class OracleSim(_SimBase):
                                             C.c_ulong(g.shape[1]), C.c_ulong(g.shape[2]), self.creal(resolution),
                                             self.creal(off_x), self.creal(off_y), self.creal(interval))
 
+    def add_cell(self, depth_def, discharge_def, cells, series, interval, length):
+        """cells: flat cell ids (y*cols + x); series: [entries][4] = time, depth/fsl, qx, qy (already per cell)."""
+        rel = np.ascontiguousarray(cells, dtype=np.uint64)
+        ser = np.ascontiguousarray(series, dtype=self.real)
+        assert ser.ndim == 2 and ser.shape[1] == 4
+        return self.lib.orc_sim_add_cell(self.h, int(depth_def), int(discharge_def), _ptr(rel), C.c_ulong(rel.size),
+                                         _ptr(ser), C.c_ulong(ser.shape[0]), self.creal(interval), self.creal(length))
+
     def set_target(self, t):
         self.lib.orc_sim_set_target(self.h, self.creal(t))
 
@@ -409,6 +419,17 @@ class RefSim(_SimBase):
         self.bdy.append(("gridded", Cfg(interval, resolution, off_x, off_y, g.shape[0], definition,
                                         g.shape[1], g.shape[2]), g))
 
+    def add_cell(self, depth_def, discharge_def, cells, series, interval, length):
+        rel = np.ascontiguousarray(cells, dtype=np.uint64)
+        ser = _aligned_zeros((len(series), 4), self.real)
+        ser[...] = series
+        cr = self.creal
+
+        class Cfg(C.Structure):              # sBdyCellConfiguration, CLBoundaries.clh:54-62
+            _fields_ = [("entries", C.c_ulong), ("interval", cr), ("length", cr), ("count", C.c_ulong),
+                        ("depth_def", C.c_uint), ("discharge_def", C.c_uint)]
+        self.bdy.append(("cell", Cfg(ser.shape[0], interval, length, rel.size, depth_def, discharge_def), (rel, ser)))
+
     def set_target(self, t):
         self.t_sync[0] = t
 
@@ -423,6 +444,11 @@ class RefSim(_SimBase):
     def _apply_boundaries(self, target):
         full = 0 if (self.quirks & Q9_BDY_TRUNCATED) else 1
         for kind, cfg, data in self.bdy:
+            if kind == "cell":
+                rel, ser = data
+                self.lib.ref_bdy_cell(C.byref(cfg), _ptr(rel), _ptr(ser), _ptr(self.t), _ptr(self.dt), _ptr(self.t_hydro),
+                                      _ptr(target), _ptr(self.bed), _ptr(self.manning), C.c_long(rel.size))
+                continue
             fn = self.lib.ref_bdy_uniform if kind == "uniform" else self.lib.ref_bdy_gridded
             fn(C.byref(cfg), _ptr(data), _ptr(self.t), _ptr(self.dt), _ptr(self.t_hydro), _ptr(target),
                _ptr(self.bed), _ptr(self.manning), C.c_int(full))

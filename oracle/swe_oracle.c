@@ -806,14 +806,60 @@ void orc_bdy_gridded(const orc_params* p, const orc_scalars* s, int definition,
 		}
 }
 
+/* bdy_Cell -- Boundaries/CLBoundaries.clc:23-128; 1-D over the relation list (CBoundaryCell.cpp:442-443) */
+void orc_bdy_cell(const orc_params* p, const orc_scalars* s, int depth_def, int discharge_def,
+                  const unsigned long* relations, unsigned long count, const real* series, unsigned long entries,
+                  real interval, real length, real* state, const real* bed)
+{
+	(void)entries;
+	const real VS = p->very_small, DX = p->dx, DY = p->dx;
+	const real dLocalTime = s->t, dLocalTimestep = s->dt;
+	for (unsigned long r = 0; r < count; ++r) {
+		if (dLocalTime >= length || dLocalTimestep <= RC(0.0)) return;            /* :38-39 */
+		const unsigned long base = (unsigned long)R_FLOOR(dLocalTime / interval), next = base + 1;   /* :41-42 */
+		const unsigned long id = relations[r];
+		real* c = state + 4 * id;
+		const real dCellBed = bed[id];
+		const real w = R_FMOD(dLocalTime, interval) / interval;                   /* :50 */
+		real ts[4];
+		for (int k = 0; k < 4; ++k) ts[k] = series[4 * base + k] + (series[4 * next + k] - series[4 * base + k]) * w;
+
+		if (depth_def == ORC_DEPTH_IS_DEPTH) {                                    /* :53-59 */
+			c[0] = dCellBed + ts[1];
+		} else if (depth_def == ORC_DEPTH_IS_FSL) {                               /* :60-66 */
+			c[0] = R_FMAX(dCellBed, ts[1]);
+		} else {                                                                  /* :67-98 */
+			if (R_FABS(ts[2]) > VS || R_FABS(ts[3]) > VS || discharge_def == ORC_DISCHARGE_IS_VOLUME) {
+				real dDepth = (R_FABS(ts[2]) * dLocalTimestep) / DY + (R_FABS(ts[3]) * dLocalTimestep) / DX;
+				real dCriticalDepth = R_FMAX(R_POW(R_POW(ts[2], RC(2.0)) / GRAVITY, (real)(RC(1.0) / RC(3.0))),
+				                             R_POW(R_POW(ts[3], RC(2.0)) / GRAVITY, (real)(RC(1.0) / RC(3.0))));
+				if (discharge_def == ORC_DISCHARGE_IS_VOLUME) {
+					dDepth = (R_FABS(ts[2]) * dLocalTimestep) / (DX * DY);
+					dCriticalDepth = RC(0.0);
+					ts[2] = RC(0.0);
+					ts[3] = RC(0.0);
+				}
+				c[0] = R_FMAX(dCellBed + dCriticalDepth, c[0] + dDepth);
+			}
+		}
+		if (discharge_def == ORC_DISCHARGE_IS_DISCHARGE) c[2] = ts[2];            /* :100-108 */
+		else if (discharge_def == ORC_DISCHARGE_IS_VELOCITY) c[2] = ts[2] * (c[0] - dCellBed);
+		if (discharge_def == ORC_DISCHARGE_IS_DISCHARGE) c[3] = ts[3];            /* :110-118 */
+		else if (discharge_def == ORC_DISCHARGE_IS_VELOCITY) c[3] = ts[3] * (c[0] - dCellBed);
+	}
+}
+
 /* =============================================================================================
  *  Simulation-level driver: the reference's per-iteration kernel graph
  *  CSchemeGodunov::scheduleIteration (CSchemeGodunov.cpp:1617-1666) and
  *  CSchemeMUSCLHancock::scheduleIteration (CSchemeMUSCLHancock.cpp:646-680)
  * ========================================================================================== */
 typedef struct {
-	int   kind;           /* 0 uniform, 1 gridded */
+	int   kind;           /* 0 uniform, 1 gridded, 2 cell */
 	int   definition;
+	int   discharge_def;
+	unsigned long* relations;
+	unsigned long  count;
 	real* data;
 	unsigned long entries, grows, gcols;
 	real  interval, length, resolution, off_x, off_y;
@@ -856,7 +902,7 @@ void orc_sim_destroy(orc_sim* s)
 	if (!s) return;
 	free(s->primary); free(s->alt); free(s->bed); free(s->manning);
 	for (int d = 0; d < 4; ++d) free(s->face[d]);
-	for (int i = 0; i < s->nbdy; ++i) free(s->bdy[i].data);
+	for (int i = 0; i < s->nbdy; ++i) { free(s->bdy[i].data); free(s->bdy[i].relations); }
 	free(s->bdy);
 	free(s);
 }
@@ -899,6 +945,19 @@ int orc_sim_add_gridded(orc_sim* s, int definition, const real* grids, unsigned 
 	return s->nbdy - 1;
 }
 
+int orc_sim_add_cell(orc_sim* s, int depth_def, int discharge_def, const unsigned long* relations,
+                     unsigned long count, const real* series, unsigned long entries, real interval, real length)
+{
+	orc_bdy* b = new_bdy(s);
+	b->kind = 2; b->definition = depth_def; b->discharge_def = discharge_def; b->count = count; b->entries = entries;
+	b->interval = interval; b->length = length;
+	b->relations = (unsigned long*)malloc(count * sizeof(unsigned long));
+	memcpy(b->relations, relations, count * sizeof(unsigned long));
+	b->data = (real*)malloc((size_t)entries * 4 * sizeof(real));
+	memcpy(b->data, series, (size_t)entries * 4 * sizeof(real));
+	return s->nbdy - 1;
+}
+
 void orc_sim_set_target(orc_sim* s, real t_sync) { s->sc.t_sync = t_sync; }       /* CSchemeGodunov.cpp:1166-1176 */
 void orc_sim_force_dt(orc_sim* s, real dt)       { s->sc.dt = dt; }               /* :1213-1232 */
 void orc_sim_reset_counters(orc_sim* s)                                           /* tst_ResetCounters, CLDynamicTimestep.clc:151-161 */
@@ -911,7 +970,10 @@ static void apply_boundaries(orc_sim* s, real* target)
 	const int trunc = (s->quirks & ORC_Q9_BDY_TRUNCATED) ? 1 : 0;
 	for (int i = 0; i < s->nbdy; ++i) {
 		orc_bdy* b = &s->bdy[i];
-		if (b->kind == 0)
+		if (b->kind == 2)
+			orc_bdy_cell(&s->p, &s->sc, b->definition, b->discharge_def, b->relations, b->count, b->data, b->entries,
+			             b->interval, b->length, target, s->bed);
+		else if (b->kind == 0)
 			orc_bdy_uniform(&s->p, &s->sc, b->definition, b->data, (unsigned)b->entries, b->interval, b->length,
 			                target, s->bed, trunc);
 		else

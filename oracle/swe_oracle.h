@@ -47,6 +47,9 @@ enum {
 /* uniform-boundary definitions: src/Boundaries/CLBoundaries.clh:44-50 */
 enum { ORC_UNIFORM_RAIN_INTENSITY = 0, ORC_UNIFORM_LOSS_RATE = 1 };
 enum { ORC_GRIDDED_RAIN_INTENSITY = 0, ORC_GRIDDED_RAIN_ACCUMUL = 1, ORC_GRIDDED_MASS_FLUX = 2 };
+/* cell-boundary definitions: src/Boundaries/CLBoundaries.clh:34-42 */
+enum { ORC_DEPTH_IGNORE = 0, ORC_DEPTH_IS_FSL = 1, ORC_DEPTH_IS_DEPTH = 2, ORC_DEPTH_IS_CRITICAL = 3 };
+enum { ORC_DISCHARGE_IGNORE = 0, ORC_DISCHARGE_IS_DISCHARGE = 1, ORC_DISCHARGE_IS_VELOCITY = 2, ORC_DISCHARGE_IS_VOLUME = 3 };
 
 typedef struct {
 	long  cols, rows;
@@ -100,6 +103,11 @@ void  orc_bdy_gridded(const orc_params* p, const orc_scalars* s, int definition,
                       unsigned long grows, unsigned long gcols, real resolution, real off_x, real off_y,
                       real interval, real* state, const real* bed, int truncated_range);
 
+void  orc_bdy_cell(const orc_params* p, const orc_scalars* s, int depth_def, int discharge_def,
+                   const unsigned long* relations, unsigned long count,
+                   const real* series /* [entries][4] time, depth/fsl, qx, qy */, unsigned long entries,
+                   real interval, real length, real* state, const real* bed);
+
 /* ---- simulation level: scheduleIteration (CSchemeGodunov.cpp:1617-1666,
  *      CSchemeMUSCLHancock.cpp:646-680) incl. ping-pong and quirks ---- */
 typedef struct orc_sim orc_sim;
@@ -110,6 +118,8 @@ int      orc_sim_add_uniform(orc_sim* s, int definition, const real* series, uns
 int      orc_sim_add_gridded(orc_sim* s, int definition, const real* grids, unsigned long entries,
                              unsigned long grows, unsigned long gcols, real resolution, real off_x, real off_y,
                              real interval);
+int      orc_sim_add_cell(orc_sim* s, int depth_def, int discharge_def, const unsigned long* relations,
+                          unsigned long count, const real* series, unsigned long entries, real interval, real length);
 void     orc_sim_set_target(orc_sim* s, real t_sync);
 void     orc_sim_force_dt(orc_sim* s, real dt);
 void     orc_sim_reset_counters(orc_sim* s);

@@ -220,6 +220,29 @@ def rain(precision, tag):
     save(f"f9_rain_{tag}", **out)
 
 
+CELL_MODES = [("depth_q", 2, 1), ("fsl_vel", 1, 2), ("free_q", 0, 1), ("free_volume", 0, 3)]
+
+
+def cell_boundary(precision, tag):
+    """F11: bdy_Cell -- imposed depth / level / discharge / velocity / volume on a short line of cells."""
+    real = np.float64 if precision == "f64" else np.float32
+    cols, rows = 60, 44
+    st, bed, man = syn.s_rough(cols, rows, dtype=real, pool_level=-10.0, amplitude=0.2, walls=True)
+    st[..., 2:] = 0
+    series = np.array([[0, 0.0, 0.0, 0.0], [5, 0.3, 0.4, 0.1], [10, 0.6, 0.8, 0.0], [15, 0.2, 0.1, -0.2], [20, 0.0, 0.0, 0.0]], real)
+    cells = np.array([10 * cols + 5, 11 * cols + 5, 12 * cols + 5, 30 * cols + 40], np.uint64)
+    out = dict(state=st, bed=bed, manning=man, series=series, cells=cells)
+    for name, dd, qd in CELL_MODES:
+        sim = oracle.RefSim(cols, rows, precision=precision)
+        sim.upload(st, bed, man)
+        sim.add_cell(dd, qd, cells, series, 5.0, 20.0)
+        sim.set_target(1e9)
+        out[f"{name}_dt"] = sim.run(300)
+        out[f"{name}_state"] = sim.download()
+        out[f"{name}_t"] = np.array(sim.scalars()["t"])
+    save(f"f11_cell_boundary_{tag}", **out)
+
+
 def newcastle(precision, tag):
     """F10: Newcastle-shaped (342x195 @ 2 m) rain + drainage, Godunov fp64 (config C1 stand-in DEM)."""
     real = np.float64
@@ -246,5 +269,6 @@ if __name__ == "__main__":
         trajectories(precision, precision)
         time_control(precision, precision)
         rain(precision, precision)
+        cell_boundary(precision, precision)
     trajectories("f64", "f64_mad", mad=True)
     newcastle("f64", "f64")

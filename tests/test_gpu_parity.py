@@ -175,6 +175,33 @@ def test_newcastle_shaped_rain_drainage(mode, t_rel):
     assert abs(dom.read_scalars()["time"] - float(g["t"])) < t_rel * float(g["t"])
 
 
+@pytest.mark.parametrize("name,dd,qd", [("depth_q", 2, 1), ("fsl_vel", 1, 2), ("free_q", 0, 1), ("free_volume", 0, 3)])
+def test_cell_boundary_fixture(name, dd, qd):
+    """bdy_Cell against the fixture produced by the reference's kernel (row N2 of SURVEY 8f)."""
+    g = load_golden("f11_cell_boundary_f64")
+    rows, cols = g["bed"].shape
+    dom = hp.Domain(cols, rows)
+    dom.upload(g["state"], g["bed"], g["manning"])
+    dom.add_cell(dd, qd, g["cells"], g["series"], 5.0, 20.0)
+    dom.set_target_time(1e9)
+    dom.step_batch(300)
+    out = dom.download()
+    dg = np.maximum(0, out[..., 0] - g["bed"])
+    dr = np.maximum(0, g[f"{name}_state"][..., 0] - g["bed"])
+    assert dr.max() > 0.05
+    assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
+    assert abs(dom.read_scalars()["time"] - float(g[f"{name}_t"])) < 1e-9
+
+
+def test_cell_boundary_rejects_bad_input():
+    dom = hp.Domain(32, 32)
+    series = np.zeros((3, 4)); series[:, 0] = [0, 5, 10]
+    with pytest.raises(hp.HipimsError, match="outside the grid"):
+        dom.add_cell(2, 1, [32 * 32], series, 5.0, 10.0)
+    with pytest.raises(hp.HipimsError, match="shorter than its length"):
+        dom.add_cell(2, 1, [40], series, 5.0, 20.0)
+
+
 def test_partial_transfers_and_busy_flag():
     st, bed, man = syn.s_rough(48, 40, manning=None)
     dom = hp.Domain(48, 40)

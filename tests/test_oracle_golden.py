@@ -181,6 +181,29 @@ def test_rain_boundaries(precision):
     assert (full[..., 0] - g["bed"]).sum() > (g["gridded_state"][..., 0] - g["bed"]).sum() > 0
 
 
+CELL_MODES = [("depth_q", 2, 1), ("fsl_vel", 1, 2), ("free_q", 0, 1), ("free_volume", 0, 3)]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_cell_boundary(precision):
+    """bdy_Cell: four depth/discharge definitions, linear interpolation in time."""
+    g = load_golden(f"f11_cell_boundary_{precision}")
+    rows, cols = g["bed"].shape
+    finals = []
+    for name, dd, qd in CELL_MODES:
+        sim = oracle.OracleSim(cols, rows, precision=precision)
+        sim.upload(g["state"], g["bed"], g["manning"])
+        sim.add_cell(dd, qd, g["cells"], g["series"], 5.0, 20.0)
+        sim.set_target(1e9)
+        dt = sim.run(300)
+        assert same(dt, g[f"{name}_dt"])
+        assert same(sim.download(), g[f"{name}_state"])
+        assert sim.scalars()["t"] == g[f"{name}_t"]
+        finals.append(g[f"{name}_state"])
+        assert (g[f"{name}_state"][..., 0] - g["bed"]).max() > 0.05
+    assert not same(finals[0], finals[1]) and not same(finals[2], finals[3])
+
+
 def test_newcastle_shape():
     g = load_golden("f10_newcastle_f64")
     from hipims_mi import synthetic as syn
