@@ -253,6 +253,9 @@ class OracleSim(_SimBase):
     def reset_counters(self):
         self.lib.orc_sim_reset_counters(self.h)
 
+    def update_timestep(self):
+        self.lib.orc_sim_update_timestep(self.h)
+
     def run(self, n):
         trace = np.zeros(n, self.real)
         self.lib.orc_sim_run(self.h, C.c_long(n), _ptr(trace))
@@ -440,6 +443,11 @@ class RefSim(_SimBase):
         self.batch_dt[0] = 0
         self.ok[0] = 0
         self.skipped[0] = 0
+
+    def update_timestep(self):
+        self._configure()
+        self.lib.ref_reduce(_ptr(self.primary), _ptr(self.bed), _ptr(self.scratch))
+        self.lib.ref_update_timestep(_ptr(self.t), _ptr(self.dt), _ptr(self.scratch), _ptr(self.t_sync), _ptr(self.batch_dt))
 
     def _apply_boundaries(self, target):
         full = 0 if (self.quirks & Q9_BDY_TRUNCATED) else 1

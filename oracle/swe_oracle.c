@@ -963,6 +963,13 @@ void orc_sim_force_dt(orc_sim* s, real dt)       { s->sc.dt = dt; }             
 void orc_sim_reset_counters(orc_sim* s)                                           /* tst_ResetCounters, CLDynamicTimestep.clc:151-161 */
 { s->sc.batch_dt = RC(0.0); s->sc.batch_ok = 0; s->sc.batch_skipped = 0; }
 
+void orc_sim_update_timestep(orc_sim* s)
+{
+	real vmax = RC(0.0);
+	if (s->p.dynamic_dt) vmax = orc_cfl_max_speed(&s->p, s->primary, s->bed);
+	orc_update_timestep(&s->p, &s->sc, vmax);
+}
+
 static void apply_boundaries(orc_sim* s, real* target)
 {
 	/* CBoundaryMap::applyBoundaries (CBoundaryMap.cpp:76-80): one kernel per boundary, unordered in the

@@ -123,6 +123,9 @@ int      orc_sim_add_cell(orc_sim* s, int depth_def, int discharge_def, const un
 void     orc_sim_set_target(orc_sim* s, real t_sync);
 void     orc_sim_force_dt(orc_sim* s, real dt);
 void     orc_sim_reset_counters(orc_sim* s);
+/* tst_Reduce (primary buffer) + tst_UpdateTimestep, as Threaded_runBatch queues them after a new target time
+ * (CSchemeGodunov.cpp:1189-1195) */
+void     orc_sim_update_timestep(orc_sim* s);
 /* run n iterations; if dt_trace != NULL it receives the dt USED by each iteration */
 void     orc_sim_run(orc_sim* s, long n, real* dt_trace);
 void     orc_sim_scalars(const orc_sim* s, orc_scalars* out);

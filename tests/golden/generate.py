@@ -244,22 +244,24 @@ def cell_boundary(precision, tag):
 
 
 def newcastle(precision, tag):
-    """F10: Newcastle-shaped (342x195 @ 2 m) rain + drainage, Godunov fp64 (config C1 stand-in DEM)."""
-    real = np.float64
-    st, bed, man = syn.newcastle_like(dtype=real)
-    series = np.array([[0, 70.0], [3600, 70.0], [7200, 0.0], [10800, 0.0]], real)
-    loss = np.array([[0, 12.0], [10800, 12.0]], real)
-    sim = oracle.RefSim(342, 195, precision=precision, dx=2.0, end_time=7200.0)
+    """F10: config C1 -- the reference's own example (342x195 @ 2 m DEM from its data file, rain 70 mm/h + drainage
+    12 mm/h, closed edges), Godunov fp64, first 900 iterations on the reference's kernels."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hipims_mi import frontend
+    from model_dir import make_newcastle
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = frontend.parse_configuration(make_newcastle(tmp))
+        st, bed, man, res = frontend.build_domain(cfg)
+    sim = oracle.RefSim(342, 195, precision=precision, dx=res, end_time=cfg.duration)
     sim.upload(st, bed, man)
-    sim.add_uniform(oracle.UNIFORM_LOSS_RATE, loss, 10800.0, 10800.0)
-    sim.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, series, 3600.0, 10800.0)
+    frontend.attach_boundaries(cfg, sim, 342)
     sim.set_target(1e9)
     dt = sim.run(900)
     final = sim.download()
     depth = np.maximum(0, final[..., 0] - bed)
-    save(f"f10_newcastle_{tag}", series=series, loss=loss, dt=dt, t=np.array(sim.scalars()["t"]),
-         depth=depth.astype(np.float32), z=final[..., 0], qx=final[..., 2].astype(np.float32),
-         qy=final[..., 3].astype(np.float32))
+    save(f"f10_newcastle_{tag}", dt=dt, t=np.array(sim.scalars()["t"]), depth=depth.astype(np.float32),
+         z=final[..., 0], qx=final[..., 2].astype(np.float32), qy=final[..., 3].astype(np.float32))
 
 
 if __name__ == "__main__":

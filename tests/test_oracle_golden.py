@@ -204,14 +204,16 @@ def test_cell_boundary(precision):
     assert not same(finals[0], finals[1]) and not same(finals[2], finals[3])
 
 
-def test_newcastle_shape():
+def test_newcastle_example(tmp_path):
+    """Config C1: the reference's example model (its own DEM file, rain + drainage), 900 iterations."""
+    from hipims_mi import frontend
+    from model_dir import make_newcastle
     g = load_golden("f10_newcastle_f64")
-    from hipims_mi import synthetic as syn
-    st, bed, man = syn.newcastle_like()
-    sim = oracle.OracleSim(342, 195, dx=2.0, end_time=7200.0)
+    cfg = frontend.parse_configuration(make_newcastle(tmp_path))
+    st, bed, man, res = frontend.build_domain(cfg)
+    sim = oracle.OracleSim(342, 195, dx=res, end_time=cfg.duration)
     sim.upload(st, bed, man)
-    sim.add_uniform(oracle.UNIFORM_LOSS_RATE, g["loss"], 10800.0, 10800.0)
-    sim.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, g["series"], 3600.0, 10800.0)
+    frontend.attach_boundaries(cfg, sim, 342)
     sim.set_target(1e9)
     dt = sim.run(900)
     assert same(dt, g["dt"])
