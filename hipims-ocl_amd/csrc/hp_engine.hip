@@ -412,7 +412,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	d->esize = (size_t)desc->precision;
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
-		if (v >= 1 && v <= 128) d->march_rseg = v;
+		if (v >= 1 && v <= 64) d->march_rseg = v;
 	}
 	if (const char* e = std::getenv("HP_MUSCL_RSEG")) {
 		const int v = std::atoi(e);

@@ -148,6 +148,62 @@ __global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const i
 //  * blockIdx is remapped so that each XCD (blocks b, b+8, ... share one) works on a contiguous run of tiles
 //    and neighbouring tiles' halo rows/columns hit the same L2.
 // -------------------------------------------------------------------------------------------------
+// ---- buffer-resource addressing (gfx9 SRD): base in 4 SGPRs, per-lane byte offset in ONE VGPR that never changes,
+//      per-row offset in an SGPR -> no 64-bit VALU address arithmetic in the row loop, and stores whose offset lies
+//      beyond num_records are dropped by the hardware range check (how non-writing lanes are masked).
+typedef unsigned int hp_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int hp_u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned HP_SRD_FLAGS = 0x00020000u;        // raw buffer, 32-bit data format (gfx90a/gfx94x/gfx950)
+constexpr unsigned HP_OOB = 0x80000000u;              // any offset >= num_records: access dropped
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, const size_t bytes)
+{
+	const unsigned n = bytes > 0x7fffffffull ? 0x7fffffffu : (unsigned)bytes;
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, (int)HP_SRD_FLAGS);
+}
+
+__device__ __forceinline__ State4<double> buf_load_state(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, double)
+{
+	const hp_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+	const hp_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff + 16, (int)soff, 0);
+	State4<double> s;
+	s.z    = __hiloint2double((int)a.y, (int)a.x); s.zmax = __hiloint2double((int)a.w, (int)a.z);
+	s.qx   = __hiloint2double((int)b.y, (int)b.x); s.qy   = __hiloint2double((int)b.w, (int)b.z);
+	return s;
+}
+__device__ __forceinline__ State4<float> buf_load_state(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, float)
+{
+	const hp_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+	State4<float> s;
+	s.z = __uint_as_float(a.x); s.zmax = __uint_as_float(a.y); s.qx = __uint_as_float(a.z); s.qy = __uint_as_float(a.w);
+	return s;
+}
+__device__ __forceinline__ double buf_load_scalar(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, double)
+{
+	const hp_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+	return __hiloint2double((int)a.y, (int)a.x);
+}
+__device__ __forceinline__ float buf_load_scalar(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, float)
+{
+	return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff)
+{
+	hp_u32x4 a, b;
+	a.x = (unsigned)__double2loint(s.z);  a.y = (unsigned)__double2hiint(s.z);
+	a.z = (unsigned)__double2loint(s.zmax); a.w = (unsigned)__double2hiint(s.zmax);
+	b.x = (unsigned)__double2loint(s.qx); b.y = (unsigned)__double2hiint(s.qx);
+	b.z = (unsigned)__double2loint(s.qy); b.w = (unsigned)__double2hiint(s.qy);
+	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, 0);
+	__builtin_amdgcn_raw_buffer_store_b128(b, r, (int)voff + 16, (int)soff, 0);
+}
+__device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff)
+{
+	hp_u32x4 a;
+	a.x = __float_as_uint(s.z); a.y = __float_as_uint(s.zmax); a.z = __float_as_uint(s.qx); a.w = __float_as_uint(s.qy);
+	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, 0);
+}
+
 constexpr int MARCH_COLS = 62;          // updated columns per wavefront (lanes 1..62)
 
 template <typename T> struct RowRegs { State4<T> c; T zb, n; };
@@ -173,7 +229,9 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	// XCD-aware tile order (grid is a multiple of 8 blocks)
 	const unsigned per_xcd = gridDim.x >> 3;
 	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// the wave index is made a scalar explicitly: everything derived from it (tile rows, buffer descriptors, row
+	// offsets) then lives in SGPRs and the buffer accesses need no waterfall loop
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const long strip = (long)(tile % (unsigned)groups) * 4 + wave;
 	const long seg = tile / (unsigned)groups;
 	if (tile < (unsigned)ntiles && strip < nstrips) {                              // wave-uniform
@@ -189,31 +247,53 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	const bool skip_step = dt <= T(0);                                             // CLSchemeGodunov.clc:201-206
 	const bool with_friction = p.friction != 0;
 	T vmax = T(0);
-	unsigned long long stale_lo = 0, stale_hi = 0;   // bit i: row y0+i of this lane was left untouched (all-dry, Q3); rseg <= 128
+	unsigned long long stale_rows = 0;   // bit i: row y0+i of this lane was left untouched (all-dry, Q3); rseg <= 64
+
+	// the wave's window of the four arrays, addressed from its first cell (row y0-1, column of lane 0)
+	const size_t cell0 = (size_t)(y0 - 1) * p.cols + (size_t)(strip * MARCH_COLS);
+	const size_t cells_left = (size_t)p.cols * p.rows - cell0;
+	const __amdgpu_buffer_rsrc_t srd_src = make_srd(src + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_dst = make_srd(dst + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_bed = make_srd(bed + cell0, cells_left * sizeof(T));
+	const __amdgpu_buffer_rsrc_t srd_man = make_srd(manning + cell0, cells_left * sizeof(T));
+	const unsigned lane_col = (unsigned)(xc - strip * MARCH_COLS);                // clamped column within the window
+	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
+	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
 
 	auto load_row = [&](const long y) {
 		RowRegs<T> r;
-		const size_t id = (size_t)y * p.cols + xc;
-		r.c = src[id]; r.zb = bed[id]; r.n = manning[id];
+		const unsigned k = (unsigned)(y - (y0 - 1));                               // wave-uniform -> SGPR offsets
+		r.c = buf_load_state(srd_src, voff_state, k * row_state, T());
+		r.zb = buf_load_scalar(srd_bed, voff_scalar, k * row_scalar, T());
+		r.n = buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
 		return r;
 	};
 
-	// pipeline fill: row y0-1 (south of the segment) gives the first south face; rows are fetched two ahead of
-	// the one being updated so a wave always has a 3 KiB row in flight behind ~400 VALU instructions of work
-	RowRegs<T> rs = load_row(y0 - 1);
+	// pipeline fill: row y0-1 (south of the segment) gives the first south face.  Rows are fetched two ahead of the
+	// one being updated, into two landing sets P and Q that alternate (the loop is unrolled twice): the row in flight
+	// is never copied, so the only wait for it is at its first real use one iteration later.  (A rolled loop has to
+	// copy "in flight" -> "next" at the bottom of every iteration, which parks the wave on vmcnt right there and
+	// collapses the prefetch distance to less than one row -- measured with in-kernel stamps: 30-50 % of a row's
+	// cycles sat in that copy.)
 	RowRegs<T> rc = load_row(y0);
-	RowRegs<T> rn = load_row(y0 + 1);                                              // y0+1 <= rows-1 always
-	Side<T> sS = make_side<STRICT>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
-	Side<T> sC = make_side<STRICT>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
-	bool dryS = (rs.c.z - rs.zb) < vs;
+	RowRegs<T> rP = load_row(y0 + 1), rQ;                                          // y0+1 <= rows-1 always
+	Side<T> sC;
 	FaceFlux<T> fS = {};
-	if (!skip_step) fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
+	bool dryS;
+	{
+		const RowRegs<T> rs = load_row(y0 - 1);
+		const Side<T> sS = make_side<STRICT>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
+		sC = make_side<STRICT>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
+		dryS = (rs.c.z - rs.zb) < vs;
+		if (!skip_step) fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
+	}
 
-	for (long y = y0; y < y1; ++y) {
-		const size_t id = (size_t)y * p.cols + xc;
-		const RowRegs<T> rnn = load_row((y + 2 < p.rows) ? (y + 2) : (p.rows - 1));   // prefetch (clamped)
+	// one row: `rc` is updated, `rn` is its northern neighbour (already landed), `pre` receives the prefetch of row y+2
+	auto row_step = [&](const long y, const RowRegs<T>& rn, RowRegs<T>& pre) {
+		pre = load_row((y + 2 < p.rows) ? (y + 2) : (p.rows - 1));                 // prefetch (clamped)
 		State4<T> out = rc.c;
 		bool write = out_x;
+		Side<T> sN = sC;
 
 		if (!skip_step) {
 			// east face first: its result has to travel to the next lane while the north face is solved
@@ -231,7 +311,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			const bool dryE = (sE.eta - sE.zb) < vs;
 			const bool dryN = (rn.c.z - rn.zb) < vs;
 
-			const Side<T> sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
+			sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
 			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sC, sN, vs);
 			const FaceFlux<T> fN = fy.forL;
 
@@ -242,24 +322,20 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			if (!disabled) {
 				if (dry5) {                                                               // dst untouched (Q3)
 					write = false;
-					if (out_x) {
-						const unsigned bit = (unsigned)(y - y0);
-						if (bit < 64) stale_lo |= 1ull << bit; else stale_hi |= 1ull << (bit - 64);
-					}
+					if (out_x) stale_rows |= 1ull << (unsigned)(y - y0);
 				} else {
 					out = upd;
 				}
 			}
 			fS = fy.forR;
 			dryS = dryC;
-			sC = sN;
 		}
 
-		// One unconditional store per row: lanes that must not write (halo lanes, all-dry cells) aim at a sink
-		// line instead of branching around the store, which keeps the wave's vmcnt bookkeeping static so the
-		// wait for the prefetched row never has to drain the stores behind it.
-		State4<T>* const target = write ? (dst + id) : (sink + lane);
-		*target = out;
+		// One unconditional store per row: lanes that must not write (halo lanes, all-dry cells) present an
+		// out-of-range offset, which the buffer range check drops, instead of branching around the store.  That
+		// keeps the wave's vmcnt bookkeeping static so the wait for the prefetched row never has to drain the
+		// stores behind it.
+		buf_store_state(out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
 		if (CFL_MODE == 1) {
 			if (write) {
 				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
@@ -271,15 +347,21 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 				if (s > vmax) vmax = s;
 			}
 		}
-		rc = rn;
-		rn = rnn;
-	}
+		rc = rn;                     // a copy of values that have already been used: no wait attached to it
+		sC = sN;
+	};
 
-	if (CFL_MODE == 1 && __any((stale_lo | stale_hi) != 0)) {
+	long y = y0;
+	for (; y + 2 <= y1; y += 2) {
+		row_step(y, rP, rQ);
+		row_step(y + 1, rQ, rP);
+	}
+	if (y < y1) row_step(y, rP, rQ);
+
+	if (CFL_MODE == 1 && __any(stale_rows != 0)) {
 		// cells the reference leaves untouched still hold their two-steps-old value in dst, and tst_Reduce prices it
 		for (long y = y0; y < y1; ++y) {
-			const unsigned bit = (unsigned)(y - y0);
-			if ((bit < 64 ? (stale_lo >> bit) : (stale_hi >> (bit - 64))) & 1ull) {
+			if ((stale_rows >> (unsigned)(y - y0)) & 1ull) {
 				const size_t id = (size_t)y * p.cols + xc;
 				const State4<T> c = dst[id];
 				const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);

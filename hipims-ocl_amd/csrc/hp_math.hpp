@@ -233,7 +233,60 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 
 	// ---- HLLC ----
 	FaceFlux<T> oL, oR;
-	if (hL < vs && hR < vs) {
+	// Wave-uniform fast path (FAST flavour): when every lane of the wavefront has water on both sides of its face,
+	// none of the dry-side forms, zeroed velocities or stopping conditions can apply (they all test h <= VERY_SMALL),
+	// and when in addition every lane is in the subcritical "middle" region of the HLLC fan only the HLL middle state
+	// is needed.  Same formulas, same results -- the selects between alternatives nobody takes are simply not executed.
+	if (!STRICT && __all(hL > vs && hR > vs)) {
+		FaceCore<T> k;
+		k.etaL = etaL; k.etaR = etaR; k.zbm = zbm;
+		k.unL = (AXIS == AXIS_X ? L.u0 : L.v0); k.unR = (AXIS == AXIS_X ? R.u0 : R.v0);
+		k.utL = (AXIS == AXIS_X ? L.v0 : L.u0); k.utR = (AXIS == AXIS_X ? R.v0 : R.u0);
+		k.qnL = (AXIS == AXIS_X ? qxL : qyL); k.qnR = (AXIS == AXIS_X ? qxR : qyR);
+		k.qtL = (AXIS == AXIS_X ? qyL : qxL); k.qtR = (AXIS == AXIS_X ? qyR : qxR);
+		const T aL = sqrt_fast(g * hL), aR = sqrt_fast(g * hR);
+		const T tmp = (aL + aR) / 2 + (k.unL - k.unR) / 4;
+		const T u_star = (k.unL + k.unR) / 2 + aL - aR;
+		const T a_star = fabs_(tmp);
+		const T sL = fmin_(k.unL - aL, u_star - a_star), sR = fmax_(k.unR + aR, u_star + a_star);
+		k.sL = sL; k.sR = sR; k.sLsR = sL * sR;
+		const T sm_num = sL * hR * (k.unR - sR) - sR * hL * (k.unL - sL);
+		const T sm_den = hR * (k.unR - sR) - hL * (k.unL - sL);
+		const bool sm_nonneg = (sm_den < T(0)) ? (sm_num <= T(0)) : ((sm_num / sm_den) >= T(0));
+		k.inv_ds = rcp_fast(sR - sL);
+		if (__all(sL < T(0) && sR >= T(0))) {
+			auto finish_mid = [&](const T s, const bool own_left) {
+				const T half_g = T(0.5) * g;
+				const T a = etaL - s, b = etaR - s, zb = zbm - s;
+				const T fnL = fma_(k.unL, k.qnL, half_g * (a * (a - 2 * zb)));
+				const T fnR = fma_(k.unR, k.qnR, half_g * (b * (b - 2 * zb)));
+				const T f1m = fma_(k.sLsR, (b - a), fma_(sR, k.qnL, -(sL * k.qnR))) * k.inv_ds;
+				const T f2m = fma_(k.sLsR, (k.qnR - k.qnL), fma_(sR, fnL, -(sL * fnR))) * k.inv_ds;
+				const T ft = f1m * (sm_nonneg ? k.utL : k.utR);
+				FaceFlux<T> o;
+				o.f0 = f1m;
+				o.fx = (AXIS == AXIS_X ? f2m : ft);
+				o.fy = (AXIS == AXIS_X ? ft : f2m);
+				o.eta_nb = own_left ? b : a;
+				o.zb_nb = zb;
+				o.stop = false;
+				return o;
+			};
+			oL = finish_mid(shL, true);
+			oR = oL;
+			if (shL != shR) oR = finish_mid(shR, false);
+			oR.eta_nb = etaL - shR;
+		} else {
+			k.bLeft = sL >= T(0);
+			k.bMid1 = sL < T(0) && sR >= T(0) && sm_nonneg;
+			const bool bMid2 = sL < T(0) && sR >= T(0) && !k.bMid1;
+			k.bRight = !k.bLeft && !k.bMid1 && !bMid2;
+			oL = finish_wet<AXIS, STRICT>(k, shL, true, false);
+			oR = oL;
+			if (shL != shR) oR = finish_wet<AXIS, STRICT>(k, shR, false, false);
+			oR.eta_nb = etaL - shR;
+		}
+	} else if (hL < vs && hR < vs) {
 		oL = finish_dry<AXIS>(etaL, etaR, zbm, shL, true, stopL);
 		oR = finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
 	} else {
