@@ -54,6 +54,8 @@ struct hp_domain {
 	void*            scalars = nullptr;               // Scalars<T> on the device
 	void*            sink = nullptr;                  // 64 State4 slots: where non-writing lanes of godunov_march store
 	void*            cfl_slot = nullptr;              // T[4]: running max | last used max | edge ring of [0] | of [1]
+	bool             manning_uniform = false;         // found at upload: one value everywhere -> kernels skip the array
+	double           manning_value = 0.0;
 	bool             need_full_reduce = true;         // the remembered maximum is stale (upload / link import)
 	bool             edge_dirty = true;               // edge-ring maxima must be re-priced
 	int              adv_fresh = 1;                   // does hp_step_end's advance kernel read a new maximum?
@@ -88,6 +90,8 @@ template <typename T> Params<T> make_params(const hp_domain* d)
 	p.dt_fixed = (T)d->desc.dt_fixed;
 	p.friction = d->desc.friction;
 	p.dynamic_dt = d->desc.dynamic_dt;
+	p.manning_uniform = d->manning_uniform ? 1 : 0;
+	p.manning_value = (T)d->manning_value;
 	return p;
 }
 
@@ -493,6 +497,21 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 	case HP_ARRAY_MANNING:
 		if (bytes != d->cells * d->esize) return fail(HP_ERR_INVALID, "manning size mismatch");
 		HIP_TRY(hipMemcpyAsync(d->manning, host, bytes, hipMemcpyHostToDevice, d->stream));
+		{
+			// "constant" Manning sources are the norm (<dataSource type="constant" value="manningCoefficient">):
+			// a uniform array is passed to the kernels as a scalar and its 8 B/cell are not streamed every step
+			bool same = true;
+			if (d->esize == 8) {
+				const double* v = (const double*)host;
+				for (size_t i = 1; i < d->cells && same; ++i) same = (v[i] == v[0]);
+				d->manning_value = v[0];
+			} else {
+				const float* v = (const float*)host;
+				for (size_t i = 1; i < d->cells && same; ++i) same = (v[i] == v[0]);
+				d->manning_value = v[0];
+			}
+			d->manning_uniform = same;
+		}
 		return HP_OK;
 	}
 	return fail(HP_ERR_INVALID, "unknown array id");

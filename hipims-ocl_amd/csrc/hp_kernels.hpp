@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		const unsigned k = (unsigned)(y - (y0 - 1));                               // wave-uniform -> SGPR offsets
 		r.c = buf_load_state(srd_src, voff_state, k * row_state, T());
 		r.zb = buf_load_scalar(srd_bed, voff_scalar, k * row_scalar, T());
-		r.n = buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
+		r.n = p.manning_uniform ? p.manning_value : buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
 		return r;
 	};
 
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 	auto load_row = [&](const long y) {
 		RowRegs<T> r;
 		const size_t id = (size_t)y * p.cols + xc;
-		r.c = src[id]; r.zb = bed[id]; r.n = manning[id];
+		r.c = src[id]; r.zb = bed[id];
+		r.n = p.manning_uniform ? p.manning_value : manning[id];
 		return r;
 	};
 	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w) {

@@ -23,6 +23,8 @@ template <typename T> struct Params {
 	long row_offset, global_rows;
 	T    dx, inv_dx, vs, qs, courant, t_end, dt_fixed;
 	int  friction, dynamic_dt;
+	int  manning_uniform;        // every cell has the same Manning n (the usual "constant" data source): not re-read per step
+	T    manning_value;
 };
 
 // device-resident time-control block ("Time", "Timestep", ... buffers, CSchemeGodunov.cpp:852-872)
