@@ -52,7 +52,6 @@ struct hp_domain {
 	void*            bed = nullptr;
 	void*            manning = nullptr;
 	void*            scalars = nullptr;               // Scalars<T> on the device
-	void*            sink = nullptr;                  // 64 State4 slots: where non-writing lanes of godunov_march store
 	void*            cfl_slot = nullptr;              // T[4]: running max | last used max | edge ring of [0] | of [1]
 	bool             manning_uniform = false;         // found at upload: one value everywhere -> kernels skip the array
 	double           manning_value = 0.0;
@@ -172,7 +171,7 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer)
 	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, d->stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer,
-	                   (State4<T>*)d->sink, rseg, nstrips, groups, ntiles);
+	                   rseg, nstrips, groups, ntiles);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -191,7 +190,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer)
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), dbg_lds, d->stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer,
-	                   (State4<T>*)d->sink, rseg, nstrips, groups, ntiles);
+	                   rseg, nstrips, groups, ntiles);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -437,7 +436,6 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	HIP_TRY_C(hipMalloc(&d->manning, d->cells * d->esize));
 	HIP_TRY_C(hipMalloc(&d->scalars, 256));
 	HIP_TRY_C(hipMalloc(&d->cfl_slot, 1024));
-	HIP_TRY_C(hipMalloc(&d->sink, 64 * 32));
 
 	HIP_TRY_C(hipHostMalloc(&d->host_scalars, 512, hipHostMallocDefault));
 	HIP_TRY_C(hipMemset(d->state[0], 0, d->cells * 4 * d->esize));
@@ -463,7 +461,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	for (auto& b : d->bdy) { hipFree(b.data); hipFree(b.cells); }
 	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
-	hipFree(d->scalars); hipFree(d->cfl_slot); hipFree(d->sink);
+	hipFree(d->scalars); hipFree(d->cfl_slot);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
 	if (d->ev_stop) hipEventDestroy(d->ev_stop);

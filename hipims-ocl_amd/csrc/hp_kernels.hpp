@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
-                                                     State4<T>* __restrict__ sink, const int rseg, const int nstrips,
+                                                     const int rseg, const int nstrips,
                                                      const int groups, const int ntiles)
 {
 	// XCD-aware tile order (grid is a multiple of 8 blocks)
@@ -407,12 +407,12 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
                                                    const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                    State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                    T* cfl_slot, const T* __restrict__ edge_max,
-                                                   State4<T>* __restrict__ sink, const int rseg, const int nstrips,
+                                                   const int rseg, const int nstrips,
                                                    const int groups, const int ntiles)
 {
 	const unsigned per_xcd = gridDim.x >> 3;
 	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: see K1
 	const long strip = (long)(tile % (unsigned)groups) * 4 + wave;
 	const long seg = tile / (unsigned)groups;
 	if (tile < (unsigned)ntiles && strip < nstrips) {
@@ -429,11 +429,23 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 	const bool with_friction = p.friction != 0;
 	T vmax = T(0);
 
+	// buffer-resource addressing as in K1: window base = row y0-2, column of lane 0
+	const size_t cell0 = (size_t)(y0 - 2) * p.cols + (size_t)(strip * MUSCL_COLS);
+	const size_t cells_left = (size_t)p.cols * p.rows - cell0;
+	const __amdgpu_buffer_rsrc_t srd_src = make_srd(src + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_dst = make_srd(dst + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_bed = make_srd(bed + cell0, cells_left * sizeof(T));
+	const __amdgpu_buffer_rsrc_t srd_man = make_srd(manning + cell0, cells_left * sizeof(T));
+	const unsigned lane_col = (unsigned)(xc - strip * MUSCL_COLS);
+	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
+	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
+
 	auto load_row = [&](const long y) {
 		RowRegs<T> r;
-		const size_t id = (size_t)y * p.cols + xc;
-		r.c = src[id]; r.zb = bed[id];
-		r.n = p.manning_uniform ? p.manning_value : manning[id];
+		const unsigned k = (unsigned)(y - (y0 - 2));
+		r.c = buf_load_state(srd_src, voff_state, k * row_state, T());
+		r.zb = buf_load_scalar(srd_bed, voff_scalar, k * row_scalar, T());
+		r.n = p.manning_uniform ? p.manning_value : buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
 		return r;
 	};
 	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w) {
@@ -444,28 +456,31 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs);
 	};
 
-	RowRegs<T> rs2 = load_row(y0 - 2);
-	RowRegs<T> rs = load_row(y0 - 1);
 	RowRegs<T> rc = load_row(y0);
 	RowRegs<T> rn = load_row(y0 + 1);                                              // y0+1 <= rows-2
-	RowRegs<T> rnn = load_row((y0 + 2 < p.rows) ? (y0 + 2) : (p.rows - 1));
+	RowRegs<T> rP = load_row((y0 + 2 < p.rows) ? (y0 + 2) : (p.rows - 1)), rQ;    // landing sets of the row two ahead
 
 	Faces<T> pc = {};
 	FaceFlux<T> fS = {};
-	bool dryE = false, dryW = false;
-	if (!skip_step) {
-		bool de, dw;
-		const Faces<T> ps = predict(rs2, rs, rc, de, dw);
-		pc = predict(rs, rc, rn, dryE, dryW);
-		const Side<T> sS = side_from_face<STRICT>(ps.n, rs.c.qx, rs.c.qy, vs);
-		const Side<T> sC = side_from_face<STRICT>(pc.s, rc.c.qx, rc.c.qy, vs);
-		fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
+	bool dryE = false, dryW = false, dryS;
+	{
+		const RowRegs<T> rs2 = load_row(y0 - 2);
+		const RowRegs<T> rs = load_row(y0 - 1);
+		dryS = rs.c.zmax < vs;
+		if (!skip_step) {
+			bool de, dw;
+			const Faces<T> ps = predict(rs2, rs, rc, de, dw);
+			pc = predict(rs, rc, rn, dryE, dryW);
+			const Side<T> sS = side_from_face<STRICT>(ps.n, rs.c.qx, rs.c.qy, vs);
+			const Side<T> sC = side_from_face<STRICT>(pc.s, rc.c.qx, rc.c.qy, vs);
+			fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
+		}
 	}
-	bool dryS = rs.c.zmax < vs;
 
-	for (long y = y0; y < y1; ++y) {
-		const size_t id = (size_t)y * p.cols + xc;
-		const RowRegs<T> rn3 = load_row((y + 3 < p.rows) ? (y + 3) : (p.rows - 1));   // prefetch (clamped)
+	// one row: `rc` is corrected, `rn` is its northern neighbour, `rnn` the row after (landed last iteration),
+	// `pre` receives the prefetch of row y+3; the row in flight is never copied (see K1)
+	auto row_step = [&](const long y, const RowRegs<T>& rnn, RowRegs<T>& pre) {
+		pre = load_row((y + 3 < p.rows) ? (y + 3) : (p.rows - 1));                 // prefetch (clamped)
 		State4<T> out = rc.c;
 
 		if (!skip_step) {
@@ -505,14 +520,20 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 			pc = pn;
 		}
 
-		State4<T>* const target = out_x ? (dst + id) : (sink + lane);
-		*target = out;
+		buf_store_state(out, srd_dst, out_x ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);
 		if (CFL_MODE == 1 && out_x) {
 			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
 			if (s > vmax) vmax = s;
 		}
-		rs = rc; rc = rn; rn = rnn; rnn = rn3;
+		rc = rn; rn = rnn;           // copies of rows that have already been used
+	};
+
+	long y = y0;
+	for (; y + 2 <= y1; y += 2) {
+		row_step(y, rP, rQ);
+		row_step(y + 1, rQ, rP);
 	}
+	if (y < y1) row_step(y, rP, rQ);
 
 	if (CFL_MODE != 0) {
 		if (tile == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
