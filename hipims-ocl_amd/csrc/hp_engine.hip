@@ -71,6 +71,11 @@ struct hp_domain {
 	uint64_t         timing_counter = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
 	long             own_lo = 0, own_hi = 0;          // rows this rank owns (CFL reduction range)
+	// halo overlap (strip decomposition): the row segments next to the ghost rows run on their own stream so the
+	// neighbours' halo transfer can start while the interior segments are still being computed
+	bool             halo_overlap = false;
+	hipStream_t      stream_halo = nullptr;
+	hipEvent_t       ev_fork = nullptr, ev_halo = nullptr;
 };
 
 namespace {
@@ -158,63 +163,95 @@ template <typename T> int price_edge_ring(hp_domain* d)
 	return HP_OK;
 }
 
+// Which row segments of the domain one launch covers
+enum { PART_ALL = 0, PART_HALO = 1, PART_INTERIOR = 2 };
+
+// Split of the `nsegs` row segments for the halo overlap: the first `a` and last `b` segments hold the `g` owned
+// rows next to each ghost row block.  Returns false when there is nothing left for an interior launch.
+inline bool split_segments(long updated_rows, int rseg, int g, int nsegs, int& a, int& b)
+{
+	a = (g + rseg - 1) / rseg;
+	const long last_len = updated_rows - (long)(nsegs - 1) * rseg;      // rows in the (possibly partial) last segment
+	b = 1;
+	for (long have = last_len; have < g; have += rseg) ++b;
+	return nsegs > a + b;
+}
+
+inline TileMap make_tile_map(long updated_rows, int rseg, int g, int nstrips, int part, bool& empty)
+{
+	TileMap tm;
+	tm.rseg = rseg; tm.nstrips = nstrips;
+	tm.groups = (nstrips + 3) / 4;
+	const int nsegs = (int)((updated_rows + rseg - 1) / rseg);
+	int a = 0, b = 0;
+	const bool can_split = split_segments(updated_rows, rseg, g, nsegs, a, b);
+	int count = nsegs;
+	tm.seg_first = 0; tm.seg_gap_at = 0x7fffffff; tm.seg_gap = 0;
+	if (part == PART_HALO && can_split) { count = a + b; tm.seg_gap_at = a; tm.seg_gap = nsegs - a - b; }
+	else if (part == PART_INTERIOR) {
+		if (can_split) { count = nsegs - a - b; tm.seg_first = a; }
+		else count = 0;                                                 // the halo launch took everything
+	}
+	tm.ntiles = tm.groups * count;
+	empty = count == 0;
+	return tm;
+}
+
 template <typename T, bool STRICT, int CFL_MODE>
-int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer)
+int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
 {
 	const Params<T> p = make_params<T>(d);
-	const int rseg = d->muscl_rseg;
-	const int nstrips = (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS);
-	const int groups = (nstrips + 3) / 4;
-	const int nsegs = (int)((p.rows - 4 + rseg - 1) / rseg);
-	const int ntiles = groups * nsegs;
-	const unsigned blocks = (unsigned)((ntiles + 7) / 8) * 8;
-	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, d->stream, p,
+	bool empty;
+	const TileMap tm = make_tile_map(p.rows - 4, d->muscl_rseg, 2, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS),
+	                                 part, empty);
+	if (empty) return HP_OK;
+	const unsigned blocks = (unsigned)((tm.ntiles + 7) / 8) * 8;
+	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer,
-	                   rseg, nstrips, groups, ntiles);
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
 
 template <typename T, bool STRICT, int CFL_MODE>
-int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer)
+int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
 {
 	const Params<T> p = make_params<T>(d);
-	const int rseg = d->march_rseg;
-	const int nstrips = (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS);
-	const int groups = (nstrips + 3) / 4;
-	const int nsegs = (int)((p.rows - 2 + rseg - 1) / rseg);
-	const int ntiles = groups * nsegs;
-	const unsigned blocks = (unsigned)((ntiles + 7) / 8) * 8;
+	bool empty;
+	const TileMap tm = make_tile_map(p.rows - 2, d->march_rseg, 1, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS),
+	                                 part, empty);
+	if (empty) return HP_OK;
+	const unsigned blocks = (unsigned)((tm.ntiles + 7) / 8) * 8;
 	static const int dbg_lds = std::getenv("HP_DEBUG_LDS") ? std::atoi(std::getenv("HP_DEBUG_LDS")) : 0;   // occupancy experiments
-	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), dbg_lds, d->stream, p,
+	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), dbg_lds, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer,
-	                   rseg, nstrips, groups, ntiles);
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
 
-template <typename T, bool STRICT> int launch_flux(hp_domain* d, const void* src, void* dst, int cfl_mode)
+template <typename T, bool STRICT>
+int launch_flux(hp_domain* d, const void* src, void* dst, int cfl_mode, int part, hipStream_t stream)
 {
 	const Params<T> p = make_params<T>(d);
 	if (d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK) {
 		if (p.cols < 5 || p.rows < 5) return fail(HP_ERR_INVALID, "MUSCL-Hancock needs at least a 5x5 grid");
-		return cfl_mode ? launch_muscl<T, STRICT, 1>(d, src, dst, d->use_alt ^ 1)
-		                : launch_muscl<T, STRICT, 0>(d, src, dst, 0);
+		return cfl_mode ? launch_muscl<T, STRICT, 1>(d, src, dst, d->use_alt ^ 1, part, stream)
+		                : launch_muscl<T, STRICT, 0>(d, src, dst, 0, part, stream);
 	}
 	if (d->desc.kernel == HP_KERNEL_BASIC) {
+		if (part == PART_INTERIOR) return HP_OK;                          // no split for the cross-check kernel
 		const dim3 block(64, 4), grid = grid2d(p.cols, p.rows, block);
-		hipLaunchKernelGGL((godunov_basic<STRICT, T>), grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars,
+		hipLaunchKernelGGL((godunov_basic<STRICT, T>), grid, block, 0, stream, p, (const Scalars<T>*)d->scalars,
 		                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning);
 		HIP_TRY(hipGetLastError());
 		return HP_OK;
 	}
 	// ring of the buffer that is priced: mode 1 -> dst, mode 2 -> src (= primary)
 	switch (cfl_mode) {
-	case 1:  return launch_march<T, STRICT, 1>(d, src, dst, d->use_alt ^ 1);
-	case 2:  return launch_march<T, STRICT, 2>(d, src, dst, d->use_alt);
-	default: return launch_march<T, STRICT, 0>(d, src, dst, 0);
+	case 1:  return launch_march<T, STRICT, 1>(d, src, dst, d->use_alt ^ 1, part, stream);
+	case 2:  return launch_march<T, STRICT, 2>(d, src, dst, d->use_alt, part, stream);
+	default: return launch_march<T, STRICT, 0>(d, src, dst, 0, part, stream);
 	}
 }
 
@@ -252,7 +289,17 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		HIP_TRY(hipEventCreate(&e1));
 		HIP_TRY(hipEventRecord(e0, d->stream));
 	}
-	if ((rc = launch_flux<T, STRICT>(d, src, dst, cfl_mode)) != HP_OK) return rc;
+	if (d->halo_overlap) {
+		// fork: everything queued so far (previous advance, boundaries, ring pricing) happens-before the halo
+		// segments; they run on their own stream, next to the interior segments on the domain's stream
+		HIP_TRY(hipEventRecord(d->ev_fork, d->stream));
+		HIP_TRY(hipStreamWaitEvent(d->stream_halo, d->ev_fork, 0));
+		if ((rc = launch_flux<T, STRICT>(d, src, dst, cfl_mode, PART_HALO, d->stream_halo)) != HP_OK) return rc;
+		HIP_TRY(hipEventRecord(d->ev_halo, d->stream_halo));
+		if ((rc = launch_flux<T, STRICT>(d, src, dst, cfl_mode, PART_INTERIOR, d->stream)) != HP_OK) return rc;
+		// join: the CFL maximum (and anything after it on the domain's stream) needs both launches
+		HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_halo, 0));
+	} else if ((rc = launch_flux<T, STRICT>(d, src, dst, cfl_mode, PART_ALL, d->stream)) != HP_OK) return rc;
 	if (sample) {
 		HIP_TRY(hipEventRecord(e1, d->stream));
 		d->timing_events.emplace_back(e0, e1);
@@ -446,6 +493,13 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	HIP_TRY_C(hipMemset(d->scalars, 0, 256));
 	HIP_TRY_C(hipEventCreate(&d->ev_start));
 	HIP_TRY_C(hipEventCreate(&d->ev_stop));
+	{
+		int lo = 0, hi = 0;                                               // numerically lower = higher priority
+		HIP_TRY_C(hipDeviceGetStreamPriorityRange(&lo, &hi));
+		HIP_TRY_C(hipStreamCreateWithPriority(&d->stream_halo, hipStreamNonBlocking, hi));
+	}
+	HIP_TRY_C(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+	HIP_TRY_C(hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming));
 #undef HIP_TRY_C
 	rc = (d->desc.precision == 8) ? write_scalars_initial<double>(d) : write_scalars_initial<float>(d);
 	if (rc != HP_OK) return cleanup(rc);
@@ -458,6 +512,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	if (!d) return HP_OK;
 	hipSetDevice(d->desc.device);
 	if (d->stream) hipStreamSynchronize(d->stream);
+	if (d->stream_halo) hipStreamSynchronize(d->stream_halo);
 	for (auto& b : d->bdy) { hipFree(b.data); hipFree(b.cells); }
 	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
@@ -465,6 +520,9 @@ int hp_domain_destroy(hp_domain_t* d)
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
 	if (d->ev_stop) hipEventDestroy(d->ev_stop);
+	if (d->ev_fork) hipEventDestroy(d->ev_fork);
+	if (d->ev_halo) hipEventDestroy(d->ev_halo);
+	if (d->stream_halo) hipStreamDestroy(d->stream_halo);
 	if (d->stream) hipStreamDestroy(d->stream);
 	delete d;
 	return HP_OK;
@@ -766,6 +824,21 @@ int hp_stream(hp_domain_t* d, void** hip_stream)
 {
 	if (!d || !hip_stream) return fail(HP_ERR_INVALID, "null argument");
 	*hip_stream = (void*)d->stream;
+	return HP_OK;
+}
+
+int hp_set_halo_overlap(hp_domain_t* d, int on)
+{
+	if (!d) return fail(HP_ERR_INVALID, "null domain");
+	if (d->in_step) return fail(HP_ERR_STATE, "hp_set_halo_overlap inside an iteration");
+	d->halo_overlap = on != 0;
+	return HP_OK;
+}
+
+int hp_stream_halo(hp_domain_t* d, void** hip_stream)
+{
+	if (!d || !hip_stream) return fail(HP_ERR_INVALID, "null argument");
+	*hip_stream = (void*)d->stream_halo;
 	return HP_OK;
 }
 

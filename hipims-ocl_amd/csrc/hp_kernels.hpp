@@ -218,13 +218,21 @@ __device__ __forceinline__ Side<T> shfl_side(const Side<T>& s, const int src_lan
 	return r;
 }
 
+// How one launch's blocks map to tiles: `groups` 4-wave column groups x a run of row segments.  A launch covers
+// segments seg_first .. seg_first+count-1 of the domain, with `seg_gap` segments skipped from position
+// `seg_gap_at` on: (0, never, 0) = the whole domain; the strip-decomposed step launches the first/last segments
+// (whose rows the neighbours' halos need) separately from the interior ones (hp_engine.hip: launch_split).
+struct TileMap {
+	int rseg, nstrips, groups, ntiles;
+	int seg_first, seg_gap_at, seg_gap;
+};
+
 template <bool STRICT, int CFL_MODE, typename T>
 __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
-                                                     const int rseg, const int nstrips,
-                                                     const int groups, const int ntiles)
+                                                     const TileMap tm)
 {
 	// XCD-aware tile order (grid is a multiple of 8 blocks)
 	const unsigned per_xcd = gridDim.x >> 3;
@@ -232,9 +240,11 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	// the wave index is made a scalar explicitly: everything derived from it (tile rows, buffer descriptors, row
 	// offsets) then lives in SGPRs and the buffer accesses need no waterfall loop
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const long strip = (long)(tile % (unsigned)groups) * 4 + wave;
-	const long seg = tile / (unsigned)groups;
-	if (tile < (unsigned)ntiles && strip < nstrips) {                              // wave-uniform
+	const int rseg = tm.rseg;
+	const long strip = (long)(tile % (unsigned)tm.groups) * 4 + wave;
+	long seg = tm.seg_first + (long)(tile / (unsigned)tm.groups);
+	if (seg >= tm.seg_gap_at) seg += tm.seg_gap;
+	if (tile < (unsigned)tm.ntiles && strip < tm.nstrips) {                              // wave-uniform
 
 	const long x = strip * MARCH_COLS + lane;
 	const long y0 = 1 + seg * rseg;
@@ -407,15 +417,16 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
                                                    const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                    State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                    T* cfl_slot, const T* __restrict__ edge_max,
-                                                   const int rseg, const int nstrips,
-                                                   const int groups, const int ntiles)
+                                                   const TileMap tm)
 {
 	const unsigned per_xcd = gridDim.x >> 3;
 	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: see K1
-	const long strip = (long)(tile % (unsigned)groups) * 4 + wave;
-	const long seg = tile / (unsigned)groups;
-	if (tile < (unsigned)ntiles && strip < nstrips) {
+	const int rseg = tm.rseg;
+	const long strip = (long)(tile % (unsigned)tm.groups) * 4 + wave;
+	long seg = tm.seg_first + (long)(tile / (unsigned)tm.groups);
+	if (seg >= tm.seg_gap_at) seg += tm.seg_gap;
+	if (tile < (unsigned)tm.ntiles && strip < tm.nstrips) {
 
 	const long x = strip * MUSCL_COLS + lane;
 	const long y0 = 2 + seg * rseg;                                                // corrector domain 2..n-3 (:569-573)

@@ -32,7 +32,8 @@ EXPORTS = [
     "hp_domain_create", "hp_domain_destroy", "hp_domain_upload", "hp_domain_download", "hp_domain_upload_rows",
     "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_add_cell", "hp_boundary_clear", "hp_set_target_time", "hp_set_time",
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
-    "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_timer_start",
+    "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_set_halo_overlap",
+    "hp_stream_halo", "hp_timer_start",
     "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read",
 ]
 
@@ -113,6 +114,8 @@ def load_library(path: str | None = None):
     lib.hp_step_needs_reduction.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.hp_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.hp_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.hp_set_halo_overlap.argtypes = [C.c_void_p, C.c_int]
+    lib.hp_stream_halo.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.hp_timer_start.argtypes = [C.c_void_p]
     lib.hp_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.hp_kernel_timing.argtypes = [C.c_void_p, C.c_int]
@@ -315,6 +318,14 @@ class Domain:
         p = C.c_void_p()
         _check(self.lib, self.lib.hp_stream(self.h, C.byref(p)), "hp_stream")
         return p.value or 0
+
+    def halo_stream_ptr(self):
+        p = C.c_void_p()
+        _check(self.lib, self.lib.hp_stream_halo(self.h, C.byref(p)), "hp_stream_halo")
+        return p.value or 0
+
+    def set_halo_overlap(self, on=True):
+        _check(self.lib, self.lib.hp_set_halo_overlap(self.h, int(bool(on))), "hp_set_halo_overlap")
 
     def device_array(self, which):
         """Zero-copy view (``__cuda_array_interface__``) of a device array, for torch.as_tensor(...)."""

@@ -12,10 +12,16 @@ semantic only (src/CModel.cpp:650-694): every iteration
 so a decomposed run is bit-identical to the single-GPU run (max is exact and order independent).
 g = 1 row for Godunov, 2 for MUSCL-Hancock (13-point stencil).
 
+Overlap: with more than one rank the engine computes the row segments next to the ghost rows on a second stream
+(hp_set_halo_overlap); the halo transfer is ordered after that stream only, so it travels while the interior
+segments are still being computed on the domain's stream, which waits for it just before step_end.
+
 The exchange is written against torch.distributed so that the very same code runs over RCCL ("nccl") on GPUs and
 over "gloo" on CPU tensors in the world_size-2 tests (tests/test_strips_gloo.py, with the oracle as engine).
 """
 from __future__ import annotations
+
+import contextlib
 
 import numpy as np
 
@@ -53,8 +59,20 @@ class HipEngine:
         torch.cuda.set_device(self.device)
         # run torch's collectives in order with the engine's kernels: make the domain's stream torch's current one
         self.stream = torch.cuda.ExternalStream(self.domain.stream_ptr(), device=self.device)
+        self.halo_stream = torch.cuda.ExternalStream(self.domain.halo_stream_ptr(), device=self.device)
         torch.cuda.set_stream(self.stream)
         self._views = {}
+
+    def set_halo_overlap(self, on):
+        self.domain.set_halo_overlap(on)
+        self._overlap = bool(on)
+
+    def halo_context(self):
+        """Stream context the halo send/recv is issued in: the collective library orders itself after the work of
+        torch's current stream, which inside this context is the stream the halo segments were computed on."""
+        if getattr(self, "_overlap", False):
+            return self.torch.cuda.stream(self.halo_stream)
+        return contextlib.nullcontext()
 
     def _view(self, which):
         ptr = self.domain.device_ptr(which)
@@ -132,7 +150,7 @@ class StripRunner:
     CPU tests substitute an oracle-backed engine; the default builds the HIP engine."""
 
     def __init__(self, cols, rows, scheme=SCHEME_GODUNOV, precision="f64", rank=0, world=1, device=0,
-                 engine_factory=None, backend=None, init_process_group=True, **kw):
+                 engine_factory=None, backend=None, init_process_group=True, overlap=None, **kw):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -158,6 +176,11 @@ class StripRunner:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
         self.south = rank - 1 if rank > 0 else None
         self.north = rank + 1 if rank < world - 1 else None
+        self._halo_ops = {}
+        if overlap is None:
+            overlap = world > 1
+        if hasattr(self.engine, "set_halo_overlap"):
+            self.engine.set_halo_overlap(overlap)
 
     # ---- data placement ----
     def local_slice(self):
@@ -187,30 +210,42 @@ class StripRunner:
         self.engine.set_target_time(t)
 
     # ---- the per-iteration protocol ----
-    def _exchange_halo(self):
+    def _start_halo(self):
+        """Queue the ghost-row exchange of the iteration in flight; returns the requests to wait for."""
         dist, g = self.dist, self.g
         new = self.engine.new_state()            # [local_rows, cols, 4]
-        n = new.shape[0]
-        ops = []
-        if self.south is not None:
-            ops.append(dist.P2POp(dist.isend, new[g:2 * g], self.south))          # my first owned rows
-            ops.append(dist.P2POp(dist.irecv, new[0:g], self.south))              # into my south ghost rows
-        if self.north is not None:
-            ops.append(dist.P2POp(dist.isend, new[n - 2 * g:n - g], self.north))  # my last owned rows
-            ops.append(dist.P2POp(dist.irecv, new[n - g:n], self.north))          # into my north ghost rows
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        ops = self._halo_ops.get(new.data_ptr())  # the two ping-pong buffers alternate: build each list once
+        if ops is None:
+            n = new.shape[0]
+            ops = []
+            if self.south is not None:
+                ops.append(dist.P2POp(dist.isend, new[g:2 * g], self.south))          # my first owned rows
+                ops.append(dist.P2POp(dist.irecv, new[0:g], self.south))              # into my south ghost rows
+            if self.north is not None:
+                ops.append(dist.P2POp(dist.isend, new[n - 2 * g:n - g], self.north))  # my last owned rows
+                ops.append(dist.P2POp(dist.irecv, new[n - g:n], self.north))          # into my north ghost rows
+            self._halo_ops[new.data_ptr()] = ops
+        if not ops:
+            return []
+        ctx = self.engine.halo_context() if hasattr(self.engine, "halo_context") else contextlib.nullcontext()
+        with ctx:
+            return dist.batch_isend_irecv(ops)
+
+    def _exchange_halo(self):
+        for req in self._start_halo():
+            req.wait()
 
     def step(self, n):
         dist = self.dist
         for _ in range(n):
             self.engine.step_begin()
-            self._exchange_halo()
+            halo = self._start_halo()                  # travels while the interior segments are computed
             # the scalar is new only when the reduction priced a buffer that changed (every iteration without
             # quirk Q1, every other one with it); the decision is identical on all ranks (same iteration parity)
             if self.world > 1 and self.engine.needs_reduction():
                 dist.all_reduce(self.engine.cfl_slot(), op=dist.ReduceOp.MAX)
+            for req in halo:
+                req.wait()                             # domain stream (or the host, with gloo) waits for the rows
             self.engine.step_end()
 
     def barrier(self):

@@ -205,6 +205,15 @@ enum {
 };
 int hp_device_ptr(hp_domain_t* d, int which, void** ptr);
 int hp_stream(hp_domain_t* d, void** hip_stream);     /* the domain's hipStream_t (COCLDevice's command queue) */
+/* Halo overlap.  When on, hp_step_begin runs the row segments that hold the rows the strip neighbours need
+ * (the first/last owned rows) on a second, higher-priority stream and the interior segments on the domain's
+ * stream; the domain's stream joins the second one before anything that follows (CFL maximum, hp_step_end).  The
+ * host starts its halo send/recv on hp_stream_halo right after hp_step_begin -- ordered after the halo rows only,
+ * so the transfer overlaps the interior compute -- and makes the domain's stream wait for the transfer before
+ * hp_step_end.  Results are identical either way.  Replaces the reference's overlap-by-wide-ghost-zones scheme
+ * (CDomainLink.cpp:297-328), which exists to amortise host-staged copies.  Off by default. */
+int hp_set_halo_overlap(hp_domain_t* d, int on);
+int hp_stream_halo(hp_domain_t* d, void** hip_stream);
 
 /* ---- measurement hooks (no reference counterpart; COCLDevice has no profiling queue, COCLDevice.cpp:283-288) ----
  * Bracket a region of the domain's stream with HIP events and return the elapsed milliseconds. */

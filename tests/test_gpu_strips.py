@@ -13,7 +13,7 @@ from hipims_mi import strips, synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def run_strips(cols, rows, nstrips, scheme, steps, st, bed, man, rain=None, **kw):
+def run_strips(cols, rows, nstrips, scheme, steps, st, bed, man, rain=None, overlap=False, **kw):
     import torch
     g = strips.ghost_rows(scheme)
     parts = strips.partition(rows, nstrips, g)
@@ -24,23 +24,37 @@ def run_strips(cols, rows, nstrips, scheme, steps, st, bed, man, rain=None, **kw
         if rain is not None:
             e.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, *rain)
         e.set_target_time(1e9)
+        e.set_halo_overlap(overlap)
         engines.append(e)
+    comm = torch.cuda.Stream()                  # stands in for the collective library's own stream
     for _ in range(steps):
         for e in engines:
             e.step_begin()
+        if not overlap:
+            for e in engines:
+                e.sync()
+        # halo: what StripRunner._start_halo sends/receives, as plain device copies
+        with torch.cuda.stream(comm):
+            if overlap:                         # ordered after the halo segments only, like RCCL inside halo_context()
+                for e in engines:
+                    comm.wait_stream(e.halo_stream)
+            for k in range(nstrips - 1):
+                south, north = engines[k].new_state(), engines[k + 1].new_state()
+                n_s = south.shape[0]
+                north[0:g].copy_(south[n_s - 2 * g:n_s - g])
+                south[n_s - g:n_s].copy_(north[g:2 * g])
+            halo_done = comm.record_event()
+            # all-reduce(MAX) of the wave speed: needs every strip's whole flux launch
+            for e in engines:
+                comm.wait_stream(e.stream)
+            vmax = torch.stack([e.cfl_slot() for e in engines]).max()
+            for e in engines:
+                e.cfl_slot().fill_(vmax)
         for e in engines:
-            e.sync()
-        # halo: what StripRunner._exchange_halo sends/receives, as plain device copies
-        for k in range(nstrips - 1):
-            south, north = engines[k].new_state(), engines[k + 1].new_state()
-            n_s = south.shape[0]
-            north[0:g].copy_(south[n_s - 2 * g:n_s - g])
-            south[n_s - g:n_s].copy_(north[g:2 * g])
-        # all-reduce(MAX) of the wave speed
-        vmax = torch.stack([e.cfl_slot() for e in engines]).max()
-        for e in engines:
-            e.cfl_slot().fill_(vmax)
-        torch.cuda.synchronize()
+            e.stream.wait_stream(comm)
+            e.stream.wait_event(halo_done)
+        if not overlap:
+            torch.cuda.synchronize()
         for e in engines:
             e.step_end()
     out = np.concatenate([e.download()[own_lo - lo:own_hi - lo] for e, (own_lo, own_hi, lo, hi) in zip(engines, parts)])
@@ -51,16 +65,21 @@ def run_strips(cols, rows, nstrips, scheme, steps, st, bed, man, rain=None, **kw
     return out, sc
 
 
-@pytest.mark.parametrize("scheme,nstrips", [(hp.SCHEME_GODUNOV, 2), (hp.SCHEME_GODUNOV, 3), (hp.SCHEME_MUSCL_HANCOCK, 2)])
-def test_strips_are_bit_identical_to_single_domain(scheme, nstrips):
-    cols, rows, steps = 200, 96, 60
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("scheme,nstrips,rows", [(hp.SCHEME_GODUNOV, 2, 96), (hp.SCHEME_GODUNOV, 3, 96),
+                                                 (hp.SCHEME_GODUNOV, 3, 211), (hp.SCHEME_MUSCL_HANCOCK, 2, 96),
+                                                 (hp.SCHEME_MUSCL_HANCOCK, 2, 263)])
+def test_strips_are_bit_identical_to_single_domain(scheme, nstrips, rows, overlap):
+    # the taller grids have interior row segments, so the overlap mode really splits the launch (263: MUSCL's last
+    # segment holds a single row and the halo part takes the last two segments)
+    cols, steps = 200, 60
     st, bed, man = syn.s_rough(cols, rows, manning=None)
     single = hp.Domain(cols, rows, scheme=scheme)
     single.upload(st, bed, man)
     single.set_target_time(1e9)
     single.step_batch(steps)
     ref, sref = single.download(), single.read_scalars()
-    out, sc = run_strips(cols, rows, nstrips, scheme, steps, st, bed, man)
+    out, sc = run_strips(cols, rows, nstrips, scheme, steps, st, bed, man, overlap=overlap)
     assert np.array_equal(out, ref)
     assert sc["t"] == sref["time"] and sc["dt"] == sref["timestep"]
 
@@ -78,7 +97,7 @@ def test_strips_with_gridded_rain_match_single_domain():
     single.step_batch(steps)
     ref = single.download()
     assert (ref[..., 0] - bed).max() > 1e-5
-    out, _ = run_strips(cols, rows, 2, hp.SCHEME_GODUNOV, steps, st, bed, man, rain=rain)
+    out, _ = run_strips(cols, rows, 2, hp.SCHEME_GODUNOV, steps, st, bed, man, rain=rain, overlap=True)
     assert np.array_equal(out, ref)
 
 
@@ -94,7 +113,7 @@ def test_single_rank_nccl_runner_matches_batch_call():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cols, rows, steps = 256, 128, 40
     st, bed, man = syn.s_dam(cols, rows)
-    r = strips.StripRunner(cols, rows, rank=0, world=1)
+    r = strips.StripRunner(cols, rows, rank=0, world=1, overlap=True)
     try:
         r.upload_global(st, bed, man)
         r.set_target_time(1e9)

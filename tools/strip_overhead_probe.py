@@ -30,11 +30,19 @@ def comm_loop(n):
         new = r.engine.new_state(); m = new.shape[0]
         ops = [dist.P2POp(dist.isend, new[g:2*g], 0), dist.P2POp(dist.irecv, new[0:g], 0),
                dist.P2POp(dist.isend, new[m-2*g:m-g], 0), dist.P2POp(dist.irecv, new[m-g:m], 0)]
-        for q in dist.batch_isend_irecv(ops): q.wait()
+        with r.engine.halo_context():
+            reqs = dist.batch_isend_irecv(ops)
         if r.engine.needs_reduction():
             dist.all_reduce(r.engine.cfl_slot(), op=dist.ReduceOp.MAX)
+        for q in reqs: q.wait()
         r.engine.step_end()
 print("(c) + self P2P + all-reduce   : %.1f us/step" % timed(comm_loop, steps))
+r.engine.set_halo_overlap(True)
+print("(d) split launch, no comm     : %.1f us/step" % timed(lambda n: r.step(n), steps))
+print("(e) (c) with halo overlap     : %.1f us/step" % timed(comm_loop, steps))
+t0 = time.perf_counter(); comm_loop(200); cpu = (time.perf_counter() - t0) / 200 * 1e6; r.barrier()
+print("CPU enqueue cost of (e)       : %.1f us/step (no sync)" % cpu)
+r.engine.set_halo_overlap(False)
 t0 = time.perf_counter()
 for _ in range(200):
     r.engine.step_begin(); r.engine.needs_reduction(); r.engine.step_end()
