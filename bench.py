@@ -66,14 +66,14 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(cols, precision, scheme, budget_s=12.0):
+def cpu_baseline(cols, precision, scheme, levels=(10.0, 1.0), budget_s=12.0):
     """Plain-C oracle (kind "port"), OpenMP over rows on all host cores, on a bounded strip of the same workload."""
     import oracle
     from hipims_mi import synthetic as syn
     cores = usable_cores()
     rows = 512
     real = np.float64 if precision == "f64" else np.float32
-    st, bed, man = syn.s_dam(cols, rows, dtype=real)
+    st, bed, man = syn.s_dam(cols, rows, dtype=real, levels=levels)
     sim = oracle.OracleSim(cols, rows, precision=precision, scheme=scheme, threads=cores,
                            quirks=oracle.QUIRKS_REFERENCE & ~oracle.Q6_MUSCL_SERIAL)
     sim.upload(st, bed, man)
@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
-    ap.add_argument("--scheme", choices=["godunov", "muscl"], default="godunov")
+    ap.add_argument("--scheme", choices=["godunov", "muscl", "inertial"], default="godunov")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--math", choices=["fast", "strict"], default="fast")
     ap.add_argument("--kernel", choices=["auto", "basic"], default="auto")
@@ -118,7 +118,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cols, rows = grid_for(world, args.cols, args.rows)
-    scheme = hp.SCHEME_GODUNOV if args.scheme == "godunov" else hp.SCHEME_MUSCL_HANCOCK
+    scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
+    # the partial-inertial scheme is only meaningful for a gentle step (2.0 m | 1.6 m instead of 10 m | 1 m)
+    levels = (2.0, 1.6) if args.scheme == "inertial" else (10.0, 1.0)
     math_mode = hp.MATH_FAST if args.math == "fast" else hp.MATH_STRICT
     kernel = hp.KERNEL_AUTO if args.kernel == "auto" else hp.KERNEL_BASIC
     real = np.float64 if args.precision == "f64" else np.float32
@@ -139,7 +141,8 @@ def main():
         runner.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"],
                                   rain["off_y"], rain["interval"])
     else:
-        st, bed, man = syn.s_dam(cols, runner.local_rows_total, dtype=real) if world == 1 else runner.make_s_dam(real)
+        st, bed, man = (syn.s_dam(cols, runner.local_rows_total, dtype=real, levels=levels) if world == 1
+                        else runner.make_s_dam(real, levels=levels))
         runner.upload(st, bed, man)
     del st, bed, man
     runner.set_target_time(1e9)
@@ -167,7 +170,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{'S-RAIN gridded-rainfall on dry terrain' if args.workload == 's-rain' else 'S-DAM flat-DEM dam-break'} "
-                                   f"{cols}x{rows}, {args.scheme}+HLLC, friction fused, "
+                                   f"{cols}x{rows}{'' if levels[0] == 10.0 else ' (levels %g|%g m)' % levels}, "
+                                   f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
                        "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}",
                        "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},
@@ -180,14 +184,13 @@ def main():
             and args.workload == "s-dam" \
             and args.math == "fast" and world == 1
         if default_cfg:
-            tr = pmc_traffic("godunov_march<false" if args.scheme == "godunov" else "muscl_march<false")
+            tr = pmc_traffic(args.scheme + "_march<false")
             if tr:
                 out["roofline"]["traffic"] = tr[0] / 1e9 / (k_ms * 1e-3) if k_ms > 0 else None   # GB/s, same unit as achieved
                 out["roofline"]["traffic_bytes_per_launch"] = tr[0]
                 out["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cols, args.precision,
-                                               0 if args.scheme == "godunov" else 1)
+            out["cpu_baseline"] = cpu_baseline(cols, args.precision, scheme, levels)
         print(json.dumps(out), flush=True)
     runner.close()
 

@@ -60,6 +60,7 @@ struct hp_domain {
 	int              adv_fresh = 1;                   // does hp_step_end's advance kernel read a new maximum?
 	int              march_rseg = 16;                 // rows per wavefront tile of godunov_march
 	int              muscl_rseg = 32;                 // ... of muscl_march (two warm-up rows per tile)
+	int              inertial_rseg = 32;              // ... of inertial_march
 	void*            host_scalars = nullptr;          // pinned mirror
 	int              use_alt = 0;                     // bUseAlternateKernel
 	bool             in_step = false;
@@ -96,6 +97,7 @@ template <typename T> Params<T> make_params(const hp_domain* d)
 	p.dynamic_dt = d->desc.dynamic_dt;
 	p.manning_uniform = d->manning_uniform ? 1 : 0;
 	p.manning_value = (T)d->manning_value;
+	p.simplified_cfl = d->desc.scheme == HP_SCHEME_INERTIAL ? 1 : 0;       // CLSchemeInertial.clh:25
 	return p;
 }
 
@@ -230,6 +232,22 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	return HP_OK;
 }
 
+template <typename T, bool STRICT, int CFL_MODE>
+int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
+{
+	const Params<T> p = make_params<T>(d);
+	bool empty;
+	const TileMap tm = make_tile_map(p.rows - 2, d->inertial_rseg, 1, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS),
+	                                 part, empty);
+	if (empty) return HP_OK;
+	const unsigned blocks = (unsigned)((tm.ntiles + 7) / 8) * 8;
+	hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
+	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
+	HIP_TRY(hipGetLastError());
+	return HP_OK;
+}
+
 template <typename T, bool STRICT>
 int launch_flux(hp_domain* d, const void* src, void* dst, int cfl_mode, int part, hipStream_t stream)
 {
@@ -238,6 +256,14 @@ int launch_flux(hp_domain* d, const void* src, void* dst, int cfl_mode, int part
 		if (p.cols < 5 || p.rows < 5) return fail(HP_ERR_INVALID, "MUSCL-Hancock needs at least a 5x5 grid");
 		return cfl_mode ? launch_muscl<T, STRICT, 1>(d, src, dst, d->use_alt ^ 1, part, stream)
 		                : launch_muscl<T, STRICT, 0>(d, src, dst, 0, part, stream);
+	}
+	if (d->desc.scheme == HP_SCHEME_INERTIAL) {
+		if (p.cols < 3 || p.rows < 3) return fail(HP_ERR_INVALID, "the inertial scheme needs at least a 3x3 grid");
+		switch (cfl_mode) {
+		case 1:  return launch_inertial<T, STRICT, 1>(d, src, dst, d->use_alt ^ 1, part, stream);
+		case 2:  return launch_inertial<T, STRICT, 2>(d, src, dst, d->use_alt, part, stream);
+		default: return launch_inertial<T, STRICT, 0>(d, src, dst, 0, part, stream);
+		}
 	}
 	if (d->desc.kernel == HP_KERNEL_BASIC) {
 		if (part == PART_INTERIOR) return HP_OK;                          // no split for the cross-check kernel
@@ -261,7 +287,7 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	void* src = d->state[d->use_alt];
 	void* dst = d->state[d->use_alt ^ 1];
 	int rc;
-	const bool has_bdy = !d->bdy.empty() && d->desc.scheme == HP_SCHEME_GODUNOV;   // MUSCL never applies them (Q8)
+	const bool has_bdy = !d->bdy.empty() && d->desc.scheme != HP_SCHEME_MUSCL_HANCOCK;   // MUSCL never applies them (Q8)
 	if (has_bdy)
 		if ((rc = apply_boundaries<T>(d, src)) != HP_OK) return rc;
 
@@ -269,7 +295,7 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	// otherwise what this iteration writes.
 	const bool q1 = (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0;
 	const bool muscl = d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK;
-	const bool basic = d->desc.kernel == HP_KERNEL_BASIC && !muscl;
+	const bool basic = d->desc.kernel == HP_KERNEL_BASIC && d->desc.scheme == HP_SCHEME_GODUNOV;
 	const bool dst_is_primary = d->use_alt == 1;
 	int cfl_mode = 0;                                    // fused epilogue of the tuned kernel
 	if (d->desc.dynamic_dt && !basic) {
@@ -440,7 +466,8 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	if (desc->struct_size != sizeof(hp_domain_desc_t)) return fail(HP_ERR_INVALID, "hp_domain_desc_t size mismatch");
 	if (desc->cols < 3 || desc->rows < 3) return fail(HP_ERR_INVALID, "grid must be at least 3x3");
 	if (desc->precision != 8 && desc->precision != 4) return fail(HP_ERR_INVALID, "precision must be 8 or 4");
-	if (desc->scheme != HP_SCHEME_GODUNOV && desc->scheme != HP_SCHEME_MUSCL_HANCOCK)
+	if (desc->scheme != HP_SCHEME_GODUNOV && desc->scheme != HP_SCHEME_MUSCL_HANCOCK &&
+	    desc->scheme != HP_SCHEME_INERTIAL)
 		return fail(HP_ERR_INVALID, "unknown scheme");
 	if (!(desc->dx > 0)) return fail(HP_ERR_INVALID, "dx must be positive");
 	int n = 0, rc = hp_device_count(&n);
@@ -463,6 +490,10 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 64) d->march_rseg = v;
+	}
+	if (const char* e = std::getenv("HP_INERTIAL_RSEG")) {
+		const int v = std::atoi(e);
+		if (v >= 1 && v <= 64) d->inertial_rseg = v;
 	}
 	if (const char* e = std::getenv("HP_MUSCL_RSEG")) {
 		const int v = std::atoi(e);

@@ -554,6 +554,148 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 	}   // tile / strip guard
 }
 
+// -------------------------------------------------------------------------------------------------
+// K6  inertial_march : partial-inertial scheme (ine_cacheDisabled / ine_cacheEnabled, CLSchemeInertial.clc:26-326).
+//
+//  State = {Z, Zmax, discharge across the WEST face, discharge across the SOUTH face}.  Same wavefront march as K1
+//  (lane = column, 62 updated columns per wave, rows streamed through a two-deep register pipeline).  The reference
+//  evaluates calculateInertialFlux four times per cell with the CELL's Manning n, so a face gets two values when n
+//  varies; with a uniform n (wave-uniform flag, found at upload) the north discharge is carried to the next row as
+//  its south discharge and the east discharge goes to the east lane as its west discharge: two evaluations per
+//  cell, bit-identical to four.  About 60 VALU instructions per evaluation: the kernel is HBM bound.
+//  dt <= 0 returns WITHOUT writing dst (:61-62, unlike the Godunov kernel), all-dry cells likewise (:103, Q3):
+//  both leave dst stale, and the fused CFL epilogue prices what dst really holds.
+// -------------------------------------------------------------------------------------------------
+template <bool STRICT, int CFL_MODE, typename T>
+__global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const Scalars<T>* sc,
+                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
+                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
+                                                      T* cfl_slot, const T* __restrict__ edge_max,
+                                                      const TileMap tm)
+{
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: see K1
+	const int rseg = tm.rseg;
+	const long strip = (long)(tile % (unsigned)tm.groups) * 4 + wave;
+	long seg = tm.seg_first + (long)(tile / (unsigned)tm.groups);
+	if (seg >= tm.seg_gap_at) seg += tm.seg_gap;
+	if (tile < (unsigned)tm.ntiles && strip < tm.nstrips) {
+
+	const long x = strip * MARCH_COLS + lane;
+	const long y0 = 1 + seg * rseg;
+	const long y1 = (y0 + rseg < p.rows - 1) ? (y0 + rseg) : (p.rows - 1);
+	const long xc = (x < p.cols) ? x : (p.cols - 1);
+	const bool out_x = lane >= 1 && lane <= MARCH_COLS && x <= p.cols - 2;
+	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
+
+	const T dt = sc->dt, vs = p.vs;
+	const bool skip_step = dt <= T(0);                                             // :61-62
+	const bool uniform_n = p.manning_uniform != 0;
+	const bool simplified = p.simplified_cfl != 0;
+	T vmax = T(0);
+	unsigned long long stale_rows = 0;
+
+	const size_t cell0 = (size_t)(y0 - 1) * p.cols + (size_t)(strip * MARCH_COLS);
+	const size_t cells_left = (size_t)p.cols * p.rows - cell0;
+	const __amdgpu_buffer_rsrc_t srd_src = make_srd(src + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_dst = make_srd(dst + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_bed = make_srd(bed + cell0, cells_left * sizeof(T));
+	const __amdgpu_buffer_rsrc_t srd_man = make_srd(manning + cell0, cells_left * sizeof(T));
+	const unsigned lane_col = (unsigned)(xc - strip * MARCH_COLS);
+	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
+	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
+
+	auto load_row = [&](const long y) {
+		RowRegs<T> r;
+		const unsigned k = (unsigned)(y - (y0 - 1));
+		r.c = buf_load_state(srd_src, voff_state, k * row_state, T());
+		r.zb = buf_load_scalar(srd_bed, voff_scalar, k * row_scalar, T());
+		r.n = uniform_n ? p.manning_value : buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
+		return r;
+	};
+	auto flux = [&](const T n, const T q_prev, const T z_up, const T b_up, const T z_down, const T b_down) {
+		return inertial_flux<STRICT>(n, dt, q_prev, z_up, b_up, z_down, b_down, p.dx, p.inv_dx, vs);
+	};
+
+	RowRegs<T> rc = load_row(y0);
+	RowRegs<T> rP = load_row(y0 + 1), rQ;
+	T zS, bS, qS_carry;                           // southern neighbour's level and bed; with uniform n: its north discharge
+	{
+		const RowRegs<T> rs = load_row(y0 - 1);
+		zS = rs.c.z; bS = rs.zb;
+		qS_carry = flux(rc.n, rc.c.qy, rc.c.z, rc.zb, zS, bS);                     // the first row's south face (:124-132)
+	}
+
+	auto row_step = [&](const long y, const RowRegs<T>& rn, RowRegs<T>& pre) {
+		pre = load_row((y + 2 < p.rows) ? (y + 2) : (p.rows - 1));
+		State4<T> out = rc.c;
+		bool write = out_x;
+
+		const T zE = __shfl(rc.c.z, lane_e, 64), bE = __shfl(rc.zb, lane_e, 64), qxE = __shfl(rc.c.qx, lane_e, 64);
+		const T zW = __shfl(rc.c.z, lane_w, 64), bW = __shfl(rc.zb, lane_w, 64);
+		const T qN = flux(rc.n, rn.c.qy, rn.c.z, rn.zb, rc.c.z, rc.zb);            // :104-112
+		const T qE = flux(rc.n, qxE, zE, bE, rc.c.z, rc.zb);                       // :114-122
+		T qS, qW;
+		if (uniform_n) {                                                           // wave-uniform
+			qS = qS_carry;
+			qW = __shfl(qE, lane_w, 64);
+		} else {
+			qS = flux(rc.n, rc.c.qy, rc.c.z, rc.zb, zS, bS);                       // :124-132
+			qW = flux(rc.n, rc.c.qx, rc.c.z, rc.zb, zW, bW);                       // :134-142
+		}
+		const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :70-74
+		const bool dry5 = (rc.c.z - rc.zb) < vs && (rn.c.z - rn.zb) < vs && (zE - bE) < vs && (zS - bS) < vs &&
+		                  (zW - bW) < vs;                                          // :93-103
+		const State4<T> upd = inertial_update<STRICT>(rc.c, rc.zb, dt, qN, qE, qS, qW, p.dx, p.inv_dx, vs);
+		if (skip_step || (!disabled && dry5)) {                                    // dst keeps what it holds
+			write = false;
+			if (out_x) stale_rows |= 1ull << (unsigned)(y - y0);
+		} else if (!disabled) {
+			out = upd;
+		}
+		buf_store_state(out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+		if (CFL_MODE == 1) {
+			if (write) {
+				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs, simplified);
+				if (s > vmax) vmax = s;
+			}
+		} else if (CFL_MODE == 2) {
+			if (out_x) {
+				const T s = cfl_speed<STRICT>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs, simplified);
+				if (s > vmax) vmax = s;
+			}
+		}
+		zS = rc.c.z; bS = rc.zb; qS_carry = qN;
+		rc = rn;
+	};
+
+	long y = y0;
+	for (; y + 2 <= y1; y += 2) {
+		row_step(y, rP, rQ);
+		row_step(y + 1, rQ, rP);
+	}
+	if (y < y1) row_step(y, rP, rQ);
+
+	if (CFL_MODE == 1 && __any(stale_rows != 0)) {
+		for (long yy = y0; yy < y1; ++yy) {
+			if ((stale_rows >> (unsigned)(yy - y0)) & 1ull) {
+				const size_t id = (size_t)yy * p.cols + xc;
+				const State4<T> c = dst[id];
+				const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs, simplified);
+				if (s > vmax) vmax = s;
+			}
+		}
+	}
+
+	if (CFL_MODE != 0) {
+		if (tile == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
+		vmax = wave_max(vmax);
+		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
+	}
+	}   // tile / strip guard
+}
+
 // max wave speed over the edge ring (cells no kernel ever writes): the `w` outermost columns on rows
 // [row_lo,row_hi) plus the `w` outermost rows at the global south / north end when this strip holds them
 // (south / north = first such local row, or -1).  w = 1 (Godunov) or 2 (MUSCL-Hancock).  Priced once per upload.
@@ -578,7 +720,7 @@ __global__ __launch_bounds__(256) void cfl_edge_ring(const Params<T> p, const St
 		}
 		const size_t id = (size_t)y * p.cols + x;
 		const State4<T> c = state[id];
-		const T s = cfl_speed<true>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
+		const T s = cfl_speed<true>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs, p.simplified_cfl != 0);
 		if (s > m) m = s;
 	}
 	m = wave_max(m);
@@ -601,7 +743,7 @@ __global__ __launch_bounds__(256) void cfl_reduce(const Params<T> p, const State
 	for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last;
 	     i += (size_t)gridDim.x * blockDim.x) {
 		const State4<T> c = state[i];
-		const T s = cfl_speed<true>(c.z, c.zmax, c.qx, c.qy, bed[i], p.qs);
+		const T s = cfl_speed<true>(c.z, c.zmax, c.qx, c.qy, bed[i], p.qs, p.simplified_cfl != 0);
 		if (s > m) m = s;
 	}
 	m = wave_max(m);

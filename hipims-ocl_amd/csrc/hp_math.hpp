@@ -25,6 +25,7 @@ template <typename T> struct Params {
 	int  friction, dynamic_dt;
 	int  manning_uniform;        // every cell has the same Manning n (the usual "constant" data source): not re-read per step
 	T    manning_value;
+	int  simplified_cfl;         // TIMESTEP_SIMPLIFIED (CLSchemeInertial.clh:25): wave speed = sqrt(g h) only
 };
 
 // device-resident time-control block ("Time", "Timestep", ... buffers, CSchemeGodunov.cpp:852-872)
@@ -574,12 +575,64 @@ __device__ __forceinline__ Side<T> side_from_face(const Face4<T>& f, const T qx_
 	return s;
 }
 
+// ---- partial-inertial scheme (CLSchemeInertial.clc) ----
+// calculateInertialFlux (:331-378): discharge per unit width across one face from the previous discharge, the
+// water-level slope and a semi-implicit Manning term, limited to Froude 0.8 (CLSchemeInertial.clh:24).
+// STRICT keeps the reference's expression order (device pow stands in for the host's); FAST writes
+// g d dt n^2 |q| / d^(10/3) as g dt n^2 |q| d^(-7/3) with the cube-root seed, and the two Froude tests as a clamp
+// to +-0.8 d sqrt(g d).
+template <bool STRICT, typename T>
+__device__ __forceinline__ T inertial_flux(const T n, const T dt, const T q_prev, const T z_up, const T b_up,
+                                           const T z_down, const T b_down, const T dx, const T inv_dx, const T vs)
+{
+	const T g = gravity<T>();
+	const T d = fmax_(z_down, z_up) - fmax_(b_up, b_down);                                // :342
+	T q;
+	if (STRICT) {
+		const T slope = (z_down - z_up) / dx;                                             // :343
+		q = (q_prev - (g * d * dt * slope)) /                                             // :346-348
+		    (T(1.0) + g * d * dt * n * n * fabs_(q_prev) / pow_(d, T(T(10.0) / T(3.0))));
+		const T c = sqrt_(g * d);
+		if (q > T(0) && ((fabs_(q) / d) / c) > T(0.8)) q = d * c * T(0.8);                // :351-356
+		if (q < T(0) && ((fabs_(q) / d) / c) > T(0.8)) q = T(0) - d * c * T(0.8);
+	} else {
+		const T slope = (z_down - z_up) * inv_dx;
+		const T rc = rcbrt_fast(d);                                                       // d^(-1/3)
+		const T rc2 = rc * rc, rc4 = rc2 * rc2;
+		const T gdt = g * dt;
+		const T den = fma_(gdt * (n * n) * fabs_(q_prev), rc4 * rc2 * rc, T(1));
+		q = fma_(-gdt * d, slope, q_prev) * rcp_fast(den);
+		const T lim = T(0.8) * d * sqrt_fast(g * d);
+		q = fmin_(fmax_(q, -lim), lim);
+	}
+	if (d < vs) q = T(0);                                                                 // :371-372
+	return q;
+}
+
+// ine_cacheDisabled's update (:144-163): new face discharges are stored in the cell, the level moves by their
+// divergence.
+template <bool STRICT, typename T>
+__device__ __forceinline__ State4<T> inertial_update(const State4<T>& c, const T zb, const T dt, const T qN, const T qE,
+                                                     const T qS, const T qW, const T dx, const T inv_dx, const T vs)
+{
+	State4<T> o;
+	o.qx = qW; o.qy = qS;
+	const T delta = STRICT ? (qE - qW + qN - qS) / dx : (qE - qW + qN - qS) * inv_dx;      // :148-149
+	o.z = STRICT ? c.z + dt * delta : fma_(dt, delta, c.z);                                // :152
+	o.zmax = (o.z > c.zmax) ? o.z : c.zmax;                                                // :155-156
+	if (o.z - zb < vs) o.z = zb;                                                           // :159-160
+	return o;
+}
+
 // Wave speed of one cell for the CFL reduction (CLDynamicTimestep.clc:185-216)
 template <bool STRICT, typename T>
-__device__ __forceinline__ T cfl_speed(const T z, const T zmax, const T qx, const T qy, const T zb, const T qs)
+__device__ __forceinline__ T cfl_speed(const T z, const T zmax, const T qx, const T qy, const T zb, const T qs,
+                                       const bool simplified = false)
 {
 	const T h = z - zb;
 	if (h > qs && zmax > T(-9999.0)) {
+		if (simplified)                                       // :205-210 (partial-inertial scheme)
+			return STRICT ? sqrt_(gravity<T>() * h) : sqrt_fast(gravity<T>() * h);
 		if (STRICT) {
 			T vx = qx / h, vy = qy / h;
 			if (vx < T(0)) vx = -vx;

@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libhipims_mi.so")
 
 # enums of include/hipims_mi.h
-SCHEME_GODUNOV, SCHEME_MUSCL_HANCOCK = 0, 1
+SCHEME_GODUNOV, SCHEME_MUSCL_HANCOCK, SCHEME_INERTIAL = 0, 1, 2
 ARRAY_STATE, ARRAY_BED, ARRAY_MANNING = 0, 1, 2
 QUIRK_CFL_READS_PRIMARY, QUIRK_BDY_TRUNCATED, QUIRKS_REFERENCE = 1, 2, 3
 MATH_FAST, MATH_STRICT = 0, 1

@@ -28,7 +28,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import (DEPTH_IGNORE, DEPTH_IS_DEPTH, DEPTH_IS_FSL, DISCHARGE_IGNORE, DISCHARGE_IS_DISCHARGE,
-               DISCHARGE_IS_VELOCITY, DISCHARGE_IS_VOLUME, SCHEME_GODUNOV, SCHEME_MUSCL_HANCOCK, UNIFORM_LOSS_RATE,
+               DISCHARGE_IS_VELOCITY, DISCHARGE_IS_VOLUME, SCHEME_GODUNOV, SCHEME_INERTIAL, SCHEME_MUSCL_HANCOCK,
+               UNIFORM_LOSS_RATE,
                UNIFORM_RAIN_INTENSITY, hfa)
 
 NODATA = -9999.0
@@ -153,7 +154,9 @@ def parse_configuration(xml_path):
         cfg.targets.append(((dt.get("value") or "").lower(), dt.get("target")))
     sch = dom.find("scheme")
     name = (sch.get("name") or "godunov").lower()
-    cfg.scheme = SCHEME_MUSCL_HANCOCK if name in ("muscl-hancock", "muscl") else SCHEME_GODUNOV
+    # CScheme::createFromConfig (CScheme.cpp:140-176): "muscl-hancock" | "godunov" | "inertial"
+    cfg.scheme = {"muscl-hancock": SCHEME_MUSCL_HANCOCK, "muscl": SCHEME_MUSCL_HANCOCK,
+                  "inertial": SCHEME_INERTIAL}.get(name, SCHEME_GODUNOV)
     sp = _params(sch)
     cfg.courant = float(sp.get("courantnumber", 0.5))                         # CSchemeGodunov.cpp:128-333
     cfg.dry_threshold = float(sp.get("drythreshold", 1e-10))

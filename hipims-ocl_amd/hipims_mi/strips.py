@@ -26,8 +26,11 @@ import contextlib
 import numpy as np
 
 from . import (KERNEL_AUTO, MATH_FAST, PTR_CFL_MAX, PTR_STATE_NEXT_SRC, PTR_STATE_OTHER, QUIRKS_REFERENCE,
-               SCHEME_GODUNOV, SCHEME_MUSCL_HANCOCK, Domain)
+               SCHEME_GODUNOV, SCHEME_INERTIAL, SCHEME_MUSCL_HANCOCK, Domain)
 from . import synthetic as syn
+
+
+FLUX_KERNELS = {SCHEME_GODUNOV: "hp::godunov_march", SCHEME_MUSCL_HANCOCK: "hp::muscl_march", SCHEME_INERTIAL: "hp::inertial_march"}
 
 
 def ghost_rows(scheme) -> int:
@@ -49,10 +52,9 @@ def partition(global_rows: int, world: int, g: int):
 class HipEngine:
     """The HIP domain of one strip + zero-copy torch views of its device buffers."""
 
-    flux_kernel_name = "hp::godunov_*"
-
     def __init__(self, cols, local_rows, global_rows, row_offset, **kw):
         import torch
+        self.flux_kernel_name = FLUX_KERNELS[kw.get("scheme", SCHEME_GODUNOV)]
         self.torch = torch
         self.domain = Domain(cols, local_rows, global_rows=global_rows, row_offset=row_offset, **kw)
         self.device = torch.device("cuda", kw.get("device", 0))
@@ -124,7 +126,7 @@ class SingleRunner:
         self.domain = Domain(cols, rows, **kw)
         self.local_rows_total = rows
         self.local_lo, self.local_hi = 0, rows
-        self.flux_kernel_name = "hp::godunov_*"
+        self.flux_kernel_name = FLUX_KERNELS[kw.get("scheme", SCHEME_GODUNOV)]
 
     def upload(self, st, bed, man):
         self.domain.upload(st, bed, man)
@@ -186,9 +188,9 @@ class StripRunner:
     def local_slice(self):
         return slice(self.local_lo, self.local_hi)
 
-    def make_s_dam(self, real):
+    def make_s_dam(self, real, levels=(10.0, 1.0)):
         """This rank's rows of the global S-DAM input (built strip by strip: a 16384 x 8192 fp64 state is 4 GiB)."""
-        st, bed, man = syn.s_dam(self.cols, self.local_rows_total, dtype=real)
+        st, bed, man = syn.s_dam(self.cols, self.local_rows_total, dtype=real, levels=levels)
         # s_dam walls all four edges of what it builds; only the global south/north rows are walls
         z_col = st[1, :, 0].copy() if self.local_rows_total > 2 else None
         if self.local_lo > 0:

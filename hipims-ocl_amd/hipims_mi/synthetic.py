@@ -24,12 +24,13 @@ def round4(x):
     return np.round(np.asarray(x, dtype=np.float64) * 1e4) / 1e4
 
 
-def s_dam(cols, rows, dtype=np.float64, wet_right=True, manning=0.03):
-    """S-DAM: flat bed, Z = 10 m for x < cols/2 else 1 m (all wet); S-DAM-DRY: right half dry."""
+def s_dam(cols, rows, dtype=np.float64, wet_right=True, manning=0.03, levels=(10.0, 1.0)):
+    """S-DAM: flat bed, Z = 10 m for x < cols/2 else 1 m (all wet); S-DAM-DRY: right half dry.  `levels` changes the
+    two water levels (the partial-inertial scheme is only meaningful for a gentle step)."""
     state = np.zeros((rows, cols, 4), dtype)
     bed = np.zeros((rows, cols), dtype)
-    state[:, : cols // 2, 0] = 10.0
-    state[:, cols // 2:, 0] = 1.0 if wet_right else 0.0
+    state[:, : cols // 2, 0] = levels[0]
+    state[:, cols // 2:, 0] = levels[1] if wet_right else 0.0
     state[..., 1] = state[..., 0]
     _walls(state, bed)
     return state, bed, np.full((rows, cols), manning, dtype)
@@ -69,23 +70,6 @@ def s_rain(cols, rows, dx=2.0, dtype=np.float32, seed=7, grid_cells=64, slices=1
     grids = rng.uniform(0.0, 120.0, (slices, grid_cells, grid_cells))
     rain = dict(grids=grids.astype(dtype), resolution=resolution, off_x=0.0, off_y=0.0, interval=interval)
     return state.astype(dtype), bed.astype(dtype), np.full((rows, cols), 0.03, dtype), rain
-
-
-def newcastle_like(cols=342, rows=195, dtype=np.float64, seed=342195):
-    """Stand-in for config C1's DEM (342x195 @ 2 m; the HFA raster needs GDAL, absent here): an urban-ish
-    terrain (gentle valley + blocky 'buildings'), initially dry, for the uniform rain + drainage case."""
-    rng = np.random.default_rng(seed)
-    y, x = np.mgrid[0:rows, 0:cols].astype(np.float64)
-    bed = 30.0 + 0.02 * x + 0.015 * np.abs(y - rows / 2) + 0.3 * np.sin(x / 17.0) * np.cos(y / 13.0)
-    for _ in range(40):
-        cx, cy = rng.integers(5, cols - 15), rng.integers(5, rows - 15)
-        w, h = rng.integers(4, 12), rng.integers(4, 12)
-        bed[cy:cy + h, cx:cx + w] += rng.uniform(3.0, 9.0)
-    bed = round4(bed)
-    state = np.zeros((rows, cols, 4), np.float64)
-    state[..., 0] = bed
-    state[..., 1] = bed
-    return state.astype(dtype), bed.astype(dtype), np.full((rows, cols), 0.03, dtype)
 
 
 def s_rain_rows(cols, rows, row_lo, row_hi, dx=2.0, dtype=np.float32, seed=7, grid_cells=64, slices=13, interval=300.0):

@@ -56,7 +56,9 @@ void CSchemeMI::prepareAll()
 	desc.device = iDevice - 1;                                        // deviceNumber is 1-based (CDomainManager.cpp:203-220)
 	desc.cols = pDomain->cols; desc.rows = pDomain->rows; desc.dx = pDomain->resolution;
 	desc.precision = 8;
-	desc.scheme = (ucScheme == schemeTypes::kMUSCLHancock) ? HP_SCHEME_MUSCL_HANCOCK : HP_SCHEME_GODUNOV;
+	desc.scheme = (ucScheme == schemeTypes::kMUSCLHancock)           ? HP_SCHEME_MUSCL_HANCOCK
+	            : (ucScheme == schemeTypes::kInertialSimplification) ? HP_SCHEME_INERTIAL
+	                                                                 : HP_SCHEME_GODUNOV;
 	desc.courant = dCourantNumber;
 	desc.dry_threshold = dThresholdVerySmall;
 	desc.friction = bFrictionEffects ? 1 : 0;

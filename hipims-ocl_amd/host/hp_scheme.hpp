@@ -36,7 +36,7 @@ struct DomainArrays {
 	double volume() const;
 };
 
-namespace schemeTypes { enum : unsigned char { kGodunov = 0, kMUSCLHancock = 1 }; }           // CScheme.h:40-46
+namespace schemeTypes { enum : unsigned char { kGodunov = 0, kMUSCLHancock = 1, kInertialSimplification = 2 }; }   // CScheme.h:33-37
 namespace timestepMode { enum : unsigned char { kCFL = 0, kFixed = 1 }; }                       // CScheme.h:48-52
 namespace syncMethod { enum : unsigned char { kSyncTimestep = 0, kSyncForecast = 1 }; }        // CScheme.h:57-62
 

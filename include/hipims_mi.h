@@ -46,7 +46,7 @@ typedef enum {
 } hp_status;
 
 /* Schemes: Schemes/CScheme.cpp:141-190 (createFromConfig "Godunov" / "MUSCL-Hancock") */
-enum { HP_SCHEME_GODUNOV = 0, HP_SCHEME_MUSCL_HANCOCK = 1 };
+enum { HP_SCHEME_GODUNOV = 0, HP_SCHEME_MUSCL_HANCOCK = 1, HP_SCHEME_INERTIAL = 2 };   /* model::schemeTypes, CScheme.h:33-37 */
 
 /* which array an upload / download moves: COCLBuffer "Cell states", "Bed elevations",
  * "Manning coefficients" (Schemes/CSchemeGodunov.cpp:832-845) */

@@ -4,7 +4,7 @@ ctypes front end to
 
 * ``liboracle_f64.so`` / ``liboracle_f32.so`` : the plain-C restatement (``swe_oracle.c``) of the
   reference's shallow-water hot path, and
-* ``_ref/libref_{god,mch}_{f64,f64_mad,f32}.so`` : the reference's OWN OpenCL C kernel sources
+* ``_ref/libref_{god,mch,ine}_{f64,f64_mad,f32}.so`` : the reference's OWN OpenCL C kernel sources
   compiled for the host (``ref_build/``; only buildable where ``/root/reference`` exists; the
   built ``.so`` files travel to the GPU box, the sources do not).
 
@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(HERE, "_ref")
 REFERENCE_SRC = "/root/reference/src"
 
-GODUNOV, MUSCL = 0, 1
+GODUNOV, MUSCL, INERTIAL = 0, 1, 2
 Q1_CFL_READS_PRIMARY, Q9_BDY_TRUNCATED, Q6_MUSCL_SERIAL = 1, 2, 4
 QUIRKS_REFERENCE = 7
 UNIFORM_RAIN_INTENSITY, UNIFORM_LOSS_RATE = 0, 1
@@ -73,7 +73,7 @@ def _params_struct(creal):
     class Params(C.Structure):
         _fields_ = [("cols", C.c_long), ("rows", C.c_long), ("dx", creal), ("very_small", creal),
                     ("quite_small", creal), ("courant", creal), ("end_time", creal), ("fixed_dt", creal),
-                    ("dynamic_dt", C.c_int), ("friction", C.c_int), ("threads", C.c_int)]
+                    ("dynamic_dt", C.c_int), ("friction", C.c_int), ("threads", C.c_int), ("simplified_cfl", C.c_int)]
     return Params
 
 
@@ -97,6 +97,8 @@ def _load_oracle(precision: str):
         lib.orc_limited_slope.restype = creal
         lib.orc_limited_slope.argtypes = [creal, creal, creal]
         lib.orc_cfl_max_speed.restype = creal
+        lib.orc_inertial_flux.restype = creal
+        lib.orc_inertial_flux.argtypes = [C.c_void_p] + [creal] * 7
         lib.orc_sim_create.restype = C.c_void_p
         _LIBS[precision] = lib
     return _LIBS[precision]
@@ -149,6 +151,10 @@ class OracleFunctions:
     def limited_slope(self, l, c, r):
         return self.lib.orc_limited_slope(self.creal(l), self.creal(c), self.creal(r))
 
+    def inertial_flux(self, n, dt, q_prev, z_up, b_up, z_down, b_down):
+        return self.lib.orc_inertial_flux(C.byref(self.p), *(self.creal(v) for v in (n, dt, q_prev, z_up, b_up,
+                                                                                     z_down, b_down)))
+
     def limiter(self, sL, sC, sR, bL, bC, bR):
         sL, sC, sR = self._a(sL, 4), self._a(sC, 4), self._a(sR, 4)
         out = np.zeros(4, self.real)
@@ -198,7 +204,8 @@ class OracleSim(_SimBase):
         self.p = self.Params(cols=self.cols, rows=self.rows, dx=self.dx, very_small=self.very_small,
                              quite_small=self.real(self.very_small) * self.real(10), courant=self.courant,
                              end_time=self.end_time, fixed_dt=self.fixed_dt, dynamic_dt=int(self.dynamic_dt),
-                             friction=int(self.friction), threads=self.threads)
+                             friction=int(self.friction), threads=self.threads,
+                             simplified_cfl=int(self.scheme == INERTIAL))
         self.h = C.c_void_p(self.lib.orc_sim_create(C.byref(self.p), int(self.scheme), C.c_uint(self.quirks),
                                                     self.creal(self.dt_initial)))
         self._bed_host = None
@@ -295,6 +302,7 @@ class RefFunctions:
         sfx = precision + ("_mad" if mad else "")
         self.god = _load_ref("god_" + sfx)
         self.mch = _load_ref("mch_" + sfx)
+        self.ine = _load_ref("ine_" + sfx) if have_ref("ine_" + sfx) else None
         self.real, self.creal = _np_real(precision), _c_real(precision)
         self.cfg = (8, 8, dx, very_small, 0.5, 1e30, 1, 0.0)
 
@@ -352,6 +360,14 @@ class RefFunctions:
         return faces.reshape(4, 4), first.value
 
 
+    def inertial_flux(self, n, dt, q_prev, z_up, b_up, z_down, b_down):
+        self._conf(self.ine)
+        a = self._a([n, dt, q_prev, z_up, b_up, z_down, b_down], 7)
+        out = np.zeros(1, self.real)
+        self.ine.refw_inertial_flux(_ptr(a), _ptr(out))
+        return out[0]
+
+
 class RefSim(_SimBase):
     """The reference's kernels driven by a restatement of its HOST-side iteration graph.
 
@@ -367,7 +383,7 @@ class RefSim(_SimBase):
         super().__init__(*a, **k)
         assert self.friction, "reference builds are compiled with FRICTION_ENABLED"
         assert self.dynamic_dt, "reference builds are compiled with TIMESTEP_DYNAMIC"
-        stem = ("god_" if self.scheme == GODUNOV else "mch_") + self.precision + ("_mad" if mad else "")
+        stem = {GODUNOV: "god_", MUSCL: "mch_", INERTIAL: "ine_"}[self.scheme] + self.precision + ("_mad" if mad else "")
         self.lib = _load_ref(stem)
         n = self.rows * self.cols
         self.primary = _aligned_zeros((self.rows, self.cols, 4), self.real)
@@ -472,10 +488,11 @@ class RefSim(_SimBase):
         trace = np.zeros(n, self.real)
         for i in range(n):
             trace[i] = self.dt[0]
-            if self.scheme == GODUNOV:
+            if self.scheme != MUSCL:           # CSchemeInertial inherits CSchemeGodunov::scheduleIteration
                 src, dst = (self.alt, self.primary) if self.use_alt else (self.primary, self.alt)
                 self._apply_boundaries(src)
-                self.lib.ref_gts(_ptr(self.dt), _ptr(self.bed), _ptr(src), _ptr(dst), _ptr(self.manning))
+                flux = self.lib.ref_gts if self.scheme == GODUNOV else self.lib.ref_ine
+                flux(_ptr(self.dt), _ptr(self.bed), _ptr(src), _ptr(dst), _ptr(self.manning))
                 self._reduce_advance(self.primary if (self.quirks & Q1_CFL_READS_PRIMARY) else dst)
                 self.use_alt = not self.use_alt
             else:
@@ -492,4 +509,4 @@ class RefSim(_SimBase):
                     batch_dt=self.batch_dt[0], batch_ok=int(self.ok[0]), batch_skipped=int(self.skipped[0]))
 
     def download(self):
-        return (self.alt if (self.scheme == GODUNOV and self.use_alt) else self.primary).copy()
+        return (self.alt if (self.scheme != MUSCL and self.use_alt) else self.primary).copy()

@@ -7,7 +7,8 @@
  * The reference builds this text at run time from its XML parameters:
  *   - extension/typedef header : src/OpenCL/Executors/COCLProgram.cpp:359-399
  *   - "#define" constants      : src/Schemes/CSchemeGodunov.cpp:666-784 (prepare1OConstants),
- *                                src/Schemes/CSchemeMUSCLHancock.cpp:404-523
+ *                                src/Schemes/CSchemeMUSCLHancock.cpp:404-523,
+ *                                src/Schemes/CSchemeInertial.cpp:226-251
  * Here every run-time parameter is an `extern __constant` variable instead of a literal so one
  * shared object serves every grid size / threshold; the arithmetic is unchanged (IEEE division
  * by a variable 1.0 == division by the literal).
@@ -60,6 +61,8 @@ extern __constant unsigned  REFP_WORKERS;
 #define MCH_STG2_DIM1         16
 #define MCH_STG2_DIM2         16
 #define MEM_SEPARATE_FACES    1
+#define INE_DIM1              16
+#define INE_DIM2              16
 
 #ifdef REF_FIXED_DT
 #define TIMESTEP_FIXED        REFP_FIXED_DT

@@ -13,7 +13,8 @@
  *     work-item.  The launch geometry of each driver follows the reference's host code, cited
  *     per function.  No arithmetic of the scheme is restated here.
  *
- * Built twice per precision: -DREF_GODUNOV (Godunov program) / -DREF_MUSCL (MUSCL program).
+ * Built three times per precision: -DREF_GODUNOV (Godunov program) / -DREF_MUSCL (MUSCL program) /
+ * -DREF_INERTIAL (partial-inertial program).
  */
 #include <cstddef>
 #include <cstdint>
@@ -86,6 +87,9 @@ void bdy_Cell(const void* cfg, const uint64_t* relations, const real* series, re
 #ifdef REF_GODUNOV
 void gts_cacheDisabled(const real* dt, const real* bed, real* src, real* dst, const real* manning);
 #endif
+#ifdef REF_INERTIAL
+void ine_cacheDisabled(const real* dt, const real* bed, real* src, real* dst, const real* manning);
+#endif
 #ifdef REF_MUSCL
 void mch_1st_cacheNone(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW);
 void mch_2nd_cacheNone(const real* dt, real* state, const real* bed, const real* manning,
@@ -127,6 +131,18 @@ void ref_gts(const real* dt, const real* bed, real* src, real* dst, const real* 
 		for (long x = 0; x < REFP_COLS; ++x) {
 			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
 			gts_cacheDisabled(dt, bed, src, dst, manning);
+		}
+}
+#endif
+
+#ifdef REF_INERTIAL
+/* same launch geometry as the Godunov kernel: CSchemeInertial.cpp:269-271 reuses prepare1OExecDimensions */
+void ref_ine(const real* dt, const real* bed, real* src, real* dst, const real* manning)
+{
+	for (long y = 0; y < REFP_ROWS; ++y)
+		for (long x = 0; x < REFP_COLS; ++x) {
+			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
+			ine_cacheDisabled(dt, bed, src, dst, manning);
 		}
 }
 #endif

@@ -13,6 +13,7 @@
  *   implicitFriction      Schemes/CLFriction.clc:26
  *   slopeLimiter          Schemes/Limiters/CLSlopeLimiterMINMOD.clc:26   (REF_MUSCL)
  *   mch_1st               Schemes/CLSchemeMUSCLHancock.clc:301           (REF_MUSCL)
+ *   calculateInertialFlux Schemes/CLSchemeInertial.clc:331               (REF_INERTIAL)
  */
 
 #define LD4(p, i)  (cl_double4)((p)[4*(i)+0], (p)[4*(i)+1], (p)[4*(i)+2], (p)[4*(i)+3])
@@ -21,6 +22,7 @@
 #define ST8(v, p)  do { (p)[0] = (v).s0; (p)[1] = (v).s1; (p)[2] = (v).s2; (p)[3] = (v).s3; \
                         (p)[4] = (v).s4; (p)[5] = (v).s5; (p)[6] = (v).s6; (p)[7] = (v).s7; } while (0)
 
+#ifndef REF_INERTIAL            /* the inertial program does not include the HLLC solver (CSchemeInertial.cpp:202-221) */
 __kernel void refw_hllc(int dir, __global const cl_double* L, __global const cl_double* R,
                         __global cl_double* out)
 {
@@ -28,6 +30,7 @@ __kernel void refw_hllc(int dir, __global const cl_double* L, __global const cl_
 	cl_double4 f = riemannSolver((cl_uchar)dir, l, r, false);
 	{ cl_double4 tmp_ = f; ST4(tmp_, out, 0); }
 }
+#endif
 
 __kernel void refw_friction(__global const cl_double* state, cl_double bed, cl_double n,
                             cl_double dt, __global cl_double* out)
@@ -86,5 +89,13 @@ __kernel void refw_mch_1st(cl_double dt, __global const cl_double* states,
 	{ cl_double4 tmp_ = fS; ST4(tmp_, faces, 2); }
 	{ cl_double4 tmp_ = fW; ST4(tmp_, faces, 3); }
 	*firstOrder = fo ? 1 : 0;
+}
+#endif
+
+#ifdef REF_INERTIAL
+/* in: {manning, dt, previous discharge, level up, bed up, level down, bed down} */
+__kernel void refw_inertial_flux(__global const cl_double* in, __global cl_double* out)
+{
+	*out = calculateInertialFlux(in[0], in[1], in[2], in[3], in[4], in[5], in[6]);
 }
 #endif

@@ -512,6 +512,84 @@ void orc_godunov_step(const orc_params* p, real dt, const real* bed, const real*
 			godunov_cell(p, dt, x, y, bed, src, dst, manning);
 }
 
+/* calculateInertialFlux -- Schemes/CLSchemeInertial.clc:331-378 (FROUDE_LIMIT 0.8: CLSchemeInertial.clh:24) */
+real orc_inertial_flux(const orc_params* p, real dManningCoef, real dTimestep, real dPreviousDischarge,
+                       real dLevelUpstream, real dBedUpstream, real dLevelDownstream, real dBedDownstream)
+{
+	const real FROUDE_LIMIT = RC(0.8);
+	real dDischarge;
+	real dDepth = R_FMAX(dLevelDownstream, dLevelUpstream) - R_FMAX(dBedUpstream, dBedDownstream);   /* :342 */
+	real dSlope = (dLevelDownstream - dLevelUpstream) / p->dx;                                        /* :343 */
+
+	dDischarge = (dPreviousDischarge - (GRAVITY * dDepth * dTimestep * dSlope)) /                     /* :346-348 */
+	             (RC(1.0) + GRAVITY * dDepth * dTimestep * dManningCoef * dManningCoef * R_FABS(dPreviousDischarge) /
+	              R_POW(dDepth, (real)(RC(10.0) / RC(3.0))));
+
+	if (dDischarge > RC(0.0) &&                                                                       /* :351-356 */
+	    ((R_FABS(dDischarge) / dDepth) / R_SQRT(GRAVITY * dDepth)) > FROUDE_LIMIT)
+		dDischarge = dDepth * R_SQRT(GRAVITY * dDepth) * FROUDE_LIMIT;
+	if (dDischarge < RC(0.0) &&
+	    ((R_FABS(dDischarge) / dDepth) / R_SQRT(GRAVITY * dDepth)) > FROUDE_LIMIT)
+		dDischarge = RC(0.0) - dDepth * R_SQRT(GRAVITY * dDepth) * FROUDE_LIMIT;
+
+	if (dDepth < p->very_small)                                                                       /* :371-372 */
+		dDischarge = RC(0.0);
+	return dDischarge;
+}
+
+/* One work-item of ine_cacheDisabled -- Schemes/CLSchemeInertial.clc:26-169.  State = {Z, Zmax, Q across the
+ * west face, Q across the south face}. */
+static void inertial_cell(const orc_params* p, real dt, long x, long y, const real* bed, const real* src,
+                          real* dst, const real* manning)
+{
+	const real VS = p->very_small;
+	if (x >= p->cols - 1 || y >= p->rows - 1 || x <= 0 || y <= 0) return;       /* :45-49 */
+	if (dt <= RC(0.0)) return;                                        /* :61-62: dst NOT written (unlike Godunov) */
+
+	const size_t id = IDX(p, x, y);
+	real c[4];
+	memcpy(c, src + 4 * id, sizeof c);                                /* :65-67 */
+	real bC = bed[id], n = manning[id];
+	if (c[1] <= RC(-9999.0) || c[0] == RC(-9999.0)) {                 /* :70-74 */
+		memcpy(dst + 4 * id, c, sizeof c);
+		return;
+	}
+	const size_t iW = IDX(p, x - 1, y), iS = IDX(p, x, y - 1), iN = IDX(p, x, y + 1), iE = IDX(p, x + 1, y);
+	const real *sW = src + 4 * iW, *sS = src + 4 * iS, *sN = src + 4 * iN, *sE = src + 4 * iE;   /* :76-91 */
+	const real bW = bed[iW], bS = bed[iS], bN = bed[iN], bE = bed[iE];
+
+	int dry = 0;                                                      /* :93-100 */
+	if (c[0]  - bC < VS) dry++;
+	if (sN[0] - bN < VS) dry++;
+	if (sE[0] - bE < VS) dry++;
+	if (sS[0] - bS < VS) dry++;
+	if (sW[0] - bW < VS) dry++;
+	if (dry >= 5) return;                                             /* dst NOT written (quirk Q3) */
+
+	const real qN = orc_inertial_flux(p, n, dt, sN[3], sN[0], bN, c[0], bC);    /* :104-112 */
+	const real qE = orc_inertial_flux(p, n, dt, sE[2], sE[0], bE, c[0], bC);    /* :114-122 */
+	const real qS = orc_inertial_flux(p, n, dt, c[3], c[0], bC, sS[0], bS);     /* :124-132 */
+	const real qW = orc_inertial_flux(p, n, dt, c[2], c[0], bC, sW[0], bW);     /* :134-142 */
+
+	c[2] = qW;                                                        /* :144-145 */
+	c[3] = qS;
+	const real dDeltaFSL = (qE - qW + qN - qS) / p->dx;               /* :148-149 (DOMAIN_DELTAY) */
+	c[0] = c[0] + dt * dDeltaFSL;                                     /* :152 */
+	if (c[0] > c[1]) c[1] = c[0];                                     /* :155-156 */
+	if (c[0] - bC < VS) c[0] = bC;                                    /* :159-160 */
+	memcpy(dst + 4 * id, c, sizeof c);                                /* :163 */
+}
+
+void orc_inertial_step(const orc_params* p, real dt, const real* bed, const real* src, real* dst,
+                       const real* manning)
+{
+	long y;
+#pragma omp parallel for schedule(static) num_threads(p->threads > 0 ? p->threads : 1)
+	for (y = 0; y < p->rows; ++y)
+		for (long x = 0; x < p->cols; ++x)
+			inertial_cell(p, dt, x, y, bed, src, dst, manning);
+}
+
 /* mch_1st_cacheNone -- Schemes/CLSchemeMUSCLHancock.clc:28-152 */
 void orc_muscl_predict(const orc_params* p, real dt, const real* bed, const real* state,
                        real* fN, real* fE, real* fS, real* fW)
@@ -650,12 +728,18 @@ real orc_cfl_max_speed(const orc_params* p, const real* state, const real* bed)
 		real dDepth = s[0] - bed[i];                                  /* :191 */
 		real dCellSpeed;
 		if (dDepth > QS && s[1] > RC(-9999.0)) {                      /* :193 */
-			real dVelX = s[2] / dDepth;                               /* :197-203 */
-			real dVelY = s[3] / dDepth;
-			if (dVelX < RC(0.0)) dVelX = -dVelX;
-			if (dVelY < RC(0.0)) dVelY = -dVelY;
-			dVelX += R_SQRT(GRAVITY * dDepth);
-			dVelY += R_SQRT(GRAVITY * dDepth);
+			real dVelX, dVelY;
+			if (!p->simplified_cfl) {                                 /* :195-203 */
+				dVelX = s[2] / dDepth;
+				dVelY = s[3] / dDepth;
+				if (dVelX < RC(0.0)) dVelX = -dVelX;
+				if (dVelY < RC(0.0)) dVelY = -dVelY;
+				dVelX += R_SQRT(GRAVITY * dDepth);
+				dVelY += R_SQRT(GRAVITY * dDepth);
+			} else {                                                  /* :205-210 TIMESTEP_SIMPLIFIED */
+				dVelX = R_SQRT(GRAVITY * dDepth);
+				dVelY = R_SQRT(GRAVITY * dDepth);
+			}
 			dCellSpeed = (dVelX < dVelY) ? dVelY : dVelX;             /* :211 */
 		} else {
 			dCellSpeed = RC(0.0);
@@ -883,6 +967,7 @@ orc_sim* orc_sim_create(const orc_params* p, int scheme, unsigned quirks, real d
 	orc_sim* s = (orc_sim*)calloc(1, sizeof *s);
 	s->p = *p;
 	s->scheme = scheme;
+	if (scheme == ORC_SCHEME_INERTIAL) s->p.simplified_cfl = 1;       /* CLSchemeInertial.clh:25, always defined */
 	s->quirks = quirks;
 	s->cells = (size_t)p->cols * (size_t)p->rows;
 	s->primary = (real*)calloc(s->cells * 4, sizeof(real));
@@ -994,7 +1079,10 @@ static void iterate_godunov(orc_sim* s)
 	real* src = s->use_alt ? s->alt : s->primary;                     /* :1624-1635 */
 	real* dst = s->use_alt ? s->primary : s->alt;
 	apply_boundaries(s, src);                                         /* :1638 */
-	orc_godunov_step(&s->p, s->sc.dt, s->bed, src, dst, s->manning);  /* :1642 */
+	if (s->scheme == ORC_SCHEME_INERTIAL)                             /* CSchemeInertial inherits the graph; its */
+		orc_inertial_step(&s->p, s->sc.dt, s->bed, src, dst, s->manning);   /* kernel is oclKernelFullTimestep */
+	else
+		orc_godunov_step(&s->p, s->sc.dt, s->bed, src, dst, s->manning);  /* :1642 */
 	real vmax = RC(0.0);
 	if (s->p.dynamic_dt)                                              /* :1653-1657; arg 3 does not exist -> primary (Q1) */
 		vmax = orc_cfl_max_speed(&s->p, (s->quirks & ORC_Q1_CFL_READS_PRIMARY) ? s->primary : dst, s->bed);
@@ -1024,7 +1112,7 @@ void orc_sim_run(orc_sim* s, long n, real* dt_trace)
 {
 	for (long i = 0; i < n; ++i) {
 		if (dt_trace) dt_trace[i] = s->sc.dt;
-		if (s->scheme == ORC_SCHEME_GODUNOV) iterate_godunov(s); else iterate_muscl(s);
+		if (s->scheme == ORC_SCHEME_MUSCL) iterate_muscl(s); else iterate_godunov(s);
 	}
 }
 
@@ -1032,6 +1120,6 @@ void orc_sim_scalars(const orc_sim* s, orc_scalars* out) { *out = s->sc; }
 
 void orc_sim_download(const orc_sim* s, real* state)
 {
-	const real* cur = (s->scheme == ORC_SCHEME_GODUNOV && s->use_alt) ? s->alt : s->primary;
+	const real* cur = (s->scheme != ORC_SCHEME_MUSCL && s->use_alt) ? s->alt : s->primary;
 	memcpy(state, cur, s->cells * 4 * sizeof(real));
 }

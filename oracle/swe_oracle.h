@@ -2,8 +2,8 @@
  * oracle/swe_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * Plain-C, scalar, CPU restatement of the reference's shallow-water hot path (HiPIMS-OCL,
- * lukeshope/hipims-ocl): Godunov / MUSCL-Hancock timestep + HLLC + MINMOD + friction +
- * rainfall source terms + CFL reduction + time control.  Every function cites the reference
+ * lukeshope/hipims-ocl): Godunov / MUSCL-Hancock / partial-inertial timestep + HLLC + MINMOD +
+ * friction + rainfall source terms + CFL reduction + time control.  Every function cites the reference
  * file:line it follows.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * may use it -- as the checker / reported baseline, never as the thing shipped.
  *
@@ -34,7 +34,7 @@ typedef double real;
 /* direction codes: src/Domain/Cartesian/CLDomainCartesian.clh:33-36 */
 enum { ORC_DIR_N = 0, ORC_DIR_E = 1, ORC_DIR_S = 2, ORC_DIR_W = 3 };
 
-enum { ORC_SCHEME_GODUNOV = 0, ORC_SCHEME_MUSCL = 1 };
+enum { ORC_SCHEME_GODUNOV = 0, ORC_SCHEME_MUSCL = 1, ORC_SCHEME_INERTIAL = 2 };
 
 /* quirk switches (SURVEY.md section 8 a-quirks); the defaults reproduce the reference */
 enum {
@@ -62,6 +62,7 @@ typedef struct {
 	int   dynamic_dt;    /* TIMESTEP_DYNAMIC */
 	int   friction;      /* FRICTION_ENABLED (fused: FRICTION_IN_FLUX_KERNEL) */
 	int   threads;       /* worker threads for the grid loops (1 = scalar) */
+	int   simplified_cfl;/* TIMESTEP_SIMPLIFIED (CLSchemeInertial.clh:25): wave speed = sqrt(g h) only */
 } orc_params;
 
 typedef struct {
@@ -84,9 +85,15 @@ int   orc_mch_1st(const orc_params* p, real dt, const real states[20], const rea
 int   orc_reconstruct2(const orc_params* p, int dir, const real sL[4], real bL, const real sR[4], real bR,
                        const real eL[4], const real eR[4], real oL[8], real oR[8]);
 
+/* calculateInertialFlux (CLSchemeInertial.clc:331-378) */
+real  orc_inertial_flux(const orc_params* p, real n, real dt, real q_prev, real z_up, real b_up, real z_down, real b_down);
+
 /* ---- grid level (one kernel of the reference each) ---- */
 void  orc_godunov_step(const orc_params* p, real dt, const real* bed, const real* src, real* dst,
                        const real* manning);
+/* ine_cacheDisabled (CLSchemeInertial.clc:26-169) */
+void  orc_inertial_step(const orc_params* p, real dt, const real* bed, const real* src, real* dst,
+                        const real* manning);
 void  orc_muscl_predict(const orc_params* p, real dt, const real* bed, const real* state,
                         real* fN, real* fE, real* fS, real* fW);
 /* src == dst: in place, row-major serial (quirk Q6); src != dst: snapshot (dst must start as a copy of src) */

@@ -7,7 +7,8 @@ inputs and outputs are stored as .npz.  The fixtures are data only -- no referen
 
     python tests/golden/generate.py          # rewrites tests/golden/*.npz
 
-Fixture list follows SURVEY.md section 8(c) (F1..F10).
+Fixture list follows SURVEY.md section 8(c) (F1..F10), plus F11 (cell boundaries) and F12 (partial-inertial scheme).
+`python tests/golden/generate.py f12` regenerates only the fixtures whose file name starts with f12.
 """
 import os
 import sys
@@ -243,9 +244,10 @@ def cell_boundary(precision, tag):
     save(f"f11_cell_boundary_{tag}", **out)
 
 
-def newcastle(precision, tag):
+def newcastle(precision, tag, mad=False):
     """F10: config C1 -- the reference's own example (342x195 @ 2 m DEM from its data file, rain 70 mm/h + drainage
-    12 mm/h, closed edges), Godunov fp64, first 900 iterations on the reference's kernels."""
+    12 mm/h, closed edges), Godunov fp64, first 900 iterations on the reference's kernels.  The -cl-mad-enable build
+    (what the reference ships) stores only the final levels and time: it brackets the reference's own spread."""
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hipims_mi import frontend
@@ -253,24 +255,105 @@ def newcastle(precision, tag):
     with tempfile.TemporaryDirectory() as tmp:
         cfg = frontend.parse_configuration(make_newcastle(tmp))
         st, bed, man, res = frontend.build_domain(cfg)
-    sim = oracle.RefSim(342, 195, precision=precision, dx=res, end_time=cfg.duration)
+    sim = oracle.RefSim(342, 195, precision=precision, dx=res, end_time=cfg.duration, mad=mad)
     sim.upload(st, bed, man)
     frontend.attach_boundaries(cfg, sim, 342)
     sim.set_target(1e9)
     dt = sim.run(900)
     final = sim.download()
+    if mad:
+        save(f"f10_newcastle_{tag}", z=final[..., 0], t=np.array(sim.scalars()["t"]))
+        return
     depth = np.maximum(0, final[..., 0] - bed)
     save(f"f10_newcastle_{tag}", dt=dt, t=np.array(sim.scalars()["t"]), depth=depth.astype(np.float32),
          z=final[..., 0], qx=final[..., 2].astype(np.float32), qy=final[..., 3].astype(np.float32))
 
 
+def inertial(precision, tag, mad=False):
+    """F12: calculateInertialFlux table + ine_cacheDisabled trajectories (CLSchemeInertial.clc)."""
+    real = np.float64 if precision == "f64" else np.float32
+    out = {}
+    if not mad:
+        ref = oracle.RefFunctions(precision=precision)
+        rng = np.random.default_rng(12)
+        n = 4096
+        bu, bd = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        kind = rng.integers(0, 5, (2, n))
+        depth = lambda k: np.where(k == 0, 0.0, np.where(k == 1, rng.uniform(0, 2e-10, n),
+                          np.where(k == 2, rng.uniform(1e-6, 1e-3, n), rng.uniform(0.01, 3.0, n))))
+        args = np.stack([rng.choice([0.0, 0.03, 0.06], n) + rng.uniform(0, 0.02, n) * (rng.random(n) < 0.5),   # n
+                         rng.choice([0.001, 0.05, 0.1], n) * rng.uniform(0.5, 1.0, n),                         # dt
+                         rng.normal(0, 1.5, n) * (rng.random(n) > 0.25),                                       # q_prev
+                         bu + depth(kind[0]), bu, bd + depth(kind[1]), bd], axis=1).astype(real)
+        res = np.array([ref.inertial_flux(*a) for a in args], real)
+        out.update(flux_args=args, flux_out=res)
+
+    def run(name, cols, rows, st, bed, man, steps, quirks=oracle.QUIRKS_REFERENCE, first=False, setup=None):
+        sim = oracle.RefSim(cols, rows, scheme=oracle.INERTIAL, precision=precision, quirks=quirks, mad=mad)
+        sim.upload(st, bed, man)
+        sim.set_target(1e9)
+        if setup:
+            setup(sim)
+        dts = []
+        if first:
+            dts.append(sim.run(1))
+            out[f"{name}_state1"] = sim.download()
+            steps -= 1
+        dts.append(sim.run(steps))
+        out[f"{name}_state"] = sim.download()
+        out[f"{name}_dt"] = np.concatenate(dts)
+        out[f"{name}_t"] = np.array(sim.scalars()["t"])
+        return sim
+
+    st, bed, man = syn.s_rough(64, 64, dtype=real, manning=None)            # spatially varying n: four fluxes per cell
+    st[..., 2:] = 0
+    out.update(rough_state=st, rough_bed=bed, rough_manning=man)
+    run("rough_q", 64, 64, st, bed, man, 200, first=True)
+    run("rough_noq1", 64, 64, st, bed, man, 200, quirks=oracle.QUIRKS_REFERENCE & ~oracle.Q1_CFL_READS_PRIMARY)
+    st, bed, man = syn.s_dam(96, 48, dtype=real)                             # uniform n: shared faces
+    run("dam", 96, 48, st, bed, man, 150)                                    # 10 m -> 1 m: far outside the scheme's range
+    st, bed, man = syn.s_dam(96, 48, dtype=real, levels=(2.0, 1.6))          # gentle step: what the scheme is for
+    run("step", 96, 48, st, bed, man, 150)
+    st, bed, man = syn.s_dam(96, 48, dtype=real, wet_right=False)
+    run("damdry", 96, 48, st, bed, man, 150)
+    # sync point: the target time is reached, iterations are skipped (dt <= 0: the kernel leaves dst untouched), then
+    # the target moves on (Threaded_runBatch: new target -> tst_UpdateTimestep)
+    st, bed, man = syn.s_rough(48, 40, dtype=real, manning=None)
+    st[..., 2:] = 0
+    out.update(sync_state=st, sync_bed=bed, sync_manning=man)
+    sim = run("sync_a", 48, 40, st, bed, man, 40, setup=lambda s: s.set_target(2.0))
+    sim.set_target(5.0)
+    sim.update_timestep()
+    out["sync_b_dt"] = sim.run(45)
+    out["sync_b_state"] = sim.download()
+    out["sync_b_t"] = np.array(sim.scalars()["t"])
+    # uniform rain + gridded rain through the inherited boundary path
+    st, bed, man = syn.s_rough(48, 40, dtype=real, pool_level=-10.0, amplitude=0.2, walls=False)
+    st[..., 2:] = 0
+    series = np.array([[0, 50.0], [10, 120.0], [20, 0.0], [30, 80.0]], real)
+    grids = np.random.default_rng(5).uniform(0, 120, (3, 5, 6)).astype(real)
+    out.update(rain_init=st, rain_bed=bed, rain_manning=man, rain_series=series, rain_grids=grids)
+
+    def add_rain(s):
+        s.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, series, 10.0, 30.0)
+        s.add_gridded(oracle.GRIDDED_RAIN_INTENSITY, grids, 10.0, 0.0, 0.0, 15.0)
+    run("rain", 48, 40, st, bed, man, 260, setup=add_rain)
+    save(f"f12_inertial_{tag}", **out)
+
+
+JOBS = [
+    ("f1", lambda: [function_level(p, p) for p in ("f64", "f32")]),      # f1..f5
+    ("f6", lambda: [trajectories(p, p) for p in ("f64", "f32")] + [trajectories("f64", "f64_mad", mad=True)]),
+    ("f8", lambda: [time_control(p, p) for p in ("f64", "f32")]),
+    ("f9", lambda: [rain(p, p) for p in ("f64", "f32")]),
+    ("f11", lambda: [cell_boundary(p, p) for p in ("f64", "f32")]),
+    ("f10", lambda: [newcastle("f64", "f64"), newcastle("f64", "f64_mad", mad=True)]),
+    ("f12", lambda: [inertial(p, p) for p in ("f64", "f32")] + [inertial("f64", "f64_mad", mad=True)]),
+]
+
 if __name__ == "__main__":
     oracle.build(ref=True)
-    for precision in ("f64", "f32"):
-        function_level(precision, precision)
-        trajectories(precision, precision)
-        time_control(precision, precision)
-        rain(precision, precision)
-        cell_boundary(precision, precision)
-    trajectories("f64", "f64_mad", mad=True)
-    newcastle("f64", "f64")
+    want = sys.argv[1:]
+    for key, job in JOBS:
+        if not want or key in want:
+            job()

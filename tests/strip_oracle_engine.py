@@ -54,8 +54,9 @@ class OracleStripEngine:
         P = self._ptr
         src, dst = self.buf[self.use_alt], self.buf[self.use_alt ^ 1]
         dt = self.creal(self.sc.dt)
-        if self.scheme == oracle.GODUNOV:
-            self.lib.orc_godunov_step(C.byref(self.p), dt, P(self.bed), P(src), P(dst), P(self.man))
+        if self.scheme != oracle.MUSCL:
+            step = self.lib.orc_godunov_step if self.scheme == oracle.GODUNOV else self.lib.orc_inertial_step
+            step(C.byref(self.p), dt, P(self.bed), P(src), P(dst), P(self.man))
             reduce_buf = self.buf[0] if (self.quirks & oracle.Q1_CFL_READS_PRIMARY) else dst
         else:
             f = self.faces

@@ -341,3 +341,97 @@ def test_full_size_4096_mass_conservation_and_kernel_agreement():
         assert dom.read_scalars()["cells_calculated"] == 30 * n * n
         dom.close()
     assert np.abs(outs[0] - outs[1]).max() < 1e-9              # tuned kernel == basic kernel
+
+
+# ---- partial-inertial scheme: K6 inertial_march ----
+@pytest.mark.parametrize("mode", MODES)
+def test_inertial_rough_bed_200_steps(mode):
+    """Spatially varying Manning n: four flux evaluations per cell (the reference's face values differ per side)."""
+    g = load_golden("f12_inertial_f64")
+    st, bed, man = g["rough_state"], g["rough_bed"], g["rough_manning"]
+    dom, ref = make_pair(64, 64, st, bed, man, scheme=hp.SCHEME_INERTIAL, math_mode=mode)
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    tr_ref, tr_gpu = ref.run(200), dom.run(200)
+    assert np.abs(tr_gpu - tr_ref).max() <= 1e-12 * tr_ref.max()
+    compare(dom, ref)
+    depth_g = np.maximum(0, g["rough_q_state"][..., 0] - bed)
+    dg, _, _ = dom.depth_velocity()
+    assert np.sqrt(np.mean((dg - depth_g) ** 2)) < 1e-9 and np.abs(dg - depth_g).max() < 1e-7
+    # the stored face discharges themselves
+    out = dom.download()
+    assert np.abs(out[..., 2:] - g["rough_q_state"][..., 2:]).max() < 1e-9
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("key,kw", [("step", dict(levels=(2.0, 1.6))), ("damdry", dict(wet_right=False))])
+def test_inertial_uniform_manning_fixture(mode, key, kw):
+    """Uniform n: the kernel shares each face between its two cells (two evaluations per cell)."""
+    g = load_golden("f12_inertial_f64")
+    st, bed, man = syn.s_dam(96, 48, **kw)
+    dom = hp.Domain(96, 48, scheme=hp.SCHEME_INERTIAL, math_mode=mode)
+    dom.upload(st, bed, man)
+    dom.set_target_time(1e9)
+    dom.step_batch(150)
+    out = dom.download()
+    dg = np.maximum(0, out[..., 0] - bed)
+    dr = np.maximum(0, g[f"{key}_state"][..., 0] - bed)
+    assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
+    assert abs(dom.read_scalars()["time"] - float(g[f"{key}_t"])) < 1e-10
+
+
+def test_inertial_sync_point_leaves_dst_untouched():
+    """dt <= 0: ine_cacheDisabled returns before writing (CLSchemeInertial.clc:61-62), so skipped iterations flip to
+    a buffer that still holds the state of two iterations earlier -- the fixture from the reference's kernel has it."""
+    g = load_golden("f12_inertial_f64")
+    dom = hp.Domain(48, 40, scheme=hp.SCHEME_INERTIAL, math_mode=hp.MATH_STRICT)
+    dom.upload(g["sync_state"], g["sync_bed"], g["sync_manning"])
+    dom.set_target_time(2.0)
+    dom.step_batch(40)
+    sc = dom.read_scalars()
+    assert sc["timestep"] < 0 and sc["batch_skipped"] > 0 and abs(sc["time"] - 2.0) < 1e-12
+    assert np.abs(dom.download() - g["sync_a_state"]).max() < 1e-9
+    dom.set_target_time(5.0)
+    dom.update_timestep()
+    dom.step_batch(45)
+    assert np.abs(dom.download() - g["sync_b_state"]).max() < 1e-9
+    assert abs(dom.read_scalars()["time"] - float(g["sync_b_t"])) < 1e-10
+
+
+def test_inertial_rain_and_fp32():
+    g = load_golden("f12_inertial_f64")
+    dom = hp.Domain(48, 40, scheme=hp.SCHEME_INERTIAL)
+    dom.upload(g["rain_init"], g["rain_bed"], g["rain_manning"])
+    dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, g["rain_series"], 10.0, 30.0)
+    dom.add_gridded(hp.GRIDDED_RAIN_INTENSITY, g["rain_grids"], 10.0, 0.0, 0.0, 15.0)
+    dom.set_target_time(1e9)
+    dom.step_batch(260)
+    dg = np.maximum(0, dom.download()[..., 0] - g["rain_bed"])
+    dr = np.maximum(0, g["rain_state"][..., 0] - g["rain_bed"])
+    assert dr.max() > 1e-5 and np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
+    g32 = load_golden("f12_inertial_f32")
+    for mode in MODES:
+        dom = hp.Domain(64, 64, scheme=hp.SCHEME_INERTIAL, precision="f32", math_mode=mode)
+        dom.upload(g32["rough_state"], g32["rough_bed"], g32["rough_manning"])
+        dom.set_target_time(1e9)
+        dom.step_batch(200)
+        d = np.maximum(0, dom.download()[..., 0].astype(np.float64) - g32["rough_bed"])
+        r = np.maximum(0, g32["rough_q_state"][..., 0].astype(np.float64) - g32["rough_bed"])
+        assert np.sqrt(np.mean((d - r) ** 2)) < 1e-4
+
+
+def test_inertial_full_size_4096_properties():
+    """BASELINE size: mass conservation of the closed basin (shared faces) and agreement of FAST with STRICT."""
+    cols = rows = 4096
+    st, bed, man = syn.s_dam(cols, rows, levels=(2.0, 1.6))
+    outs = []
+    for mode in MODES:
+        dom = hp.Domain(cols, rows, scheme=hp.SCHEME_INERTIAL, math_mode=mode)
+        dom.upload(st, bed, man)
+        dom.set_target_time(1e9)
+        dom.step_batch(300)
+        outs.append(dom.download()[..., 0].copy())
+        dom.close()
+    d0 = np.maximum(0, st[..., 0] - bed).sum()
+    for z in outs:
+        assert abs(np.maximum(0, z - bed).sum() - d0) / d0 < 1e-12
+    assert np.abs(outs[0] - outs[1]).max() < 1e-9

@@ -68,7 +68,7 @@ def run_strips(cols, rows, nstrips, scheme, steps, st, bed, man, rain=None, over
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("scheme,nstrips,rows", [(hp.SCHEME_GODUNOV, 2, 96), (hp.SCHEME_GODUNOV, 3, 96),
                                                  (hp.SCHEME_GODUNOV, 3, 211), (hp.SCHEME_MUSCL_HANCOCK, 2, 96),
-                                                 (hp.SCHEME_MUSCL_HANCOCK, 2, 263)])
+                                                 (hp.SCHEME_MUSCL_HANCOCK, 2, 263), (hp.SCHEME_INERTIAL, 2, 211)])
 def test_strips_are_bit_identical_to_single_domain(scheme, nstrips, rows, overlap):
     # the taller grids have interior row segments, so the overlap mode really splits the launch (263: MUSCL's last
     # segment holds a single row and the halo part takes the last two segments)

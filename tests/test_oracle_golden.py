@@ -221,3 +221,62 @@ def test_newcastle_example(tmp_path):
     assert same(final[..., 0], g["z"])
     assert sim.scalars()["t"] == g["t"]
     assert g["depth"].max() > 1e-4
+
+
+# ---- partial-inertial scheme ----
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_inertial_flux_table(precision):
+    g = load_golden(f"f12_inertial_{precision}")
+    of = oracle.OracleFunctions(precision)
+    got = np.array([of.inertial_flux(*a) for a in g["flux_args"]], g["flux_out"].dtype)
+    assert same(got, g["flux_out"])
+    assert (g["flux_out"] != 0).sum() > 1000 and (g["flux_out"] == 0).sum() > 100      # both regimes are in the table
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_inertial_trajectories(precision):
+    from hipims_mi import synthetic as syn
+    g = load_golden(f"f12_inertial_{precision}")
+    real = np.float64 if precision == "f64" else np.float32
+    st, bed, man = g["rough_state"], g["rough_bed"], g["rough_manning"]
+    for qname, quirks in (("q", oracle.QUIRKS_REFERENCE), ("noq1", oracle.QUIRKS_REFERENCE & ~oracle.Q1_CFL_READS_PRIMARY)):
+        sim = oracle.OracleSim(64, 64, scheme=oracle.INERTIAL, precision=precision, quirks=quirks)
+        sim.upload(st, bed, man)
+        sim.set_target(1e9)
+        dts = [sim.run(1)]
+        if qname == "q":
+            assert same(sim.download(), g["rough_q_state1"])
+        dts.append(sim.run(199))
+        assert same(np.concatenate(dts), g[f"rough_{qname}_dt"])
+        assert same(sim.download(), g[f"rough_{qname}_state"])
+        assert sim.scalars()["t"] == g[f"rough_{qname}_t"]
+    for kw, key in ((dict(), "dam"), (dict(wet_right=False), "damdry"), (dict(levels=(2.0, 1.6)), "step")):
+        st, bed, man = syn.s_dam(96, 48, dtype=real, **kw)
+        sim = oracle.OracleSim(96, 48, scheme=oracle.INERTIAL, precision=precision)
+        assert same(_run(sim, st, bed, man, 150), g[f"{key}_dt"])
+        assert same(sim.download(), g[f"{key}_state"])
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_inertial_sync_point_and_rain(precision):
+    g = load_golden(f"f12_inertial_{precision}")
+    sim = oracle.OracleSim(48, 40, scheme=oracle.INERTIAL, precision=precision)
+    sim.upload(g["sync_state"], g["sync_bed"], g["sync_manning"])
+    sim.set_target(2.0)
+    assert same(sim.run(40), g["sync_a_dt"])
+    assert same(sim.download(), g["sync_a_state"])
+    assert sim.scalars()["batch_skipped"] > 0                      # the target was reached: skipped iterations happened
+    sim.set_target(5.0)
+    sim.update_timestep()
+    assert same(sim.run(45), g["sync_b_dt"])
+    assert same(sim.download(), g["sync_b_state"])
+    assert sim.scalars()["t"] == g["sync_b_t"]
+
+    sim = oracle.OracleSim(48, 40, scheme=oracle.INERTIAL, precision=precision)
+    sim.upload(g["rain_init"], g["rain_bed"], g["rain_manning"])
+    sim.set_target(1e9)
+    sim.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, g["rain_series"], 10.0, 30.0)
+    sim.add_gridded(oracle.GRIDDED_RAIN_INTENSITY, g["rain_grids"], 10.0, 0.0, 0.0, 15.0)
+    assert same(sim.run(260), g["rain_dt"])
+    assert same(sim.download(), g["rain_state"])
+    assert (g["rain_state"][..., 0] - g["rain_bed"]).max() > 1e-5          # it rained

@@ -10,11 +10,13 @@ pytestmark = pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not b
 
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
-@pytest.mark.parametrize("scheme", [oracle.GODUNOV, oracle.MUSCL])
+@pytest.mark.parametrize("scheme", [oracle.GODUNOV, oracle.MUSCL, oracle.INERTIAL])
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_terrain_trajectory(precision, scheme, seed):
     real = np.float64 if precision == "f64" else np.float32
     st, bed, man = syn.s_rough(40, 33, dtype=real, seed=seed, manning=None, walls=bool(seed % 2))
+    if scheme == oracle.INERTIAL and not oracle.have_ref("ine_" + precision):
+        pytest.skip("oracle/_ref built before the inertial recipe existed")
     a = oracle.OracleSim(40, 33, scheme=scheme, precision=precision, dx=1.5)
     b = oracle.RefSim(40, 33, scheme=scheme, precision=precision, dx=1.5)
     for s in (a, b):
@@ -51,3 +53,17 @@ def test_muscl_snapshot_equals_serial_when_wet():
         s.run(80)
         outs.append(s.download())
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.skipif(not oracle.have_ref("ine_f64"), reason="inertial reference build missing")
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_inertial_flux_random(precision):
+    rng = np.random.default_rng(77)
+    of, rf = oracle.OracleFunctions(precision), oracle.RefFunctions(precision)
+    for _ in range(3000):
+        bu, bd = rng.uniform(-1, 1, 2)
+        args = (rng.choice([0.0, 0.03, rng.uniform(0.01, 0.1)]), rng.choice([0.001, 0.05, rng.uniform(1e-4, 1)]),
+                rng.choice([0.0, rng.normal(0, 2)]), bu + rng.choice([0, 1e-11, rng.uniform(0, 3)]), bu,
+                bd + rng.choice([0, 1e-11, rng.uniform(0, 3)]), bd)
+        a, b = of.inertial_flux(*args), rf.inertial_flux(*args)
+        assert a == b or (np.isnan(a) and np.isnan(b)), args

@@ -7,7 +7,7 @@ import oracle
 from hipims_mi import synthetic as syn
 
 
-@pytest.mark.parametrize("scheme", [oracle.GODUNOV, oracle.MUSCL])
+@pytest.mark.parametrize("scheme", [oracle.GODUNOV, oracle.MUSCL, oracle.INERTIAL])
 def test_lake_at_rest(scheme):
     # tools/model-builder/tests/TestLakeAtRest.js:59-70 -- still water over a bumpy bed must not move
     rng = np.random.default_rng(3)
@@ -26,9 +26,12 @@ def test_lake_at_rest(scheme):
     assert np.abs(out[..., 2:]).max() == 0.0
 
 
-def test_mass_conservation_closed_basin():
-    st, bed, man = syn.s_dam(64, 40)
-    s = oracle.OracleSim(64, 40)
+@pytest.mark.parametrize("scheme", [oracle.GODUNOV, oracle.INERTIAL])
+def test_mass_conservation_closed_basin(scheme):
+    # the inertial scheme is not positivity preserving under a 10 m -> 1 m dam break (cells drained below the bed
+    # are reset to it, CLSchemeInertial.clc:159-160): it gets the gentle step it is meant for
+    st, bed, man = syn.s_dam(64, 40, levels=(10.0, 1.0) if scheme == oracle.GODUNOV else (2.0, 1.6))
+    s = oracle.OracleSim(64, 40, scheme=scheme)
     s.upload(st, bed, man)
     s.set_target(1e9)
     d0, _, _ = s.depth_velocity()

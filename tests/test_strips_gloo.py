@@ -24,7 +24,7 @@ def _worker(rank, world, port, scheme, cols, rows, steps, q):
     from strip_oracle_engine import OracleStripEngine
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     st, bed, man = syn.s_rough(cols, rows, manning=None)
-    oscheme = oracle.MUSCL if scheme == strips.SCHEME_MUSCL_HANCOCK else oracle.GODUNOV
+    oscheme = scheme                                  # same numbering: 0 Godunov, 1 MUSCL-Hancock, 2 inertial
     factory = functools.partial(OracleStripEngine, scheme=oscheme)
     r = strips.StripRunner(cols, rows, scheme=scheme, rank=rank, world=world, engine_factory=factory)
     r.upload_global(st, bed, man)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, scheme, cols, rows, steps, q):
 
 
 @pytest.mark.parametrize("scheme,world", [(strips.SCHEME_GODUNOV, 2), (strips.SCHEME_GODUNOV, 3),
-                                          (strips.SCHEME_MUSCL_HANCOCK, 2)])
+                                          (strips.SCHEME_MUSCL_HANCOCK, 2), (strips.SCHEME_INERTIAL, 2)])
 def test_decomposed_run_is_bit_identical(scheme, world):
     cols, rows, steps = 40, 36, 90
     ctx = mp.get_context("spawn")
@@ -53,7 +53,7 @@ def test_decomposed_run_is_bit_identical(scheme, world):
         assert p.exitcode == 0
 
     st, bed, man = syn.s_rough(cols, rows, manning=None)
-    oscheme = oracle.MUSCL if scheme == strips.SCHEME_MUSCL_HANCOCK else oracle.GODUNOV
+    oscheme = scheme
     quirks = oracle.QUIRKS_REFERENCE & ~oracle.Q6_MUSCL_SERIAL
     single = oracle.OracleSim(cols, rows, scheme=oscheme, quirks=quirks)
     single.upload(st, bed, man)
