@@ -1,0 +1,99 @@
+// Memory-pattern probe for the marching kernels (not product code): how fast can the chip move the bytes of one
+// Godunov step (read 32 B state + 8 B bed per cell, write 32 B state) with different per-lane access shapes?
+//   0  linear float4 copy of the same byte count (the guide's 6.3 TB/s reference shape)
+//   1  row march, lane = cell, state as two 16-B loads at stride 32 (what K1/K2/K6 do), 2 rows in flight
+//   2  row march, lane-contiguous 16-B loads (two instructions cover 2 KB contiguously), stores likewise
+//   3  like 1 with 4 rows in flight
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_linear(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst, size_t cells)
+{
+	const size_t n2 = cells * 2;                       // 16-B elements of the state
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t stride = (size_t)gridDim.x * 256;
+	double acc = 0;
+	for (; i < n2; i += stride) {
+		d2 v = src[i];
+		if ((i & 3) == 0) acc += bed[i >> 1];          // 8 B per cell, coalesced enough
+		v.x += acc * 1e-300;
+		dst[i] = v;
+	}
+}
+
+template <int DEPTH, bool CONTIG>
+__global__ __launch_bounds__(256) void k_march(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst,
+                                               int cols, int rows, int rseg, int groups, int ntiles)
+{
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int strip = (tile % groups) * 4 + wave, seg = tile / groups;
+	if (tile >= (unsigned)ntiles) return;
+	const int x0 = strip * 64;
+	if (x0 >= cols) return;
+	const int y0 = seg * rseg, y1 = min(y0 + rseg, rows);
+	d2 a[DEPTH], b[DEPTH]; double z[DEPTH];
+	auto load = [&](int y, int slot) {
+		const size_t cell = (size_t)y * cols + x0;
+		if (CONTIG) { a[slot] = src[cell * 2 + lane]; b[slot] = src[cell * 2 + 64 + lane]; }
+		else        { a[slot] = src[(cell + lane) * 2]; b[slot] = src[(cell + lane) * 2 + 1]; }
+		z[slot] = bed[cell + lane];
+	};
+	#pragma unroll
+	for (int k = 0; k < DEPTH; ++k) load(min(y0 + k, rows - 1), k);
+	for (int y = y0; y < y1; y += DEPTH) {
+		#pragma unroll
+		for (int k = 0; k < DEPTH; ++k) {
+			if (y + k >= y1) break;
+			d2 va = a[k], vb = b[k]; const double zz = z[k];
+			load(min(y + k + DEPTH, rows - 1), k);
+			va.x += zz * 1e-300;
+			const size_t cell = (size_t)(y + k) * cols + x0;
+			if (CONTIG) { dst[cell * 2 + lane] = va; dst[cell * 2 + 64 + lane] = vb; }
+			else        { dst[(cell + lane) * 2] = va; dst[(cell + lane) * 2 + 1] = vb; }
+		}
+	}
+}
+
+int main(int argc, char** argv)
+{
+	const int cols = 4096, rows = 4096;
+	const size_t cells = (size_t)cols * rows;
+	d2 *src, *dst; double* bed;
+	CK(hipMalloc(&src, cells * 32)); CK(hipMalloc(&dst, cells * 32)); CK(hipMalloc(&bed, cells * 8));
+	CK(hipMemset(src, 0, cells * 32)); CK(hipMemset(dst, 0, cells * 32)); CK(hipMemset(bed, 0, cells * 8));
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	const double bytes = (double)cells * 72;
+	auto timeit = [&](const char* name, auto launch) {
+		for (int i = 0; i < 5; ++i) launch();
+		CK(hipEventRecord(e0));
+		const int n = 50;
+		for (int i = 0; i < n; ++i) launch();
+		CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= n;
+		printf("%-44s %.4f ms  %.2f TB/s\n", name, ms, bytes / ms / 1e9);
+	};
+	for (int blocks : {2048, 4096, 8192, 16384})
+		timeit(("linear float4-shaped copy, blocks=" + std::to_string(blocks)).c_str(),
+		       [&] { hipLaunchKernelGGL(k_linear, dim3(blocks), dim3(256), 0, 0, src, bed, dst, cells); });
+	for (int rseg : {16, 32, 64}) {
+		const int groups = cols / 64 / 4, nsegs = (rows + rseg - 1) / rseg, ntiles = groups * nsegs;
+		const unsigned blocks = (ntiles + 7) / 8 * 8;
+		char nm[128];
+		snprintf(nm, sizeof nm, "march stride-32 pairs, depth 2, rseg=%d", rseg);
+		timeit(nm, [&] { hipLaunchKernelGGL((k_march<2, false>), dim3(blocks), dim3(256), 0, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+		snprintf(nm, sizeof nm, "march lane-contiguous, depth 2, rseg=%d", rseg);
+		timeit(nm, [&] { hipLaunchKernelGGL((k_march<2, true>), dim3(blocks), dim3(256), 0, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+		snprintf(nm, sizeof nm, "march stride-32 pairs, depth 4, rseg=%d", rseg);
+		timeit(nm, [&] { hipLaunchKernelGGL((k_march<4, false>), dim3(blocks), dim3(256), 0, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+		snprintf(nm, sizeof nm, "march lane-contiguous, depth 4, rseg=%d", rseg);
+		timeit(nm, [&] { hipLaunchKernelGGL((k_march<4, true>), dim3(blocks), dim3(256), 0, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+	}
+	return 0;
+}
