@@ -256,78 +256,70 @@ def attach_boundaries(cfg, sim, cols):
 
 
 # ------------------------------------------------------------------------------------------------ outputs
-def derive_output(what, state, bed):
+def data_value_code(name):
+    """CDomain::getDataValueCode (CDomain.cpp:464-500): SUBSTRING matches, in the reference's order (so "maxdepth"
+    wins over "depth", "maxfsl" over "fsl")."""
+    n = (name or "").lower()
+    if "dem" in n:
+        return "dem"
+    if "maxdepth" in n:
+        return "maxdepth"
+    if "depth" in n:
+        return "depth"
+    for key in ("disabled", "dischargex", "dischargey"):
+        if key in n:
+            return key
+    if "maxfsl" in n:
+        return "maxfsl"
+    if "fsl" in n:
+        return "fsl"
+    for key in ("manningcoefficient", "velocityx", "velocityy", "froude"):
+        if key in n:
+            return key
+    return None
+
+
+def derive_output(what, state, bed, resolution=1.0):
     """Datasets/CRasterDataset.cpp:185-267."""
+    code = data_value_code(what)
     z, zmax, qx, qy = (state[..., k].astype(np.float64) for k in range(4))
     bed = bed.astype(np.float64)
     depth = z - bed
     with np.errstate(divide="ignore", invalid="ignore"):
-        if what == "depth":
+        if code == "depth":
             d = np.maximum(0.0, depth)
             return np.where(d < 1e-8, NODATA, d)
-        if what == "maxdepth":
+        if code == "maxdepth":
             d = np.maximum(0.0, zmax - bed)
             return np.where((d < 1e-8) | (d <= -9990.0) | (d >= 9999.0), NODATA, d)
-        if what == "fsl":
+        if code == "fsl":
             return np.where((z < bed + 1e-8) | (bed > 9999.0), NODATA, z)
-        if what == "maxfsl":
+        if code == "maxfsl":
             return np.where((zmax < bed + 1e-8) | (bed > 9999.0), NODATA, zmax)
-        if what == "velocityx":
+        if code == "dischargex":
+            return qx * resolution
+        if code == "dischargey":
+            return qy * resolution
+        if code == "velocityx":
             return np.where(depth > 1e-8, qx / depth, NODATA)
-        if what == "velocityy":
+        if code == "velocityy":
             return np.where(depth > 1e-8, qy / depth, NODATA)
-        if what == "froude":
+        if code == "froude":
             return np.where(depth > 1e-8, np.sqrt((qx / depth) ** 2 + (qy / depth) ** 2) / np.sqrt(9.81 * depth), NODATA)
     raise ValueError(f"unknown output {what}")
 
 
-def run_model(xml_path, make_sim=None, batch=200, output_format=".npy", max_outputs=None, log=None):
-    """CModel::runModel for one domain: advance to each output time, write the configured rasters there.
-
+def run_model(xml_path, make_sim=None, batch=None, output_format=".npy", max_outputs=None, log=None):
+    """CModel::runModel for one domain (see model.py): advance to each output time, write the configured rasters
+    there.  `batch` fixes the batch size (the reference's `queueMode="fixed"`); default = the autotuner.
     make_sim(cfg, cols, rows, res) may return any object with the Domain surface (the tests pass the oracle);
     the default is the HIP engine.  Returns [(time, {value: south-up array})]."""
-    cfg = parse_configuration(xml_path)
-    state, bed, man, res = build_domain(cfg)
-    rows, cols = bed.shape
-    if make_sim is None:
-        from . import Domain
-        sim = Domain(cols, rows, dx=res, scheme=cfg.scheme, precision=cfg.precision, dry_threshold=cfg.dry_threshold,
-                     courant=cfg.courant, t_end=cfg.duration, dynamic_dt=cfg.dynamic_dt, dt_fixed=cfg.timestep,
-                     dt_initial=cfg.timestep, friction=cfg.friction, device=cfg.device_number - 1)
-    else:
-        sim = make_sim(cfg, cols, rows, res)
-    sim.upload(state, bed, man)
-    attach_boundaries(cfg, sim, cols)
-
-    def scalars():
-        s = sim.read_scalars() if hasattr(sim, "read_scalars") else sim.scalars()
-        return (s["time"], s["timestep"]) if "time" in s else (s["t"], s["dt"])
-
-    results, target = [], 0.0
-    t, dt = scalars()
-    while t < cfg.duration - 1e-9 and (max_outputs is None or len(results) < max_outputs):
-        target = min(cfg.duration, target + cfg.output_frequency)               # runModelUpdateTarget (:723-770)
-        (sim.set_target_time if hasattr(sim, "set_target_time") else sim.set_target)(target)
-        if dt <= 0.0:                                                            # Threaded_runBatch :1189-1195
-            if hasattr(sim, "update_timestep"):
-                sim.update_timestep()
-            t, dt = scalars()
-        if t + dt > target + 1e-5:
-            (sim.force_timestep if hasattr(sim, "force_timestep") else sim.force_dt)(target - t)
-        while target - t > 1e-5:
-            (sim.step_batch if hasattr(sim, "step_batch") else sim.run)(batch)
-            t, dt = scalars()
-        final = sim.download()
-        out = {}
-        for what, pattern in cfg.targets:                                        # CDomainCartesian.cpp:804-829
-            arr = derive_output(what, final, bed)
-            out[what] = arr
-            if pattern and cfg.target_dir and output_format:
-                fname = os.path.splitext(pattern.replace("%t", str(int(round(t)))))[0] + output_format
-                write_raster(os.path.join(cfg.target_dir, fname), arr, res)
-        results.append((t, out))
-        if log:
-            log(f"t = {t:.3f} s written ({len(out)} rasters)")
-    if hasattr(sim, "close"):
-        sim.close()
-    return results
+    from .model import Model
+    m = Model(xml_path, make_sim=make_sim, output_format=output_format, log=log)
+    if batch:
+        m.scheme.automatic_queue = False
+        m.scheme.queue_addition_size = int(batch)
+    try:
+        return m.run(max_outputs=max_outputs)
+    finally:
+        m.close()

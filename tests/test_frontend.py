@@ -64,3 +64,96 @@ def test_run_model_writes_reference_outputs(tmp_path):
     assert "depth_60.npy" in files and "velX_120.npy" in files and len(files) == 10
     saved = np.load(os.path.join(str(tmp_path), "output", "depth_120.npy"))
     assert np.array_equal(saved, depth)
+
+
+# ---- orchestrator parity: hipims_mi/model.py ----
+def test_value_codes_follow_the_reference_substring_order():
+    codes = {n: frontend.data_value_code(n) for n in
+             ("depth", "MaxDepth", "fsl", "maxfsl", "velocityX", "dischargey", "froude", "dem", "manningcoefficient", "x")}
+    assert codes == {"depth": "depth", "MaxDepth": "maxdepth", "fsl": "fsl", "maxfsl": "maxfsl", "velocityX": "velocityx",
+                     "dischargey": "dischargey", "froude": "froude", "dem": "dem",
+                     "manningcoefficient": "manningcoefficient", "x": None}
+    st = np.zeros((2, 2, 4)); st[..., 0] = 1.5; st[..., 1] = 2.0; st[..., 2] = 0.3; st[..., 3] = -0.4
+    bed = np.full((2, 2), 1.0)
+    assert np.allclose(frontend.derive_output("dischargex", st, bed, 2.0), 0.6)       # Q * resolution (:222-233)
+    assert np.allclose(frontend.derive_output("froude", st, bed), 0.5 / 0.5 / np.sqrt(9.81 * 0.5))
+    assert np.allclose(frontend.derive_output("maxdepth", st, bed), 1.0) and np.allclose(frontend.derive_output("maxfsl", st, bed), 2.0)
+
+
+class _Clock:
+    """Deterministic stand-in for the wall clock: every reading advances by `tick` seconds."""
+    def __init__(self, tick):
+        self.t, self.tick = 0.0, tick
+
+    def __call__(self):
+        self.t += self.tick
+        return self.t
+
+
+def test_orchestrator_targets_batches_progress_and_outputs(tmp_path):
+    from hipims_mi.model import Model
+    xml = make_newcastle(tmp_path, duration=90, frequency=30)
+    lines = []
+    m = Model(xml, make_sim=_oracle_sim, log=lines.append, clock=_Clock(0.01), progress_interval=0.085)
+    outs = m.run()
+    # outputs exactly at the multiples of the output frequency; the device-side sync clipping lands on them
+    assert [round(t, 9) for t, _ in outs] == [30.0, 60.0, 90.0]
+    assert m.last_output_time == m.current_time == 90.0 and m.target_time == 90.0
+    sc = m.sim.scalars()
+    assert sc["t"] == 90.0
+    # the autotuner aims for a second of work per batch: with 0.01 s per clock reading it grows from 1, at most
+    # doubling once past 40 and never beyond 3x the iterations the previous batch completed (:1420-1448)
+    sizes = [b["batch_size"] for b in m.progress_blocks]
+    assert sizes[0] >= 1 and max(sizes) > 8 and all(b <= 3 * max(1, a) or b <= 40 for a, b in zip(sizes, sizes[1:]))
+    last = m.progress_blocks[-1]
+    assert last["progress"] == 1.0 and last["cells_calculated"] == m.scheme.iterations * 342 * 195
+    assert last["rate"] == int(last["cells_calculated"] / last["processing_time"])
+    assert any("SIMULATION PROGRESS" in l for l in lines) and any("Output files written" in l for l in lines)
+
+    # Batch boundaries are not physics-neutral IN THE REFERENCE: with quirk Q1 the timestep that follows a sync point is
+    # priced on the pre- or post-step buffer depending on the parity of the iteration that landed on it and on
+    # whether skipped iterations followed (the reference's wall-clock autotuner makes that non-deterministic there).
+    # While dt is capped (t < 60 s: dt <= 0.1) nothing changes; afterwards the runs differ at rounding-of-dt level.
+    fixed = frontend.run_model(make_newcastle(tmp_path / "b", duration=90, frequency=30), make_sim=_oracle_sim, batch=7)
+    for (ta, a), (tb, b) in zip(outs[:2], fixed[:2]):
+        assert ta == tb and all(np.array_equal(a[k], b[k]) for k in a)
+    assert outs[2][0] == fixed[2][0] == 90.0 and np.abs(outs[2][1]["fsl"] - fixed[2][1]["fsl"]).max() < 1e-4
+    again = frontend.run_model(make_newcastle(tmp_path / "c", duration=90, frequency=30), make_sim=_oracle_sim, batch=100)
+    assert all(np.array_equal(fixed[2][1][k], again[2][1][k]) for k in fixed[2][1])
+
+
+def test_orchestrator_matches_a_plain_run_to_the_same_sync_points(tmp_path):
+    """Same state as driving the engine by hand: set the target, step until it is reached, move the target."""
+    from hipims_mi.model import Model
+    xml = make_newcastle(tmp_path, duration=40, frequency=20)
+    m = Model(xml, make_sim=_oracle_sim, clock=_Clock(0.05))
+    m.run()
+    cfg = frontend.parse_configuration(xml)
+    st, bed, man, res = frontend.build_domain(cfg)
+    sim = _oracle_sim(cfg, 342, 195, res)
+    sim.upload(st, bed, man)
+    frontend.attach_boundaries(cfg, sim, 342)
+    for target in (20.0, 40.0):
+        sim.set_target(target)
+        if sim.scalars()["dt"] <= 0:
+            sim.update_timestep()
+        while target - sim.scalars()["t"] > 1e-5:
+            sim.run(5)
+    assert np.array_equal(m.sim.download(), sim.download())
+
+
+def test_cli_fails_loudly_without_a_gpu(tmp_path):
+    """`python -m hipims_mi -c ...` is the product path: no CPU fallback, a clear error instead."""
+    import subprocess, sys
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import pytest
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    xml = make_newcastle(tmp_path, duration=10, frequency=10)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(os.path.dirname(os.path.dirname(__file__)), "hipims-ocl_amd"),
+                                                        os.environ.get("PYTHONPATH", "")]), HIPIMS_MI_NO_TORCH="1")
+    r = subprocess.run([sys.executable, "-m", "hipims_mi", "-c", xml, "-s"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and ("no usable HIP device" in r.stderr or "HP_ERR" in r.stderr or "hip" in r.stderr.lower())

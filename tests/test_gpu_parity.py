@@ -435,3 +435,25 @@ def test_inertial_full_size_4096_properties():
     for z in outs:
         assert abs(np.maximum(0, z - bed).sum() - d0) / d0 < 1e-12
     assert np.abs(outs[0] - outs[1]).max() < 1e-9
+
+
+def test_cli_runs_the_example(tmp_path):
+    """`python -m hipims_mi -c model.xml` (the reference's own command line, main.cpp:464-567) on the example."""
+    import subprocess, sys
+    from model_dir import make_newcastle
+    xml = make_newcastle(tmp_path, duration=60, frequency=30)
+    log = os.path.join(str(tmp_path), "run.log")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hipims-ocl_amd"),
+                                                        os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, "-m", "hipims_mi", "-c", xml, "-l", log, "--batch", "50"], capture_output=True,
+                       text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Simulation complete: 2 output times" in r.stdout and "SIMULATION PROGRESS" in open(log).read()
+    files = sorted(os.listdir(os.path.join(str(tmp_path), "output")))
+    assert "depth_30.asc" in files and "depth_60.asc" in files
+    # same rasters as the library call with the same fixed batch
+    from hipims_mi import frontend
+    res = frontend.run_model(make_newcastle(tmp_path / "b", duration=60, frequency=30), batch=50, output_format=None)
+    asc = np.loadtxt(os.path.join(str(tmp_path), "output", "depth_60.asc"), skiprows=6)[::-1]
+    ref = res[-1][1]["depth"]
+    assert np.allclose(asc, ref, rtol=1e-9, atol=1e-12)
