@@ -104,6 +104,12 @@ __device__ __forceinline__ float rcbrt_fast(float x)
 	return __builtin_fmaf(y * (1.0f / 3.0f), e, y);
 }
 
+// a*b + c: two roundings in STRICT (what the reference computes without -cl-mad-enable), one FMA in FAST
+template <bool STRICT, typename T> __device__ __forceinline__ T mad(const T a, const T b, const T c)
+{
+	return STRICT ? (a * b + c) : fma_(a, b, c);
+}
+
 // One side of a face as the cell owner prepares it: raw state + the cell-centre velocities of
 // reconstructInterface (CLSchemeGodunov.clc:39-61): u0 = (Z - zb < VERY_SMALL) ? 0 : Qx / (Z - zb).
 template <typename T> struct Side { T eta, zb, qx, qy, u0, v0; };
@@ -489,14 +495,14 @@ __device__ __forceinline__ Face4<T> limiter(const Raw<T>& l, const Raw<T>& c, co
 }
 
 // faceExtrapolate (CLSchemeMUSCLHancock.clc:389-403); `c.h` is unused: H is rebuilt from Z - zb
-template <typename T>
+template <bool STRICT, typename T>
 __device__ __forceinline__ Face4<T> face_extrapolate(const T zb, const Face4<T>& c, const Face4<T>& slope, const T coef)
 {
 	Face4<T> f;
-	f.z = c.z + coef * slope.z;
-	f.h = (c.z - zb) + coef * slope.h;
-	f.qx = c.qx + coef * slope.qx;
-	f.qy = c.qy + coef * slope.qy;
+	f.z = mad<STRICT>(coef, slope.z, c.z);
+	f.h = mad<STRICT>(coef, slope.h, c.z - zb);
+	f.qx = mad<STRICT>(coef, slope.qx, c.qx);
+	f.qy = mad<STRICT>(coef, slope.qy, c.qy);
 	return f;
 }
 
@@ -513,19 +519,22 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 	if (first) return f;
 
 	const Face4<T> sx = limiter<STRICT>(w, c, e, vs), sy = limiter<STRICT>(s, c, n, vs);   // :343-346
-	f.n = face_extrapolate(c.zb, cc, sy, T(+0.5));                                         // :349-352
-	f.e = face_extrapolate(c.zb, cc, sx, T(+0.5));
-	f.s = face_extrapolate(c.zb, cc, sy, T(-0.5));
-	f.w = face_extrapolate(c.zb, cc, sx, T(-0.5));
+	f.n = face_extrapolate<STRICT>(c.zb, cc, sy, T(+0.5));                                         // :349-352
+	f.e = face_extrapolate<STRICT>(c.zb, cc, sx, T(+0.5));
+	f.s = face_extrapolate<STRICT>(c.zb, cc, sy, T(-0.5));
+	f.w = face_extrapolate<STRICT>(c.zb, cc, sx, T(-0.5));
 
 	// estimateFluxVectorX / Y (:420-471): FSL form with zb = Z - H
-	auto press = [&](const Face4<T>& a) { return T(0.5) * g * ((a.z * a.z) - 2 * (a.z - a.h) * a.z); };
+	auto press = [&](const Face4<T>& a) {
+		return STRICT ? T(0.5) * g * ((a.z * a.z) - 2 * (a.z - a.h) * a.z)
+		              : (T(0.5) * g) * (a.z * fma_(T(2), a.h, -a.z));              // z^2 - 2 (z - h) z = z (2h - z)
+	};
 	auto vel = [&](const T q, const T h) { return STRICT ? (h < vs ? T(0) : q / h) : (h < vs ? T(0) : q * rcp_fast(h)); };
 	const T uE = vel(f.e.qx, f.e.h), uW = vel(f.w.qx, f.w.h), vN = vel(f.n.qy, f.n.h), vS = vel(f.s.qy, f.s.h);
-	const T FE0 = f.e.qx, FE1 = uE * f.e.qx + press(f.e), FE2 = uE * f.e.qy;
-	const T FW0 = f.w.qx, FW1 = uW * f.w.qx + press(f.w), FW2 = uW * f.w.qy;
-	const T FN0 = f.n.qy, FN1 = vN * f.n.qx, FN2 = vN * f.n.qy + press(f.n);
-	const T FS0 = f.s.qy, FS1 = vS * f.s.qx, FS2 = vS * f.s.qy + press(f.s);
+	const T FE0 = f.e.qx, FE1 = mad<STRICT>(uE, f.e.qx, press(f.e)), FE2 = uE * f.e.qy;
+	const T FW0 = f.w.qx, FW1 = mad<STRICT>(uW, f.w.qx, press(f.w)), FW2 = uW * f.w.qy;
+	const T FN0 = f.n.qy, FN1 = vN * f.n.qx, FN2 = mad<STRICT>(vN, f.n.qy, press(f.n));
+	const T FS0 = f.s.qy, FS1 = vS * f.s.qx, FS2 = mad<STRICT>(vS, f.s.qy, press(f.s));
 
 	// evolveCellState (:476-526)
 	T d0, d2, d3;
@@ -546,14 +555,19 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 	d0 = small_to_zero<STRICT>(d0, vs);
 	d2 = small_to_zero<STRICT>(d2, vs);
 	d3 = small_to_zero<STRICT>(d3, vs);
-	cc.z  = cc.z  - T(0.5) * dt * d0;
-	cc.qx = cc.qx - T(0.5) * dt * d2;
-	cc.qy = cc.qy - T(0.5) * dt * d3;
+	if (STRICT) {
+		cc.z  = cc.z  - T(0.5) * dt * d0;
+		cc.qx = cc.qx - T(0.5) * dt * d2;
+		cc.qy = cc.qy - T(0.5) * dt * d3;
+	} else {
+		const T mh = T(-0.5) * dt;
+		cc.z = fma_(mh, d0, cc.z); cc.qx = fma_(mh, d2, cc.qx); cc.qy = fma_(mh, d3, cc.qy);
+	}
 
-	f.n = face_extrapolate(c.zb, cc, sy, T(+0.5));                                         // :376-379
-	f.e = face_extrapolate(c.zb, cc, sx, T(+0.5));
-	f.s = face_extrapolate(c.zb, cc, sy, T(-0.5));
-	f.w = face_extrapolate(c.zb, cc, sx, T(-0.5));
+	f.n = face_extrapolate<STRICT>(c.zb, cc, sy, T(+0.5));                                         // :376-379
+	f.e = face_extrapolate<STRICT>(c.zb, cc, sx, T(+0.5));
+	f.s = face_extrapolate<STRICT>(c.zb, cc, sy, T(-0.5));
+	f.w = face_extrapolate<STRICT>(c.zb, cc, sx, T(-0.5));
 	return f;
 }
 
