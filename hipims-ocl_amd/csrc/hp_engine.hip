@@ -6,6 +6,7 @@
 #include "../../include/hipims_mi.h"
 #include "hp_kernels.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -498,6 +499,16 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	if (const char* e = std::getenv("HP_MUSCL_RSEG")) {
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 4096) d->muscl_rseg = v;
+	}
+
+	{
+		// a wavefront addresses its tile through a buffer resource whose range field is 31 bits wide: the tile's rows
+		// (segment + halo rows) must fit in it
+		const int rseg_max = std::max(d->march_rseg, std::max(d->muscl_rseg, d->inertial_rseg));
+		if ((double)(rseg_max + 4) * (double)desc->cols * 4.0 * (double)desc->precision >= 2147483647.0) {
+			delete d;
+			return fail(HP_ERR_UNSUPPORTED, "grid too wide for the tile addressing (cols * 32 B * (rows per tile + 4) >= 2 GiB)");
+		}
 	}
 
 	auto cleanup = [&](int code) { hp_domain_destroy(d); return code; };
