@@ -66,19 +66,8 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(cols, precision, scheme, levels=(10.0, 1.0), budget_s=12.0):
-    """Plain-C oracle (kind "port"), OpenMP over rows on all host cores, on a bounded strip of the same workload."""
-    import oracle
-    from hipims_mi import synthetic as syn
-    cores = usable_cores()
-    rows = 512
-    real = np.float64 if precision == "f64" else np.float32
-    st, bed, man = syn.s_dam(cols, rows, dtype=real, levels=levels)
-    sim = oracle.OracleSim(cols, rows, precision=precision, scheme=scheme, threads=cores,
-                           quirks=oracle.QUIRKS_REFERENCE & ~oracle.Q6_MUSCL_SERIAL)
-    sim.upload(st, bed, man)
-    sim.set_target(1e9)
-    sim.run(2)
+def _time_cpu(sim, cells, budget_s):
+    sim.run(4)                                   # thread pool up, first-touch done
     steps, t0 = 0, time.perf_counter()
     while True:
         sim.run(2)
@@ -86,8 +75,43 @@ def cpu_baseline(cols, precision, scheme, levels=(10.0, 1.0), budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or steps >= 400:
             break
-    return {"value": cols * rows * steps / el / 1e6, "unit": "Mcell-steps/s", "cores": cores, "kind": "port",
-            "sample": f"S-DAM {cols}x{rows} strip, {steps} steps, {el:.1f} s, oracle/swe_oracle.c OpenMP x{cores}"}
+    return cells * steps / el / 1e6, steps, el
+
+
+def cpu_baseline(cols, precision, scheme, levels=(10.0, 1.0), budget_s=8.0):
+    """CPU legs on a bounded strip of the same workload, on the cores the cgroup really grants:
+    kind "reference" = the reference's OWN kernel sources (gts_cacheDisabled / ine_cacheDisabled + tst_Reduce +
+    tst_Advance_Normal) compiled for the host (oracle/_ref, built where /root/reference exists and shipped as .so),
+    work-items spread over the cores by rows as a CPU OpenCL runtime would; kind "port" = the plain-C restatement
+    (oracle/swe_oracle.c, OpenMP over rows).  The reference leg is reported when its library is present (the MUSCL
+    corrector is in-place and order dependent, so that scheme only has the port leg); the other leg rides along."""
+    import oracle
+    from hipims_mi import synthetic as syn
+    cores = usable_cores()
+    rows = 512
+    real = np.float64 if precision == "f64" else np.float32
+    st, bed, man = syn.s_dam(cols, rows, dtype=real, levels=levels)
+    legs = {}
+    sim = oracle.OracleSim(cols, rows, precision=precision, scheme=scheme, threads=cores,
+                           quirks=oracle.QUIRKS_REFERENCE & ~oracle.Q6_MUSCL_SERIAL)
+    sim.upload(st, bed, man)
+    sim.set_target(1e9)
+    legs["port"] = _time_cpu(sim, cols * rows, budget_s)
+    stem = {oracle.GODUNOV: "god_", oracle.INERTIAL: "ine_"}.get(scheme)
+    if stem and oracle.have_ref(stem + precision):
+        ref = oracle.RefSim(cols, rows, precision=precision, scheme=scheme, threads=cores)
+        ref.upload(st, bed, man)
+        ref.set_target(1e9)
+        legs["reference"] = _time_cpu(ref, cols * rows, budget_s)
+    kind = "reference" if "reference" in legs else "port"
+    value, steps, el = legs[kind]
+    what = ("the reference's kernel sources compiled for the host (oracle/_ref), rows over %d threads" % cores
+            if kind == "reference" else "oracle/swe_oracle.c OpenMP x%d" % cores)
+    out = {"value": value, "unit": "Mcell-steps/s", "cores": cores, "kind": kind,
+           "sample": f"S-DAM {cols}x{rows} strip, {steps} steps, {el:.1f} s, {what}"}
+    if kind == "reference":
+        out["port_value"] = legs["port"][0]
+    return out
 
 
 def main():

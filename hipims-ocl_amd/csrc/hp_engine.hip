@@ -225,8 +225,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	                                 part, empty);
 	if (empty) return HP_OK;
 	const unsigned blocks = (unsigned)((tm.ntiles + 7) / 8) * 8;
-	static const int dbg_lds = std::getenv("HP_DEBUG_LDS") ? std::atoi(std::getenv("HP_DEBUG_LDS")) : 0;   // occupancy experiments
-	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), dbg_lds, stream, p,
+	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
 	HIP_TRY(hipGetLastError());

@@ -403,6 +403,8 @@ class RefSim(_SimBase):
     def _configure(self):
         self.lib.ref_configure(self.cols, self.rows, self.dx, self.very_small, self.courant, self.end_time,
                                self.WORKERS, self.fixed_dt)
+        if hasattr(self.lib, "ref_set_threads"):
+            self.lib.ref_set_threads(int(self.threads))            # rows of independent work-items over host threads
 
     def upload(self, state=None, bed=None, manning=None):
         if state is not None:

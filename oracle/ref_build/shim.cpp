@@ -9,8 +9,11 @@
  *     (get_global_id ..., sqrt, pow, fmax ...) -- each is the obvious one-liner over libm;
  *  2. the run-time parameter variables that prelude.cl declares (the reference bakes the same
  *     values in as #defines, CSchemeGodunov.cpp:666-784);
- *  3. drivers that walk an NDRange serially (x fastest, then y) and call the kernel once per
- *     work-item.  The launch geometry of each driver follows the reference's host code, cited
+ *  3. drivers that walk an NDRange (x fastest, then y) and call the kernel once per work-item:
+ *     serially by default; the kernels whose work-items are independent can be spread over host
+ *     threads by rows (ref_set_threads) the way a CPU OpenCL runtime spreads work-groups over cores --
+ *     bench.py's cpu_baseline uses that.  The in-place MUSCL corrector and the boundary kernels stay
+ *     serial (their result depends on the order).  The launch geometry of each driver follows the reference's host code, cited
  *     per function.  No arithmetic of the scheme is restated here.
  *
  * Built three times per precision: -DREF_GODUNOV (Godunov program) / -DREF_MUSCL (MUSCL program) /
@@ -101,6 +104,9 @@ void mch_2nd_cacheNone(const real* dt, real* state, const real* bed, const real*
 // ---------------------------------------------------------------------------------------------
 int ref_real_bytes(void) { return (int)sizeof(real); }
 
+static int g_threads = 1;
+void ref_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
 /* CSchemeGodunov.cpp:666-784 -- the constants every kernel is compiled against.
  * `workers` = TIMESTEP_WORKERS = reduction GLOBAL size (CSchemeGodunov.cpp:764, quirk Q5). */
 void ref_configure(long cols, long rows, double dx, double very_small, double courant,
@@ -127,6 +133,7 @@ static inline void set_item_2d(size_t x, size_t y, size_t gx, size_t gy)
  * work-items beyond the grid return at the bounds guard, so cols x rows is equivalent. */
 void ref_gts(const real* dt, const real* bed, real* src, real* dst, const real* manning)
 {
+	#pragma omp parallel for schedule(static) num_threads(g_threads)
 	for (long y = 0; y < REFP_ROWS; ++y)
 		for (long x = 0; x < REFP_COLS; ++x) {
 			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
@@ -139,6 +146,7 @@ void ref_gts(const real* dt, const real* bed, real* src, real* dst, const real* 
 /* same launch geometry as the Godunov kernel: CSchemeInertial.cpp:269-271 reuses prepare1OExecDimensions */
 void ref_ine(const real* dt, const real* bed, real* src, real* dst, const real* manning)
 {
+	#pragma omp parallel for schedule(static) num_threads(g_threads)
 	for (long y = 0; y < REFP_ROWS; ++y)
 		for (long x = 0; x < REFP_COLS; ++x) {
 			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
@@ -150,6 +158,7 @@ void ref_ine(const real* dt, const real* bed, real* src, real* dst, const real* 
 #ifdef REF_MUSCL
 void ref_mch_1st(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW)
 {
+	#pragma omp parallel for schedule(static) num_threads(g_threads)
 	for (long y = 0; y < REFP_ROWS; ++y)
 		for (long x = 0; x < REFP_COLS; ++x) {
 			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
@@ -171,6 +180,7 @@ void ref_mch_2nd(const real* dt, real* state, const real* bed, const real* manni
 /* 1-D, global size = TIMESTEP_WORKERS, group size 1 here (prelude.cl) so group id == global id. */
 void ref_reduce(real* state, const real* bed, real* scratch)
 {
+	#pragma omp parallel for schedule(static) num_threads(g_threads)
 	for (size_t g = 0; g < (size_t)REFP_WORKERS; ++g) {
 		t_gid[0] = g; t_grp[0] = g; t_lid[0] = 0; t_lsz[0] = 1; t_gsz[0] = REFP_WORKERS;
 		t_gid[1] = t_gid[2] = 0;
