@@ -156,8 +156,11 @@ def main():
                         device=local_rank)
     else:
         from hipims_mi.strips import StripRunner as Runner
+        # HIPIMS_MI_BACKEND=gloo: rehearsal of this branch with several processes on one GPU (host-staged exchange)
+        backend = os.environ.get("HIPIMS_MI_BACKEND", "nccl")
+        device = local_rank if backend == "nccl" else local_rank % max(1, hp.device_count())
         runner = Runner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
-                        device=local_rank, rank=rank, world=world)
+                        device=device, rank=rank, world=world, backend=backend)
 
     if args.workload == "s-rain":
         st, bed, man, rain = syn.s_rain_rows(cols, rows, runner.local_lo, runner.local_hi, dx=dx, dtype=real)
@@ -197,7 +200,8 @@ def main():
                                    f"{cols}x{rows}{'' if levels[0] == 10.0 else ' (levels %g|%g m)' % levels}, "
                                    f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
-                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}",
+                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
+                                                                else " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"),
                        "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -18,6 +18,9 @@ segments are still being computed on the domain's stream, which waits for it jus
 
 The exchange is written against torch.distributed so that the very same code runs over RCCL ("nccl") on GPUs and
 over "gloo" on CPU tensors in the world_size-2 tests (tests/test_strips_gloo.py, with the oracle as engine).
+Rehearsal transport: `backend="gloo"` together with the HIP engine stages the ghost rows and the scalar through
+host memory.  It exists so that the whole multi-rank path (partition, strip inputs, bench.py's N > 1 branch) can be
+run with several processes on ONE GPU, where RCCL refuses to put two ranks; it is not a production path.
 """
 from __future__ import annotations
 
@@ -178,6 +181,7 @@ class StripRunner:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
         self.south = rank - 1 if rank > 0 else None
         self.north = rank + 1 if rank < world - 1 else None
+        self.staged = engine_factory is None and backend == "gloo"      # device buffers, host transport (rehearsal)
         self._halo_ops = {}
         if overlap is None:
             overlap = world > 1
@@ -216,6 +220,8 @@ class StripRunner:
         """Queue the ghost-row exchange of the iteration in flight; returns the requests to wait for."""
         dist, g = self.dist, self.g
         new = self.engine.new_state()            # [local_rows, cols, 4]
+        if self.staged:
+            return self._start_halo_staged(new)
         ops = self._halo_ops.get(new.data_ptr())  # the two ping-pong buffers alternate: build each list once
         if ops is None:
             n = new.shape[0]
@@ -233,6 +239,35 @@ class StripRunner:
         with ctx:
             return dist.batch_isend_irecv(ops)
 
+    def _start_halo_staged(self, new):
+        """Rehearsal transport: rows go device -> host -> gloo -> host -> device."""
+        dist, g, n = self.dist, self.g, new.shape[0]
+        ops, landings = [], []
+        with self.engine.halo_context():                      # .cpu() waits for the halo segments only
+            for peer, send, recv in ((self.south, new[g:2 * g], new[0:g]), (self.north, new[n - 2 * g:n - g], new[n - g:n])):
+                if peer is None:
+                    continue
+                buf = self.torch.empty(recv.shape, dtype=recv.dtype)
+                ops += [dist.P2POp(dist.isend, send.cpu(), peer), dist.P2POp(dist.irecv, buf, peer)]
+                landings.append((recv, buf))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+
+        class _Landing:
+            def wait(_self):
+                for r in reqs:
+                    r.wait()
+                for recv, buf in landings:
+                    recv.copy_(buf)                           # on the domain stream, before step_end
+        return [_Landing()] if ops else []
+
+    def _all_reduce_max(self, slot):
+        if self.staged:
+            host = slot.cpu()                                 # waits for the whole flux launch
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.MAX)
+            slot.copy_(host)
+        else:
+            self.dist.all_reduce(slot, op=self.dist.ReduceOp.MAX)
+
     def _exchange_halo(self):
         for req in self._start_halo():
             req.wait()
@@ -245,7 +280,7 @@ class StripRunner:
             # the scalar is new only when the reduction priced a buffer that changed (every iteration without
             # quirk Q1, every other one with it); the decision is identical on all ranks (same iteration parity)
             if self.world > 1 and self.engine.needs_reduction():
-                dist.all_reduce(self.engine.cfl_slot(), op=dist.ReduceOp.MAX)
+                self._all_reduce_max(self.engine.cfl_slot())
             for req in halo:
                 req.wait()                             # domain stream (or the host, with gloo) waits for the rows
             self.engine.step_end()
@@ -259,7 +294,7 @@ class StripRunner:
     def max_over_ranks(self, x):
         if self.world == 1:
             return x
-        dev = getattr(self.engine, "device", "cpu")
+        dev = "cpu" if self.staged else getattr(self.engine, "device", "cpu")
         t = self.torch.tensor([x], dtype=self.torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
