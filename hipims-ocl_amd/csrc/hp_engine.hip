@@ -487,6 +487,21 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	d->own_hi = d->desc.rows - ((d->desc.row_offset + d->desc.rows < d->desc.global_rows) ? g : 0);
 	d->cells = (size_t)desc->cols * (size_t)desc->rows;
 	d->esize = (size_t)desc->precision;
+	// Tile height: a wavefront marches its tile's rows one after the other, so a grid that yields few tiles is bound
+	// by that serial walk, not by bandwidth (342 x 195: 35 us per step at 16 rows, 12 us at 2).  Take the tallest
+	// tile that still gives every CU some blocks (tools/small_grid_probe.py: 4096^2 and 2048^2 want 16, 1024^2 8,
+	// 512^2 4, the 342 x 195 example 2).
+	{
+		auto pick = [&](long updated_rows, long updated_cols, int tile_cols, int tallest, int shortest) {
+			const long groups = ((updated_cols + tile_cols - 1) / tile_cols + 3) / 4;
+			int rseg = tallest;
+			while (rseg > shortest && groups * ((updated_rows + rseg - 1) / rseg) < 350) rseg /= 2;
+			return rseg;
+		};
+		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, 16, 2);
+		d->inertial_rseg = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, 32, 2);
+		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 32, 4);
+	}
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 64) d->march_rseg = v;
