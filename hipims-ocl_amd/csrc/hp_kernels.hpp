@@ -79,7 +79,10 @@ __device__ __forceinline__ void advance_body(const Params<T>& p, Scalars<T>* sc,
 	T t = sc->t, t_sync = sc->t_sync, batch = sc->batch_dt;
 	if (UPDATE_ONLY) {
 		const T dt_orig = fabs_(sc->dt);                                          // :264
-		T dt = T(0);
+		// TIMESTEP_FIXED leaves the reference's dLclTimestep UNINITIALISED here (:268, :269-292 compiled out) before
+		// fmin(dLclTimestep, original); its host build yields the original value (what any garbage >= original, or a
+		// NaN, gives through fmin) -- restated as that
+		T dt = dt_orig;
 		if (p.dynamic_dt) {
 			T tmin = p.dx / vmax;
 			if (t < START_DURATION && tmin < START_MIN) tmin = START_MIN;

@@ -382,8 +382,10 @@ class RefSim(_SimBase):
     def __init__(self, *a, mad=False, **k):
         super().__init__(*a, **k)
         assert self.friction, "reference builds are compiled with FRICTION_ENABLED"
-        assert self.dynamic_dt, "reference builds are compiled with TIMESTEP_DYNAMIC"
         stem = {GODUNOV: "god_", MUSCL: "mch_", INERTIAL: "ine_"}[self.scheme] + self.precision + ("_mad" if mad else "")
+        if not self.dynamic_dt:                      # the TIMESTEP_FIXED program exists for Godunov fp64 only
+            assert stem == "god_f64", "fixed-timestep reference build: Godunov fp64 only"
+            stem += "_fixed"
         self.lib = _load_ref(stem)
         n = self.rows * self.cols
         self.primary = _aligned_zeros((self.rows, self.cols, 4), self.real)
@@ -464,7 +466,8 @@ class RefSim(_SimBase):
 
     def update_timestep(self):
         self._configure()
-        self.lib.ref_reduce(_ptr(self.primary), _ptr(self.bed), _ptr(self.scratch))
+        if self.dynamic_dt:
+            self.lib.ref_reduce(_ptr(self.primary), _ptr(self.bed), _ptr(self.scratch))
         self.lib.ref_update_timestep(_ptr(self.t), _ptr(self.dt), _ptr(self.scratch), _ptr(self.t_sync), _ptr(self.batch_dt))
 
     def _apply_boundaries(self, target):
@@ -480,7 +483,8 @@ class RefSim(_SimBase):
                _ptr(self.bed), _ptr(self.manning), C.c_int(full))
 
     def _reduce_advance(self, reduce_buf):
-        self.lib.ref_reduce(_ptr(reduce_buf), _ptr(self.bed), _ptr(self.scratch))
+        if self.dynamic_dt:                          # CSchemeGodunov.cpp:1653-1657
+            self.lib.ref_reduce(_ptr(reduce_buf), _ptr(self.bed), _ptr(self.scratch))
         self.lib.ref_advance(_ptr(self.t), _ptr(self.dt), _ptr(self.t_hydro), _ptr(self.scratch),
                              _ptr(self.primary), _ptr(self.bed), _ptr(self.t_sync), _ptr(self.batch_dt),
                              _ptr(self.ok), _ptr(self.skipped))

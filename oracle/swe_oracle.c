@@ -808,7 +808,10 @@ void orc_update_timestep(const orc_params* p, orc_scalars* s, real dMaxSpeed)
 	real dLclOriginalTimestep = R_FABS(s->dt);                        /* :264 */
 	real dLclSyncTime = s->t_sync;
 	real dLclBatchTimesteps = s->batch_dt;
-	real dLclTimestep = RC(0.0);
+	/* :268 declares dLclTimestep WITHOUT a value; with TIMESTEP_FIXED nothing assigns it before the fmin at :297
+	 * (undefined behaviour in the reference).  The reference's host build (oracle/_ref, -DREF_FIXED_DT) returns the
+	 * original timestep there -- what fmin gives for any garbage >= original or a NaN -- so that is what is restated. */
+	real dLclTimestep = dLclOriginalTimestep;
 
 	if (p->dynamic_dt) {                                              /* :269-292 */
 		real dMinTime = p->dx / dMaxSpeed;

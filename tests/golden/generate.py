@@ -341,6 +341,31 @@ def inertial(precision, tag, mad=False):
     save(f"f12_inertial_{tag}", **out)
 
 
+def fixed_timestep(tag="f64"):
+    """F13: the TIMESTEP_FIXED program (CSchemeGodunov.cpp:735-755, CLDynamicTimestep.clc:92-96): no reduction kernel,
+    dt = the configured value, still subject to the sync clip, the early limit (0.1 s before t = 60 s) and the end time."""
+    out = {}
+    st, bed, man = syn.s_rough(64, 64, manning=None)
+    out.update(state=st, bed=bed, manning=man)
+    for name, dt, target, end in (("small", 0.02, 2.5, 1e30), ("clipped", 0.25, 1e9, 11.0)):
+        sim = oracle.RefSim(64, 64, dynamic_dt=False, fixed_dt=dt, dt_initial=dt, end_time=end)
+        sim.upload(st, bed, man)
+        sim.set_target(target)
+        out[f"{name}_dt"] = sim.run(160)
+        out[f"{name}_state"] = sim.download()
+        sc = sim.scalars()
+        out[f"{name}_t"] = np.array(sc["t"]); out[f"{name}_ok"] = np.array(sc["batch_ok"]); out[f"{name}_skipped"] = np.array(sc["batch_skipped"])
+        if name == "small":
+            # resume after the sync point: new target -> tst_UpdateTimestep (whose dLclTimestep is uninitialised in this
+            # program, CLDynamicTimestep.clc:268/:297: the host build returns |dt|)
+            sim.set_target(4.0)
+            sim.update_timestep()
+            out["resume_dt"] = sim.run(100)
+            out["resume_state"] = sim.download()
+            out["resume_t"] = np.array(sim.scalars()["t"])
+    save(f"f13_fixed_timestep_{tag}", **out)
+
+
 JOBS = [
     ("f1", lambda: [function_level(p, p) for p in ("f64", "f32")]),      # f1..f5
     ("f6", lambda: [trajectories(p, p) for p in ("f64", "f32")] + [trajectories("f64", "f64_mad", mad=True)]),
@@ -348,6 +373,7 @@ JOBS = [
     ("f9", lambda: [rain(p, p) for p in ("f64", "f32")]),
     ("f11", lambda: [cell_boundary(p, p) for p in ("f64", "f32")]),
     ("f10", lambda: [newcastle("f64", "f64"), newcastle("f64", "f64_mad", mad=True)]),
+    ("f13", fixed_timestep),
     ("f12", lambda: [inertial(p, p) for p in ("f64", "f32")] + [inertial("f64", "f64_mad", mad=True)]),
 ]
 

@@ -457,3 +457,26 @@ def test_cli_runs_the_example(tmp_path):
     asc = np.loadtxt(os.path.join(str(tmp_path), "output", "depth_60.asc"), skiprows=6)[::-1]
     ref = res[-1][1]["depth"]
     assert np.allclose(asc, ref, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_fixed_timestep_fixture(mode):
+    """desc.dynamic_dt = 0: no CFL reduction, dt = dt_fixed under the sync / early-limit / end-time clips (fixture from
+    the reference's TIMESTEP_FIXED program)."""
+    g = load_golden("f13_fixed_timestep_f64")
+    for name, dt, target, end in (("small", 0.02, 2.5, 1e30), ("clipped", 0.25, 1e9, 11.0)):
+        dom = hp.Domain(64, 64, dynamic_dt=False, dt_fixed=dt, dt_initial=dt, t_end=end, math_mode=mode)
+        dom.upload(g["state"], g["bed"], g["manning"])
+        dom.set_target_time(target)
+        tr = dom.run(160)
+        assert np.array_equal(tr, g[f"{name}_dt"])                       # no arithmetic on the way to dt: exact in both modes
+        sc = dom.read_scalars()
+        assert sc["time"] == float(g[f"{name}_t"]) and sc["batch_skipped"] == int(g[f"{name}_skipped"])
+        dg = np.maximum(0, dom.download()[..., 0] - g["bed"]); dr = np.maximum(0, g[f"{name}_state"][..., 0] - g["bed"])
+        assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
+        if name == "small":
+            dom.set_target_time(4.0)
+            dom.update_timestep()
+            assert np.array_equal(dom.run(100), g["resume_dt"]) and dom.read_scalars()["time"] == 4.0
+            assert np.abs(dom.download()[..., 0] - g["resume_state"][..., 0]).max() < 1e-7
+        dom.close()

@@ -280,3 +280,22 @@ def test_inertial_sync_point_and_rain(precision):
     assert same(sim.run(260), g["rain_dt"])
     assert same(sim.download(), g["rain_state"])
     assert (g["rain_state"][..., 0] - g["rain_bed"]).max() > 1e-5          # it rained
+
+
+def test_fixed_timestep_program():
+    """TIMESTEP_FIXED: dt is the configured value, but still clipped by the sync time, the early limit and the end time."""
+    g = load_golden("f13_fixed_timestep_f64")
+    for name, dt, target, end in (("small", 0.02, 2.5, 1e30), ("clipped", 0.25, 1e9, 11.0)):
+        sim = oracle.OracleSim(64, 64, dynamic_dt=False, fixed_dt=dt, dt_initial=dt, end_time=end)
+        sim.upload(g["state"], g["bed"], g["manning"])
+        sim.set_target(target)
+        assert same(sim.run(160), g[f"{name}_dt"])
+        assert same(sim.download(), g[f"{name}_state"])
+        sc = sim.scalars()
+        assert (sc["t"], sc["batch_ok"], sc["batch_skipped"]) == (g[f"{name}_t"], g[f"{name}_ok"], g[f"{name}_skipped"])
+        if name == "small":
+            sim.set_target(4.0)
+            sim.update_timestep()
+            assert same(sim.run(100), g["resume_dt"]) and same(sim.download(), g["resume_state"])
+            assert sim.scalars()["t"] == g["resume_t"] == 4.0 and g["resume_dt"][0] == 0.02
+    assert g["clipped_dt"][0] == 0.25 and g["clipped_dt"][1] == 0.1 and g["clipped_dt"][-1] == 0.0 and g["clipped_t"] == 11.0

@@ -67,3 +67,22 @@ def test_inertial_flux_random(precision):
                 bd + rng.choice([0, 1e-11, rng.uniform(0, 3)]), bd)
         a, b = of.inertial_flux(*args), rf.inertial_flux(*args)
         assert a == b or (np.isnan(a) and np.isnan(b)), args
+
+
+@pytest.mark.skipif(not oracle.have_ref("god_f64_fixed"), reason="fixed-timestep reference build missing")
+@pytest.mark.parametrize("dt", [0.01, 0.05, 0.3])
+def test_fixed_timestep_trajectory(dt):
+    st, bed, man = syn.s_rough(40, 33, seed=5, manning=None)
+    a = oracle.OracleSim(40, 33, dynamic_dt=False, fixed_dt=dt, dt_initial=dt, end_time=9.0)
+    b = oracle.RefSim(40, 33, dynamic_dt=False, fixed_dt=dt, dt_initial=dt, end_time=9.0)
+    for s in (a, b):
+        s.upload(st, bed, man)
+        s.set_target(4.0)
+    assert np.array_equal(a.run(90), b.run(90))
+    for s in (a, b):
+        s.set_target(20.0)
+        s.update_timestep()
+    assert np.array_equal(a.run(90), b.run(90))
+    assert np.array_equal(a.download(), b.download(), equal_nan=True)
+    sa, sb = a.scalars(), b.scalars()
+    assert sa == {k: (type(sa[k])(v)) for k, v in sb.items()}
