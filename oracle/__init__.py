@@ -381,8 +381,10 @@ class RefSim(_SimBase):
 
     def __init__(self, *a, mad=False, **k):
         super().__init__(*a, **k)
-        assert self.friction, "reference builds are compiled with FRICTION_ENABLED"
         stem = {GODUNOV: "god_", MUSCL: "mch_", INERTIAL: "ine_"}[self.scheme] + self.precision + ("_mad" if mad else "")
+        if not self.friction:                        # FRICTION_ENABLED undefined: Godunov / MUSCL fp64 builds exist
+            assert stem in ("god_f64", "mch_f64") and self.dynamic_dt, "no-friction reference build: fp64 Godunov/MUSCL"
+            stem += "_nofric"
         if not self.dynamic_dt:                      # the TIMESTEP_FIXED program exists for Godunov fp64 only
             assert stem == "god_f64", "fixed-timestep reference build: Godunov fp64 only"
             stem += "_fixed"

@@ -366,6 +366,22 @@ def fixed_timestep(tag="f64"):
     save(f"f13_fixed_timestep_{tag}", **out)
 
 
+def no_friction(tag="f64"):
+    """F14: frictionEffects="no" (FRICTION_ENABLED undefined): no transcendental on the path, so the STRICT HIP
+    kernels must reproduce these states bit for bit."""
+    out = {}
+    st, bed, man = syn.s_rough(72, 40, manning=None)
+    out.update(state=st, bed=bed, manning=man)
+    for scheme, name in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch")):
+        sim = oracle.RefSim(72, 40, scheme=scheme, friction=False)
+        sim.upload(st, bed, man)
+        sim.set_target(1e9)
+        out[f"{name}_dt"] = sim.run(120)
+        out[f"{name}_state"] = sim.download()
+        out[f"{name}_t"] = np.array(sim.scalars()["t"])
+    save(f"f14_no_friction_{tag}", **out)
+
+
 JOBS = [
     ("f1", lambda: [function_level(p, p) for p in ("f64", "f32")]),      # f1..f5
     ("f6", lambda: [trajectories(p, p) for p in ("f64", "f32")] + [trajectories("f64", "f64_mad", mad=True)]),
@@ -374,6 +390,7 @@ JOBS = [
     ("f11", lambda: [cell_boundary(p, p) for p in ("f64", "f32")]),
     ("f10", lambda: [newcastle("f64", "f64"), newcastle("f64", "f64_mad", mad=True)]),
     ("f13", fixed_timestep),
+    ("f14", no_friction),
     ("f12", lambda: [inertial(p, p) for p in ("f64", "f32")] + [inertial("f64", "f64_mad", mad=True)]),
 ]
 

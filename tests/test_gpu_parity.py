@@ -77,6 +77,10 @@ def test_strict_mode_is_bit_identical_without_friction(kernel):
     ref.run(120); dom.step_batch(120)
     assert np.array_equal(dom.download(), ref.download())
     assert dom.read_scalars()["time"] == ref.scalars()["t"]
+    # and bit for bit against what the reference's own no-friction program produced (fixture F14)
+    g = load_golden("f14_no_friction_f64")
+    assert np.array_equal(st, g["state"]) and np.array_equal(dom.download(), g["god_state"])
+    assert dom.read_scalars()["time"] == float(g["god_t"])
 
 
 @pytest.mark.parametrize("kernel", KERNELS)

@@ -299,3 +299,11 @@ def test_fixed_timestep_program():
             assert same(sim.run(100), g["resume_dt"]) and same(sim.download(), g["resume_state"])
             assert sim.scalars()["t"] == g["resume_t"] == 4.0 and g["resume_dt"][0] == 0.02
     assert g["clipped_dt"][0] == 0.25 and g["clipped_dt"][1] == 0.1 and g["clipped_dt"][-1] == 0.0 and g["clipped_t"] == 11.0
+
+
+def test_no_friction_program():
+    g = load_golden("f14_no_friction_f64")
+    for scheme, name in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch")):
+        sim = oracle.OracleSim(72, 40, scheme=scheme, friction=False)
+        assert same(_run(sim, g["state"], g["bed"], g["manning"], 120), g[f"{name}_dt"])
+        assert same(sim.download(), g[f"{name}_state"]) and sim.scalars()["t"] == g[f"{name}_t"]

@@ -86,3 +86,16 @@ def test_fixed_timestep_trajectory(dt):
     assert np.array_equal(a.download(), b.download(), equal_nan=True)
     sa, sb = a.scalars(), b.scalars()
     assert sa == {k: (type(sa[k])(v)) for k, v in sb.items()}
+
+
+@pytest.mark.skipif(not oracle.have_ref("god_f64_nofric"), reason="no-friction reference build missing")
+@pytest.mark.parametrize("scheme", [oracle.GODUNOV, oracle.MUSCL])
+def test_no_friction_trajectory(scheme):
+    st, bed, man = syn.s_rough(40, 33, seed=9, manning=None, walls=False)
+    a = oracle.OracleSim(40, 33, scheme=scheme, friction=False)
+    b = oracle.RefSim(40, 33, scheme=scheme, friction=False)
+    for s in (a, b):
+        s.upload(st, bed, man)
+        s.set_target(2.0)
+    assert np.array_equal(a.run(140), b.run(140))
+    assert np.array_equal(a.download(), b.download(), equal_nan=True)
