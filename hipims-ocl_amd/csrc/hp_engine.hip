@@ -62,6 +62,7 @@ struct hp_domain {
 	int              march_rseg = 16;                 // rows per wavefront tile of godunov_march
 	int              muscl_rseg = 32;                 // ... of muscl_march (two warm-up rows per tile)
 	int              inertial_rseg = 32;              // ... of inertial_march
+	int              tail_rseg = 8, tail_pct = 0;     // optional short tiles for the last tail_pct % of each XCD band (measured: no gain)
 	void*            host_scalars = nullptr;          // pinned mirror
 	int              use_alt = 0;                     // bUseAlternateKernel
 	bool             in_step = false;
@@ -166,49 +167,66 @@ template <typename T> int price_edge_ring(hp_domain* d)
 	return HP_OK;
 }
 
-// Which row segments of the domain one launch covers
+// Which rows of the domain one launch covers
 enum { PART_ALL = 0, PART_HALO = 1, PART_INTERIOR = 2 };
 
-// Split of the `nsegs` row segments for the halo overlap: the first `a` and last `b` segments hold the `g` owned
-// rows next to each ghost row block.  Returns false when there is nothing left for an interior launch.
-inline bool split_segments(long updated_rows, int rseg, int g, int nsegs, int& a, int& b)
-{
-	a = (g + rseg - 1) / rseg;
-	const long last_len = updated_rows - (long)(nsegs - 1) * rseg;      // rows in the (possibly partial) last segment
-	b = 1;
-	for (long have = last_len; have < g; have += rseg) ++b;
-	return nsegs > a + b;
-}
+// Row ranges of the three parts.  [lo, hi) are the updated rows of the domain; with the halo overlap the `halo` rows
+// next to each ghost block (one tile height, at least the g rows the neighbours need) form the halo part -- a south
+// and a north block, covered by ONE launch with two bands -- and the rest the interior part.  A domain too thin for
+// an interior part runs whole in the halo part.
+struct RowRange { long lo, hi; };
 
-inline TileMap make_tile_map(long updated_rows, int rseg, int g, int nstrips, int part, bool& empty)
+// TileMap of one launch (see hp_kernels.hpp): 8 XCD bands over [lo, hi), tall tiles first and optionally short tiles
+// for the last `tail_pct` percent of each band; or, for the halo part, the two blocks of `halo` rows as two bands.
+inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rseg, int rseg_tail, int tail_pct,
+                          TileMap& tm, unsigned& blocks)
 {
-	TileMap tm;
-	tm.rseg = rseg; tm.nstrips = nstrips;
+	static const long halo_env = std::getenv("HP_HALO_ROWS") ? std::atol(std::getenv("HP_HALO_ROWS")) : 0;
+	const long halo = halo_env >= g ? halo_env : (rseg > g ? rseg : g);
+	const bool can_split = hi - lo > 2 * halo;
+	tm.nstrips = nstrips;
 	tm.groups = (nstrips + 3) / 4;
-	const int nsegs = (int)((updated_rows + rseg - 1) / rseg);
-	int a = 0, b = 0;
-	const bool can_split = split_segments(updated_rows, rseg, g, nsegs, a, b);
-	int count = nsegs;
-	tm.seg_first = 0; tm.seg_gap_at = 0x7fffffff; tm.seg_gap = 0;
-	if (part == PART_HALO && can_split) { count = a + b; tm.seg_gap_at = a; tm.seg_gap = nsegs - a - b; }
-	else if (part == PART_INTERIOR) {
-		if (can_split) { count = nsegs - a - b; tm.seg_first = a; }
-		else count = 0;                                                 // the halo launch took everything
+	if (part == PART_HALO && can_split) {
+		tm.y_begin = lo; tm.y_end = hi;
+		tm.nbands = 2; tm.band_stride = (hi - halo) - lo; tm.band_rows = (int)halo;
+		tm.rseg = rseg < tm.band_rows ? rseg : tm.band_rows;
+		tm.nbig = (tm.band_rows + tm.rseg - 1) / tm.rseg;
+		tm.rseg_tail = rseg_tail; tm.ntail = 0;
+		blocks = 2u * (unsigned)(tm.groups * tm.nbig);
+		return true;
 	}
-	tm.ntiles = tm.groups * count;
-	empty = count == 0;
-	return tm;
+	if (part == PART_INTERIOR) {
+		if (!can_split) return false;                                   // the halo launch took everything
+		lo += halo; hi -= halo;
+	}
+	tm.y_begin = lo; tm.y_end = hi;
+	const long rows = hi - lo;
+	tm.nbands = 8;
+	tm.band_rows = (int)((rows + 7) / 8);
+	tm.band_stride = tm.band_rows;
+	tm.rseg = rseg < tm.band_rows ? rseg : tm.band_rows;
+	tm.rseg_tail = rseg_tail;
+	if (rseg_tail >= tm.rseg || tail_pct <= 0) {
+		tm.nbig = (tm.band_rows + tm.rseg - 1) / tm.rseg;
+		tm.ntail = 0;
+	} else {
+		const int tail_rows = (int)((long)tm.band_rows * tail_pct / 100);
+		tm.nbig = (tm.band_rows - tail_rows + tm.rseg - 1) / tm.rseg;
+		const int rest = tm.band_rows - tm.nbig * tm.rseg;
+		tm.ntail = rest > 0 ? (rest + rseg_tail - 1) / rseg_tail : 0;
+	}
+	blocks = 8u * (unsigned)(tm.groups * (tm.nbig + tm.ntail));
+	return true;
 }
 
 template <typename T, bool STRICT, int CFL_MODE>
 int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
 {
 	const Params<T> p = make_params<T>(d);
-	bool empty;
-	const TileMap tm = make_tile_map(p.rows - 4, d->muscl_rseg, 2, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS),
-	                                 part, empty);
-	if (empty) return HP_OK;
-	const unsigned blocks = (unsigned)((tm.ntiles + 7) / 8) * 8;
+	TileMap tm;
+	unsigned blocks;
+	if (!make_tile_map(2, p.rows - 2, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks))
+		return HP_OK;
 	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
@@ -220,11 +238,10 @@ template <typename T, bool STRICT, int CFL_MODE>
 int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
 {
 	const Params<T> p = make_params<T>(d);
-	bool empty;
-	const TileMap tm = make_tile_map(p.rows - 2, d->march_rseg, 1, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS),
-	                                 part, empty);
-	if (empty) return HP_OK;
-	const unsigned blocks = (unsigned)((tm.ntiles + 7) / 8) * 8;
+	TileMap tm;
+	unsigned blocks;
+	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks))
+		return HP_OK;
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
@@ -236,11 +253,10 @@ template <typename T, bool STRICT, int CFL_MODE>
 int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
 {
 	const Params<T> p = make_params<T>(d);
-	bool empty;
-	const TileMap tm = make_tile_map(p.rows - 2, d->inertial_rseg, 1, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS),
-	                                 part, empty);
-	if (empty) return HP_OK;
-	const unsigned blocks = (unsigned)((tm.ntiles + 7) / 8) * 8;
+	TileMap tm;
+	unsigned blocks;
+	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks))
+		return HP_OK;
 	hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
@@ -506,6 +522,8 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 64) d->march_rseg = v;
 	}
+	if (const char* e = std::getenv("HP_TAIL_RSEG")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) d->tail_rseg = v; }
+	if (const char* e = std::getenv("HP_TAIL_PCT"))  { const int v = std::atoi(e); if (v >= 0 && v <= 100) d->tail_pct = v; }
 	if (const char* e = std::getenv("HP_INERTIAL_RSEG")) {
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 64) d->inertial_rseg = v;

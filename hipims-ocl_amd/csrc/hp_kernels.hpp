@@ -221,14 +221,47 @@ __device__ __forceinline__ Side<T> shfl_side(const Side<T>& s, const int src_lan
 	return r;
 }
 
-// How one launch's blocks map to tiles: `groups` 4-wave column groups x a run of row segments.  A launch covers
-// segments seg_first .. seg_first+count-1 of the domain, with `seg_gap` segments skipped from position
-// `seg_gap_at` on: (0, never, 0) = the whole domain; the strip-decomposed step launches the first/last segments
-// (whose rows the neighbours' halos need) separately from the interior ones (hp_engine.hip: launch_split).
+// How one launch's blocks map to tiles.  A launch covers the updated rows [y_begin, y_end) of the domain (all of them,
+// or the interior / one halo block of a strip-decomposed step: hp_engine.hip).  The rows are cut into 8 bands, one per
+// XCD (blocks are dealt round-robin to the XCDs, so blockIdx & 7 IS the XCD: its blocks walk one contiguous band and
+// the halo rows of neighbouring tiles are hits in that XCD's L2).  Inside a band the first `nbig` row segments are
+// `rseg` rows tall and the last `ntail` segments only `rseg_tail`: blocks start in blockIdx order, so the short
+// tiles are what is running when the band drains, and the tail of the launch is one SHORT tile long instead of one
+// tall tile (a tall tile lasts ~48 us at 4096^2 -- 18 % of the launch, measured as the intercept of
+// time-vs-cells between 4096^2 and 16384 x 8192).
 struct TileMap {
-	int rseg, nstrips, groups, ntiles;
-	int seg_first, seg_gap_at, seg_gap;
+	int  nstrips, groups;        // 62/60-column strips of the grid, and 4-wave groups of them
+	long y_begin, y_end;         // updated rows covered by this launch
+	int  nbands;                 // 8 (one band per XCD); 2 for the halo launch of a strip (south block, north block)
+	long band_stride;            // distance between band starts (= band_rows, except for the halo launch)
+	int  band_rows;              // rows per band
+	int  rseg, nbig;             // tall segments per band
+	int  rseg_tail, ntail;       // short segments per band (after the tall ones)
 };
+
+// rows [y0, y1) and the column strip of this wave; false if the block / wave has nothing to do (wave-uniform)
+__device__ __forceinline__ bool tile_rows(const TileMap& tm, const int wave, long& strip, long& y0, long& y1)
+{
+	const unsigned band = blockIdx.x % (unsigned)tm.nbands, i = blockIdx.x / (unsigned)tm.nbands;
+	const unsigned nbig_tiles = (unsigned)(tm.groups * tm.nbig);
+	const long band_y0 = tm.y_begin + (long)band * tm.band_stride;
+	const long band_y1 = (band_y0 + tm.band_rows < tm.y_end) ? (band_y0 + tm.band_rows) : tm.y_end;
+	unsigned g;
+	long h;
+	if (i < nbig_tiles) {
+		g = i % (unsigned)tm.groups;
+		h = tm.rseg;
+		y0 = band_y0 + (long)(i / (unsigned)tm.groups) * tm.rseg;
+	} else {
+		const unsigned j = i - nbig_tiles;
+		g = j % (unsigned)tm.groups;
+		h = tm.rseg_tail;
+		y0 = band_y0 + (long)tm.nbig * tm.rseg + (long)(j / (unsigned)tm.groups) * tm.rseg_tail;
+	}
+	y1 = (y0 + h < band_y1) ? (y0 + h) : band_y1;
+	strip = (long)g * 4 + wave;
+	return y0 < band_y1 && strip < tm.nstrips;
+}
 
 template <bool STRICT, int CFL_MODE, typename T>
 __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* sc,
@@ -237,21 +270,13 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
                                                      T* cfl_slot, const T* __restrict__ edge_max,
                                                      const TileMap tm)
 {
-	// XCD-aware tile order (grid is a multiple of 8 blocks)
-	const unsigned per_xcd = gridDim.x >> 3;
-	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 	// the wave index is made a scalar explicitly: everything derived from it (tile rows, buffer descriptors, row
 	// offsets) then lives in SGPRs and the buffer accesses need no waterfall loop
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int rseg = tm.rseg;
-	const long strip = (long)(tile % (unsigned)tm.groups) * 4 + wave;
-	long seg = tm.seg_first + (long)(tile / (unsigned)tm.groups);
-	if (seg >= tm.seg_gap_at) seg += tm.seg_gap;
-	if (tile < (unsigned)tm.ntiles && strip < tm.nstrips) {                              // wave-uniform
+	long strip, y0, y1;                                                            // rows [y0, y1) are updated
+	if (tile_rows(tm, wave, strip, y0, y1)) {                                      // wave-uniform
 
 	const long x = strip * MARCH_COLS + lane;
-	const long y0 = 1 + seg * rseg;
-	const long y1 = (y0 + rseg < p.rows - 1) ? (y0 + rseg) : (p.rows - 1);         // rows [y0, y1) are updated
 	const long xc = (x < p.cols) ? x : (p.cols - 1);                               // clamp halo lanes past the grid
 	const bool out_x = lane >= 1 && lane <= MARCH_COLS && x <= p.cols - 2;         // x >= 1 is implied
 	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 
 	if (CFL_MODE != 0) {
 		// the edge ring (never written, priced at upload) joins the maximum before any cross-rank all-reduce
-		if (tile == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
+		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
 		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
@@ -422,18 +447,11 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
                                                    T* cfl_slot, const T* __restrict__ edge_max,
                                                    const TileMap tm)
 {
-	const unsigned per_xcd = gridDim.x >> 3;
-	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: see K1
-	const int rseg = tm.rseg;
-	const long strip = (long)(tile % (unsigned)tm.groups) * 4 + wave;
-	long seg = tm.seg_first + (long)(tile / (unsigned)tm.groups);
-	if (seg >= tm.seg_gap_at) seg += tm.seg_gap;
-	if (tile < (unsigned)tm.ntiles && strip < tm.nstrips) {
+	long strip, y0, y1;                                                            // corrector domain 2..n-3 (:569-573)
+	if (tile_rows(tm, wave, strip, y0, y1)) {
 
 	const long x = strip * MUSCL_COLS + lane;
-	const long y0 = 2 + seg * rseg;                                                // corrector domain 2..n-3 (:569-573)
-	const long y1 = (y0 + rseg < p.rows - 2) ? (y0 + rseg) : (p.rows - 2);
 	const long xc = (x < p.cols) ? x : (p.cols - 1);
 	const bool out_x = lane >= 2 && lane <= MUSCL_COLS + 1 && x <= p.cols - 3;
 	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 	if (y < y1) row_step(y, rP, rQ);
 
 	if (CFL_MODE != 0) {
-		if (tile == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
+		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
 		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
@@ -576,18 +594,11 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
                                                       T* cfl_slot, const T* __restrict__ edge_max,
                                                       const TileMap tm)
 {
-	const unsigned per_xcd = gridDim.x >> 3;
-	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: see K1
-	const int rseg = tm.rseg;
-	const long strip = (long)(tile % (unsigned)tm.groups) * 4 + wave;
-	long seg = tm.seg_first + (long)(tile / (unsigned)tm.groups);
-	if (seg >= tm.seg_gap_at) seg += tm.seg_gap;
-	if (tile < (unsigned)tm.ntiles && strip < tm.nstrips) {
+	long strip, y0, y1;
+	if (tile_rows(tm, wave, strip, y0, y1)) {
 
 	const long x = strip * MARCH_COLS + lane;
-	const long y0 = 1 + seg * rseg;
-	const long y1 = (y0 + rseg < p.rows - 1) ? (y0 + rseg) : (p.rows - 1);
 	const long xc = (x < p.cols) ? x : (p.cols - 1);
 	const bool out_x = lane >= 1 && lane <= MARCH_COLS && x <= p.cols - 2;
 	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
@@ -692,7 +703,7 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 	}
 
 	if (CFL_MODE != 0) {
-		if (tile == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
+		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
 		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
