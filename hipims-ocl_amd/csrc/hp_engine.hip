@@ -5,6 +5,7 @@
 // the reference's per-device command queue, stream order for its explicit queueBarrier() calls.
 #include "../../include/hipims_mi.h"
 #include "hp_kernels.hpp"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -79,6 +80,7 @@ struct hp_domain {
 	bool             halo_overlap = false;
 	hipStream_t      stream_halo = nullptr;
 	hipEvent_t       ev_fork = nullptr, ev_halo = nullptr;
+	bool             fork_is_advance = false;         // ev_fork was recorded BY the last advance_time launch
 };
 
 namespace {
@@ -304,8 +306,10 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	void* dst = d->state[d->use_alt ^ 1];
 	int rc;
 	const bool has_bdy = !d->bdy.empty() && d->desc.scheme != HP_SCHEME_MUSCL_HANCOCK;   // MUSCL never applies them (Q8)
-	if (has_bdy)
+	if (has_bdy) {
+		d->fork_is_advance = false;
 		if ((rc = apply_boundaries<T>(d, src)) != HP_OK) return rc;
+	}
 
 	// Which buffer does the CFL reduction price?  Q1: always the primary one (CSchemeGodunov.cpp:1629/:1634);
 	// otherwise what this iteration writes.
@@ -321,7 +325,7 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		else if (has_bdy)          cfl_mode = 2;         // primary = source, changed in place by the boundaries
 		else                       cfl_mode = 0;         // primary untouched: last maximum still holds
 		if (cfl_mode != 0 && d->edge_dirty)
-			if ((rc = price_edge_ring<T>(d)) != HP_OK) return rc;
+			{ d->fork_is_advance = false; if ((rc = price_edge_ring<T>(d)) != HP_OK) return rc; }
 	}
 
 	const bool sample = d->timing_stride > 0 && (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
@@ -334,7 +338,10 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	if (d->halo_overlap) {
 		// fork: everything queued so far (previous advance, boundaries, ring pricing) happens-before the halo
 		// segments; they run on their own stream, next to the interior segments on the domain's stream
-		HIP_TRY(hipEventRecord(d->ev_fork, d->stream));
+		// (when nothing was queued since the previous advance_time, that kernel's own completion event serves:
+		// a separate marker packet in front of the interior launch costs a few microseconds on the critical path)
+		if (!d->fork_is_advance) HIP_TRY(hipEventRecord(d->ev_fork, d->stream));
+		d->fork_is_advance = false;
 		HIP_TRY(hipStreamWaitEvent(d->stream_halo, d->ev_fork, 0));
 		if ((rc = launch_flux<T, STRICT>(d, src, dst, cfl_mode, PART_HALO, d->stream_halo)) != HP_OK) return rc;
 		HIP_TRY(hipEventRecord(d->ev_halo, d->stream_halo));
@@ -365,8 +372,14 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 template <typename T> int step_end_impl(hp_domain* d)
 {
 	const Params<T> p = make_params<T>(d);
-	hipLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, p, (Scalars<T>*)d->scalars,
-	                   (T*)d->cfl_slot, d->adv_fresh);
+	if (d->halo_overlap) {
+		hipExtLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, nullptr, d->ev_fork, 0, p,
+		                      (Scalars<T>*)d->scalars, (T*)d->cfl_slot, d->adv_fresh);
+		d->fork_is_advance = true;                                        // cleared by anything else queued on the stream
+	} else {
+		hipLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, p, (Scalars<T>*)d->scalars,
+		                   (T*)d->cfl_slot, d->adv_fresh);
+	}
 	HIP_TRY(hipGetLastError());
 	d->use_alt ^= 1;                                                      // Threaded_runBatch :1300
 	d->cells_calculated += (uint64_t)d->desc.cols * (uint64_t)d->desc.rows;   // :1299
@@ -407,6 +420,7 @@ template <typename T> int set_scalar_field(hp_domain* d, size_t offset, double v
 
 int check_domain(hp_domain* d)
 {
+	if (d) d->fork_is_advance = false;        // any entry point may queue work behind the last advance_time
 	if (!d) return fail(HP_ERR_INVALID, "null domain");
 	hipError_t e = hipSetDevice(d->desc.device);
 	if (e != hipSuccess) return fail(HP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
@@ -805,9 +819,11 @@ int hp_update_timestep(hp_domain_t* d)
 
 int hp_step_begin(hp_domain_t* d)
 {
+	const bool fork_ready = d && d->fork_is_advance;     // nothing was queued since the last hp_step_end
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	if (d->in_step) return fail(HP_ERR_STATE, "hp_step_begin called twice");
+	d->fork_is_advance = fork_ready;
 	if ((rc = dispatch_begin(d)) != HP_OK) return rc;
 	d->in_step = true;
 	return HP_OK;
