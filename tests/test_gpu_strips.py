@@ -148,7 +148,8 @@ def _torchrun(nproc, script_args, env_extra=None, timeout=600):
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
 
 
-@pytest.mark.parametrize("scheme,world", [(hp.SCHEME_GODUNOV, 2), (hp.SCHEME_GODUNOV, 3), (hp.SCHEME_MUSCL_HANCOCK, 2)])
+@pytest.mark.parametrize("scheme,world", [(hp.SCHEME_GODUNOV, 2), (hp.SCHEME_GODUNOV, 3), (hp.SCHEME_MUSCL_HANCOCK, 2),
+                                          (hp.SCHEME_INERTIAL, 2)])
 def test_multi_process_rehearsal_on_one_gpu(scheme, world, tmp_path):
     """Several PROCESSES (torch.distributed.run, one rank each) decompose one grid with the HIP engine on the same
     GPU; the exchange goes through host memory over gloo (RCCL refuses two ranks on one device).  Everything but the
