@@ -382,6 +382,29 @@ def no_friction(tag="f64"):
     save(f"f14_no_friction_{tag}", **out)
 
 
+def disabled_cells(tag="f64"):
+    """F15: disabled cells -- the domain's nulls (CDomain.cpp:351-360: Zmax = -9999; the kernels also test Z == -9999):
+    a block and a sprinkle of them in a wet/dry rough grid, all three schemes, through a sync point."""
+    out = {}
+    st, bed, man = syn.s_rough(64, 48, manning=None)
+    rng = np.random.default_rng(15)
+    dis = np.zeros((48, 64), bool)
+    dis[10:18, 20:30] = True
+    dis |= rng.random((48, 64)) < 0.03
+    dis[0] = dis[-1] = False; dis[:, 0] = dis[:, -1] = False
+    st[dis, 1] = -9999.0
+    st[5, 5, 0] = -9999.0
+    out.update(state=st, bed=bed, manning=man, disabled=dis)
+    for scheme, name in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch"), (oracle.INERTIAL, "ine")):
+        sim = oracle.RefSim(64, 48, scheme=scheme)
+        sim.upload(st, bed, man)
+        sim.set_target(2.5)
+        out[f"{name}_dt"] = sim.run(150)
+        out[f"{name}_state"] = sim.download()
+        out[f"{name}_t"] = np.array(sim.scalars()["t"])
+    save(f"f15_disabled_cells_{tag}", **out)
+
+
 JOBS = [
     ("f1", lambda: [function_level(p, p) for p in ("f64", "f32")]),      # f1..f5
     ("f6", lambda: [trajectories(p, p) for p in ("f64", "f32")] + [trajectories("f64", "f64_mad", mad=True)]),
@@ -391,6 +414,7 @@ JOBS = [
     ("f10", lambda: [newcastle("f64", "f64"), newcastle("f64", "f64_mad", mad=True)]),
     ("f13", fixed_timestep),
     ("f14", no_friction),
+    ("f15", disabled_cells),
     ("f12", lambda: [inertial(p, p) for p in ("f64", "f32")] + [inertial("f64", "f64_mad", mad=True)]),
 ]
 

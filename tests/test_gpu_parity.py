@@ -503,3 +503,22 @@ def test_strict_bit_identity_at_scale(scheme):
     sc, sr = dom.read_scalars(), ref.scalars()
     assert sc["time"] == sr["t"] and sc["timestep"] == sr["dt"]
     dom.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("scheme,name", [(hp.SCHEME_GODUNOV, "god"), (hp.SCHEME_MUSCL_HANCOCK, "mch"), (hp.SCHEME_INERTIAL, "ine")])
+def test_disabled_cells_fixture(scheme, name, mode):
+    """Disabled cells (Zmax = -9999 / Z == -9999) against the fixture from the reference's kernels: carried unchanged bit
+    for bit, the wet cells around them within the stated tolerance, same time."""
+    g = load_golden("f15_disabled_cells_f64")
+    dom = hp.Domain(64, 48, scheme=scheme, math_mode=mode)
+    dom.upload(g["state"], g["bed"], g["manning"])
+    dom.set_target_time(2.5)
+    dom.step_batch(150)
+    out, ref, dis = dom.download(), g[f"{name}_state"], g["disabled"]
+    assert np.array_equal(out[dis], g["state"][dis])
+    live = ~dis & (g["state"][..., 0] != -9999.0)
+    dg = np.maximum(0, out[..., 0] - g["bed"])[live]; dr = np.maximum(0, ref[..., 0] - g["bed"])[live]
+    assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
+    assert abs(dom.read_scalars()["time"] - float(g[f"{name}_t"])) <= 1e-12 * float(g[f"{name}_t"])
+    dom.close()

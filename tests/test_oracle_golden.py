@@ -307,3 +307,16 @@ def test_no_friction_program():
         sim = oracle.OracleSim(72, 40, scheme=scheme, friction=False)
         assert same(_run(sim, g["state"], g["bed"], g["manning"], 120), g[f"{name}_dt"])
         assert same(sim.download(), g[f"{name}_state"]) and sim.scalars()["t"] == g[f"{name}_t"]
+
+
+def test_disabled_cells():
+    """The domain's nulls: cells with Zmax = -9999 (or Z == -9999) are carried unchanged, neighbours see their level."""
+    g = load_golden("f15_disabled_cells_f64")
+    for scheme, name in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch"), (oracle.INERTIAL, "ine")):
+        sim = oracle.OracleSim(64, 48, scheme=scheme)
+        sim.upload(g["state"], g["bed"], g["manning"])
+        sim.set_target(2.5)
+        assert same(sim.run(150), g[f"{name}_dt"])
+        out = sim.download()
+        assert same(out, g[f"{name}_state"]) and sim.scalars()["t"] == g[f"{name}_t"]
+        assert same(out[g["disabled"]], g["state"][g["disabled"]]) and g["disabled"].sum() > 100
