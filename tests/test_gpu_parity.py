@@ -522,3 +522,21 @@ def test_disabled_cells_fixture(scheme, name, mode):
     assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
     assert abs(dom.read_scalars()["time"] - float(g[f"{name}_t"])) <= 1e-12 * float(g[f"{name}_t"])
     dom.close()
+
+
+@pytest.mark.parametrize("definition", [hp.GRIDDED_MASS_FLUX, hp.GRIDDED_RAIN_INTENSITY])
+def test_gridded_definitions_and_series_end(definition):
+    """Gridded mass flux (rate / cell area) and what happens past the end of the series: the reference indexes one
+    slice beyond its buffer there (CLBoundaries.clc:229); oracle and engine both hold the last slice instead."""
+    st, bed, man = syn.s_rough(72, 56, seed=3, manning=None, pool_level=-10.0, amplitude=0.2)
+    st[..., 2:] = 0
+    scale = 0.02 if definition == hp.GRIDDED_MASS_FLUX else 100.0
+    grids = np.random.default_rng(4).uniform(0, scale, (3, 5, 6))
+    dom, ref = make_pair(72, 56, st, bed, man, dx=2.0)
+    for s in (dom, ref):
+        s.add_gridded(definition, grids, 32.0, 0.0, 0.0, 4.0)           # series ends at t = 12 s
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    ref.run(400); dom.step_batch(400)
+    assert ref.scalars()["t"] > 20.0                                    # well past the end of the series
+    compare(dom, ref)
+    assert (ref.download()[..., 0] - bed).max() > 1e-4

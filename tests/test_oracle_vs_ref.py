@@ -99,3 +99,21 @@ def test_no_friction_trajectory(scheme):
         s.set_target(2.0)
     assert np.array_equal(a.run(140), b.run(140))
     assert np.array_equal(a.download(), b.download(), equal_nan=True)
+
+
+@pytest.mark.parametrize("definition", [oracle.GRIDDED_MASS_FLUX, oracle.GRIDDED_RAIN_ACCUMUL])
+def test_gridded_mass_flux_and_accumulation(definition):
+    """BOUNDARY_GRIDDED_MASS_FLUX adds rate / (dx dy) per second; RAIN_ACCUMULATION is accepted and ignored by the
+    device code (CLBoundaries.clc:237-243): both bit-identical between the restatement and the reference's kernel."""
+    st, bed, man = syn.s_rough(40, 33, seed=3, manning=None, pool_level=-10.0, amplitude=0.2)
+    st[..., 2:] = 0
+    grids = np.random.default_rng(4).uniform(0, 0.02, (4, 5, 6))
+    sims = [oracle.OracleSim(40, 33, dx=2.0), oracle.RefSim(40, 33, dx=2.0)]
+    for s in sims:
+        s.upload(st, bed, man)
+        s.add_gridded(definition, grids, 20.0, 0.0, 0.0, 5.0)          # stays inside the 4 x 5 s series
+        s.set_target(1e9)
+    ta, tb = sims[0].run(150), sims[1].run(150)
+    assert np.array_equal(ta, tb) and np.array_equal(sims[0].download(), sims[1].download())
+    wet = (sims[0].download()[..., 0] - bed).max()
+    assert (wet > 1e-4) == (definition == oracle.GRIDDED_MASS_FLUX) and sims[0].scalars()["t"] < 19.0
