@@ -117,3 +117,19 @@ def test_gridded_mass_flux_and_accumulation(definition):
     assert np.array_equal(ta, tb) and np.array_equal(sims[0].download(), sims[1].download())
     wet = (sims[0].download()[..., 0] - bed).max()
     assert (wet > 1e-4) == (definition == oracle.GRIDDED_MASS_FLUX) and sims[0].scalars()["t"] < 19.0
+
+
+def test_uniform_boundary_past_the_end_of_its_series():
+    """bdy_Uniform stops applying once t >= TimeseriesLength (CLBoundaries.clc:168-169): rain and loss for 12 s, then
+    nothing; piecewise-constant lookup in between.  Bit for bit against the reference's kernel."""
+    st, bed, man = syn.s_rough(40, 33, seed=3, manning=None, pool_level=-10.0, amplitude=0.2)
+    st[..., 2:] = 0
+    series = np.array([[0, 60.0], [4, 20.0], [8, 90.0], [12, 0.0]])
+    sims = [oracle.OracleSim(40, 33), oracle.RefSim(40, 33)]
+    for s in sims:
+        s.upload(st, bed, man)
+        s.add_uniform(oracle.UNIFORM_RAIN_INTENSITY, series, 4.0, 12.0)
+        s.add_uniform(oracle.UNIFORM_LOSS_RATE, np.array([[0, 5.0], [12, 5.0]]), 12.0, 12.0)
+        s.set_target(20.0)
+    assert np.array_equal(sims[0].run(400), sims[1].run(400))
+    assert np.array_equal(sims[0].download(), sims[1].download()) and sims[0].scalars()["t"] == 20.0
