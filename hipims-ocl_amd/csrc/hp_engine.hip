@@ -229,9 +229,14 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	unsigned blocks;
 	if (!make_tile_map(2, p.rows - 2, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks))
 		return HP_OK;
-	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
-	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
+	if (d->manning_uniform)
+		hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, true, T>), dim3(blocks), dim3(256), 0, stream, p,
+		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
+	else
+		hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, false, T>), dim3(blocks), dim3(256), 0, stream, p,
+		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }

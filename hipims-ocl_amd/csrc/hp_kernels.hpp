@@ -440,8 +440,13 @@ __device__ __forceinline__ Raw<T> shfl_raw(const Raw<T>& r, const int src_lane)
 	              __shfl(r.qy, src_lane, 64), __shfl(r.zb, src_lane, 64)};
 }
 
-template <bool STRICT, int CFL_MODE, typename T>
-__global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scalars<T>* sc,
+// waves per SIMD the register allocator is asked to make room for: the FAST fp64 flavour fits three once its waiting
+// values sit in LDS (168 VGPRs, no scratch with a uniform Manning n); STRICT fp64 (IEEE division / sqrt expansions)
+// would spill there and keeps two; fp32 has room for four
+template <bool STRICT, typename T> constexpr int muscl_waves() { return sizeof(T) == 4 ? 4 : (STRICT ? 2 : 3); }
+
+template <bool STRICT, int CFL_MODE, bool UNIFORM_N, typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves<STRICT, T>()))) void muscl_march(const Params<T> p, const Scalars<T>* sc,
                                                    const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                    State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                    T* cfl_slot, const T* __restrict__ edge_max,
@@ -450,6 +455,12 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: see K1
 	long strip, y0, y1;                                                            // corrector domain 2..n-3 (:569-573)
 	if (tile_rows(tm, wave, strip, y0, y1)) {
+
+	// Register diet for a third wave per SIMD: what a row does not need while its two faces are being solved -- the
+	// predicted N/E/W face values of a row (12 values) -- waits in LDS ([value][lane]: conflict-free 8-byte columns, 24 KiB
+	// per block in fp64) from the moment the predictor has produced them until the row's own faces are solved.
+	__shared__ T lds_stash[4][18][64];
+	T (*const stash)[64] = lds_stash[wave];
 
 	const long x = strip * MUSCL_COLS + lane;
 	const long xc = (x < p.cols) ? x : (p.cols - 1);
@@ -477,7 +488,8 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 		const unsigned k = (unsigned)(y - (y0 - 2));
 		r.c = buf_load_state(srd_src, voff_state, k * row_state, T());
 		r.zb = buf_load_scalar(srd_bed, voff_scalar, k * row_scalar, T());
-		r.n = p.manning_uniform ? p.manning_value : buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
+		if (UNIFORM_N) r.n = p.manning_value;               // one value everywhere (found at upload): stays a scalar
+		else           r.n = buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
 		return r;
 	};
 	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w) {
@@ -492,7 +504,6 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 	RowRegs<T> rn = load_row(y0 + 1);                                              // y0+1 <= rows-2
 	RowRegs<T> rP = load_row((y0 + 2 < p.rows) ? (y0 + 2) : (p.rows - 1)), rQ;    // landing sets of the row two ahead
 
-	Faces<T> pc = {};
 	FaceFlux<T> fS = {};
 	bool dryE = false, dryW = false, dryS;
 	{
@@ -502,7 +513,10 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 		if (!skip_step) {
 			bool de, dw;
 			const Faces<T> ps = predict(rs2, rs, rc, de, dw);
-			pc = predict(rs, rc, rn, dryE, dryW);
+			const Faces<T> pc = predict(rs, rc, rn, dryE, dryW);
+			stash[0][lane] = pc.n.z; stash[1][lane] = pc.n.h; stash[2][lane] = pc.n.qx; stash[3][lane] = pc.n.qy;
+			stash[4][lane] = pc.e.z; stash[5][lane] = pc.e.h; stash[6][lane] = pc.e.qx; stash[7][lane] = pc.e.qy;
+			stash[8][lane] = pc.w.z; stash[9][lane] = pc.w.h; stash[10][lane] = pc.w.qx; stash[11][lane] = pc.w.qy;
 			const Side<T> sS = side_from_face<STRICT>(ps.n, rs.c.qx, rs.c.qy, vs);
 			const Side<T> sC = side_from_face<STRICT>(pc.s, rc.c.qx, rc.c.qy, vs);
 			fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
@@ -519,10 +533,24 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 			// predictor of the next row (needs rows y, y+1, y+2)
 			bool dryE_n, dryW_n;
 			const Faces<T> pn = predict(rc, rn, rnn, dryE_n, dryW_n);
+			// the current row's faces come back from LDS only now that the predictor's temporaries are dead, and the
+			// next row's take their place there
+			Face4<T> pc_n, pc_e, pc_w;
+			pc_n.z = stash[0][lane]; pc_n.h = stash[1][lane]; pc_n.qx = stash[2][lane]; pc_n.qy = stash[3][lane];
+			pc_e.z = stash[4][lane]; pc_e.h = stash[5][lane]; pc_e.qx = stash[6][lane]; pc_e.qy = stash[7][lane];
+			pc_w.z = stash[8][lane]; pc_w.h = stash[9][lane]; pc_w.qx = stash[10][lane]; pc_w.qy = stash[11][lane];
+			stash[0][lane] = pn.n.z; stash[1][lane] = pn.n.h; stash[2][lane] = pn.n.qx; stash[3][lane] = pn.n.qy;
+			stash[4][lane] = pn.e.z; stash[5][lane] = pn.e.h; stash[6][lane] = pn.e.qx; stash[7][lane] = pn.e.qy;
+			stash[8][lane] = pn.w.z; stash[9][lane] = pn.w.h; stash[10][lane] = pn.w.qx; stash[11][lane] = pn.w.qy;
+			const Face4<T> pn_s = pn.s;
+			// the row two ahead has served the predictor; it is next needed as the northern row of the next iteration
+			stash[12][lane] = rnn.c.z; stash[13][lane] = rnn.c.zmax; stash[14][lane] = rnn.c.qx; stash[15][lane] = rnn.c.qy;
+			stash[16][lane] = rnn.zb;
+			if (!UNIFORM_N) stash[17][lane] = rnn.n;
 
 			// east face: my E-face state against the east neighbour's W-face state
-			const Side<T> sE_mine = side_from_face<STRICT>(pc.e, rc.c.qx, rc.c.qy, vs);
-			const Side<T> sW_mine = side_from_face<STRICT>(pc.w, rc.c.qx, rc.c.qy, vs);
+			const Side<T> sE_mine = side_from_face<STRICT>(pc_e, rc.c.qx, rc.c.qy, vs);
+			const Side<T> sW_mine = side_from_face<STRICT>(pc_w, rc.c.qx, rc.c.qy, vs);
 			const Side<T> sE_nb = shfl_side(sW_mine, lane_e);
 			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sE_mine, sE_nb, vs);
 			const FaceFlux<T> fE = fx.forL, forW = fx.forR;
@@ -533,8 +561,8 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 			fW.stop = __shfl((int)forW.stop, lane_w, 64) != 0;
 
 			// north face: my N-face state against the north neighbour's S-face state
-			const Side<T> sN_mine = side_from_face<STRICT>(pc.n, rc.c.qx, rc.c.qy, vs);
-			const Side<T> sN_nb = side_from_face<STRICT>(pn.s, rn.c.qx, rn.c.qy, vs);
+			const Side<T> sN_mine = side_from_face<STRICT>(pc_n, rc.c.qx, rc.c.qy, vs);
+			const Side<T> sN_nb = side_from_face<STRICT>(pn_s, rn.c.qx, rn.c.qy, vs);
 			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sN_mine, sN_nb, vs);
 			const FaceFlux<T> fN = fy.forL;
 
@@ -549,7 +577,6 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 			fS = fy.forR;
 			dryS = rc.c.zmax < vs;
 			dryE = dryE_n; dryW = dryW_n;
-			pc = pn;
 		}
 
 		buf_store_state(out, srd_dst, out_x ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);
@@ -557,7 +584,14 @@ __global__ __launch_bounds__(256) void muscl_march(const Params<T> p, const Scal
 			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
 			if (s > vmax) vmax = s;
 		}
-		rc = rn; rn = rnn;           // copies of rows that have already been used
+		rc = rn;                     // a copy of a row that has already been used
+		if (!skip_step) {
+			rn.c.z = stash[12][lane]; rn.c.zmax = stash[13][lane]; rn.c.qx = stash[14][lane]; rn.c.qy = stash[15][lane];
+			rn.zb = stash[16][lane];
+			rn.n = UNIFORM_N ? p.manning_value : stash[17][lane];
+		} else {
+			rn = rnn;
+		}
 	};
 
 	long y = y0;
