@@ -2,7 +2,7 @@
  * hipims_mi.h -- C ABI of the MI355X-native shallow-water step engine (libhipims_mi.so).
  *
  * This is the drop-in boundary for ONE path of HiPIMS-OCL (lukeshope/hipims-ocl): the per-timestep
- * update that `CSchemeGodunov` / `CSchemeMUSCLHancock` drive through the OpenCL executor classes
+ * update that `CSchemeGodunov` / `CSchemeMUSCLHancock` / `CSchemeInertial` drive through the OpenCL executor classes
  * (`COCLProgram`, `COCLKernel`, `COCLBuffer`, `COCLDevice`).  The HIP engine owns the kernel graph,
  * so the reference's generic program/kernel/argument layer collapses into semantic calls; each
  * entry point below cites the reference interface it replaces (paths relative to the reference's
