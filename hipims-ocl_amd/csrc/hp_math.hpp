@@ -59,6 +59,8 @@ __device__ __forceinline__ float  floor_(float x)  { return __builtin_floorf(x);
 
 // ---- FAST-flavour primitives: hardware seed + Newton steps instead of the IEEE expansions ----
 // 1/x to about 1 ulp: v_rcp_f64 seed, two Newton-Raphson steps (the IEEE division adds scaling + fix-up).
+// Measured on gfx950 (tools/seedcheck): seed 4.6e-8 relative (2^-24.4), one step 2.1e-15, two steps 1.1e-16;
+// v_rsq_f64 seed 5.2e-8.
 __device__ __forceinline__ double rcp_fast(double x)
 {
 	double r = __builtin_amdgcn_rcp(x);
