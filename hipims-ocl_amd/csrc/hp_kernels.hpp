@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void godunov_basic(const Params<T> p, const Sc
 	const Side<T> sW = make_side<STRICT>(cW.z, cW.qx, cW.qy, zW, p.vs);
 
 	const FaceFlux<T> fN = face_solve<AXIS_Y, STRICT, true, false>(sC, sN, p.vs).forL;
-	const FaceFlux<T> fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, p.vs).forR;
+	const FaceFlux<T> fS = face_solve<AXIS_Y, STRICT, true, true>(sS, sC, p.vs).forR;
 	const FaceFlux<T> fE = face_solve<AXIS_X, STRICT, true, false>(sC, sE, p.vs).forL;
 	const FaceFlux<T> fW = face_solve<AXIS_X, STRICT, false, true>(sW, sC, p.vs).forR;
 
@@ -323,7 +323,10 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		const Side<T> sS = make_side<STRICT>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
 		sC = make_side<STRICT>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
 		dryS = (rs.c.z - rs.zb) < vs;
-		if (!skip_step) fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
+		// both sides are asked for although only the north cell's is used: the tile below finishes this same face as
+		// ITS north face, and the two must take the same code path or results would depend on where tiles (and strip
+		// boundaries) fall
+		if (!skip_step) fS = face_solve<AXIS_Y, STRICT, true, true>(sS, sC, vs).forR;
 	}
 
 	// one row: `rc` is updated, `rn` is its northern neighbour (already landed), `pre` receives the prefetch of row y+2
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			stash[8][lane] = pc.w.z; stash[9][lane] = pc.w.h; stash[10][lane] = pc.w.qx; stash[11][lane] = pc.w.qy;
 			const Side<T> sS = side_from_face<STRICT>(ps.n, rs.c.qx, rs.c.qy, vs);
 			const Side<T> sC = side_from_face<STRICT>(pc.s, rc.c.qx, rc.c.qy, vs);
-			fS = face_solve<AXIS_Y, STRICT, false, true>(sS, sC, vs).forR;
+			fS = face_solve<AXIS_Y, STRICT, true, true>(sS, sC, vs).forR;
 		}
 	}
 

@@ -205,6 +205,28 @@ __device__ __forceinline__ FaceFlux<T> finish_wet(const FaceCore<T>& k, const T 
 	return o;
 }
 
+// The same face finished for the OTHER cell (FAST flavour): of everything finish_wet produces only the
+// normal-momentum flux feels the shift -- through the pressure-like terms g/2 (eta^2 - 2 zb eta) -- besides the two
+// values handed to the bed-slope source.  Mass flux and tangential momentum are carried over from the first finish
+// ((b - a) is the same difference up to rounding); this is what thin films over rough terrain execute on most faces.
+template <int AXIS, typename T>
+__device__ __forceinline__ FaceFlux<T> refinish_wet(const FaceCore<T>& k, const FaceFlux<T>& first, const T s,
+                                                    const bool own_left, const bool stop)
+{
+	const T half_g = T(0.5) * gravity<T>();
+	const T a = k.etaL - s, b = k.etaR - s, zb = k.zbm - s;
+	const T fnL = fma_(k.unL, k.qnL, half_g * (a * (a - 2 * zb)));
+	const T fnR = fma_(k.unR, k.qnR, half_g * (b * (b - 2 * zb)));
+	const T f2m = fma_(k.sLsR, (k.qnR - k.qnL), fma_(k.sR, fnL, -(k.sL * fnR))) * k.inv_ds;
+	const T fn = k.bLeft ? fnL : (k.bRight ? fnR : f2m);
+	FaceFlux<T> o = first;
+	if (AXIS == AXIS_X) o.fx = fn; else o.fy = fn;
+	o.eta_nb = own_left ? b : a;
+	o.zb_nb = zb;
+	o.stop = stop;
+	return o;
+}
+
 template <typename T> struct FacePair { FaceFlux<T> forL, forR; };
 
 // Solve the face between cell L (west/south) and cell R (east/north).
@@ -294,7 +316,7 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 			k.bRight = !k.bLeft && !k.bMid1 && !bMid2;
 			oL = finish_wet<AXIS, STRICT>(k, shL, true, false);
 			oR = oL;
-			if (shL != shR) oR = finish_wet<AXIS, STRICT>(k, shR, false, false);
+			if (shL != shR) oR = refinish_wet<AXIS>(k, oL, shR, false, false);
 			oR.eta_nb = etaL - shR;
 		}
 	} else if (hL < vs && hR < vs) {
@@ -357,7 +379,7 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 		// its neighbour's bed.  FAST reuses the first result where the shifts agree (bit-identical by construction).
 		if (!STRICT && WANT_L && WANT_R) {
 			oR = oL;
-			if (shL != shR) oR = finish_wet<AXIS, STRICT>(k, shR, false, stopR);   // rare, skipped wave-wide
+			if (shL != shR) oR = refinish_wet<AXIS>(k, oL, shR, false, stopR);     // skipped wave-wide where no lane needs it
 			oR.eta_nb = etaL - shR;
 			oR.stop = stopR;
 		} else {
