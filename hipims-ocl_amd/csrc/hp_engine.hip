@@ -534,10 +534,11 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 			return rseg;
 		};
 		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, 16, 2);
-		// large grids: 18 rows measured 1.9 % ahead of 16 at 4096^2 in interleaved repeats (tools/rseg_fine_sweep.sh)
+		// large grids: 18 rows measured 1.9 % (K1) / 2.8 % (K6, against 32) ahead in interleaved repeats at 4096^2
+		// (tools/rseg_fine_sweep*.sh)
 		if (d->march_rseg == 16 && (((desc->cols - 2 + MARCH_COLS - 1) / MARCH_COLS + 3) / 4) * ((desc->rows - 2 + 17) / 18) >= 350)
 			d->march_rseg = 18;
-		d->inertial_rseg = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, 32, 2);
+		d->inertial_rseg = d->march_rseg;
 		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 32, 4);
 	}
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
