@@ -206,6 +206,10 @@ inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rs
 	tm.nbands = 8;
 	tm.band_rows = (int)((rows + 7) / 8);
 	tm.band_stride = tm.band_rows;
+	// K1/K6 on tall bands: 18-row tiles measured 1.9 % / 2.8 % ahead of 16 at 4096^2 (band of 512 rows) and 0.6 % at
+	// 8192 x 2050 (256), but 3 % behind at 16384 x 1026 (128 rows = eight exact 16-row tiles); interleaved repeats
+	// on one box, tools/rseg_fine_sweep*.sh
+	if (rseg == 16 && g == 1 && tm.band_rows >= 256) rseg = 18;
 	tm.rseg = rseg < tm.band_rows ? rseg : tm.band_rows;
 	tm.rseg_tail = rseg_tail;
 	if (rseg_tail >= tm.rseg || tail_pct <= 0) {
@@ -534,10 +538,6 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 			return rseg;
 		};
 		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, 16, 2);
-		// large grids: 18 rows measured 1.9 % (K1) / 2.8 % (K6, against 32) ahead in interleaved repeats at 4096^2
-		// (tools/rseg_fine_sweep*.sh)
-		if (d->march_rseg == 16 && (((desc->cols - 2 + MARCH_COLS - 1) / MARCH_COLS + 3) / 4) * ((desc->rows - 2 + 17) / 18) >= 350)
-			d->march_rseg = 18;
 		d->inertial_rseg = d->march_rseg;
 		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 32, 4);
 	}
