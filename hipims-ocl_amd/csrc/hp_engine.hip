@@ -63,6 +63,7 @@ struct hp_domain {
 	int              march_rseg = 16;                 // rows per wavefront tile of godunov_march
 	int              muscl_rseg = 32;                 // ... of muscl_march (two warm-up rows per tile)
 	int              inertial_rseg = 32;              // ... of inertial_march
+	int              tall_rseg = 18;                  // K1/K6 tile height where an XCD band has >= 256 rows (16 if a knob is set)
 	int              tail_rseg = 8, tail_pct = 0;     // optional short tiles for the last tail_pct % of each XCD band (measured: no gain)
 	void*            host_scalars = nullptr;          // pinned mirror
 	int              use_alt = 0;                     // bUseAlternateKernel
@@ -181,7 +182,7 @@ struct RowRange { long lo, hi; };
 // TileMap of one launch (see hp_kernels.hpp): 8 XCD bands over [lo, hi), tall tiles first and optionally short tiles
 // for the last `tail_pct` percent of each band; or, for the halo part, the two blocks of `halo` rows as two bands.
 inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rseg, int rseg_tail, int tail_pct,
-                          TileMap& tm, unsigned& blocks)
+                          TileMap& tm, unsigned& blocks, int rseg_tall = 16)
 {
 	static const long halo_env = std::getenv("HP_HALO_ROWS") ? std::atol(std::getenv("HP_HALO_ROWS")) : 0;
 	const long halo = halo_env >= g ? halo_env : (rseg > g ? rseg : g);
@@ -209,7 +210,7 @@ inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rs
 	// K1/K6 on tall bands: 18-row tiles measured 1.9 % / 2.8 % ahead of 16 at 4096^2 (band of 512 rows) and 0.6 % at
 	// 8192 x 2050 (256), but 3 % behind at 16384 x 1026 (128 rows = eight exact 16-row tiles); interleaved repeats
 	// on one box, tools/rseg_fine_sweep*.sh
-	if (rseg == 16 && g == 1 && tm.band_rows >= 256) rseg = 18;
+	if (rseg == 16 && g == 1 && tm.band_rows >= 256) rseg = rseg_tall;
 	tm.rseg = rseg < tm.band_rows ? rseg : tm.band_rows;
 	tm.rseg_tail = rseg_tail;
 	if (rseg_tail >= tm.rseg || tail_pct <= 0) {
@@ -251,7 +252,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
-	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks))
+	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg))
 		return HP_OK;
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
@@ -266,7 +267,7 @@ int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, i
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
-	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks))
+	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg))
 		return HP_OK;
 	hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
@@ -543,13 +544,13 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	}
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
-		if (v >= 1 && v <= 64) d->march_rseg = v;
+		if (v >= 1 && v <= 64) { d->march_rseg = v; d->tall_rseg = 16; }   // a forced 16 stays 16
 	}
 	if (const char* e = std::getenv("HP_TAIL_RSEG")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) d->tail_rseg = v; }
 	if (const char* e = std::getenv("HP_TAIL_PCT"))  { const int v = std::atoi(e); if (v >= 0 && v <= 100) d->tail_pct = v; }
 	if (const char* e = std::getenv("HP_INERTIAL_RSEG")) {
 		const int v = std::atoi(e);
-		if (v >= 1 && v <= 64) d->inertial_rseg = v;
+		if (v >= 1 && v <= 64) { d->inertial_rseg = v; d->tall_rseg = 16; }
 	}
 	if (const char* e = std::getenv("HP_MUSCL_RSEG")) {
 		const int v = std::atoi(e);
