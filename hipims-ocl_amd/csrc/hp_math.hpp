@@ -69,12 +69,7 @@ __device__ __forceinline__ double rcp_fast(double x)
 	e = __builtin_fma(-x, r, 1.0);
 	return __builtin_fma(r, e, r);
 }
-__device__ __forceinline__ float rcp_fast(float x)
-{
-	float r = __builtin_amdgcn_rcpf(x);
-	const float e = __builtin_fmaf(-x, r, 1.0f);
-	return __builtin_fmaf(r, e, r);
-}
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32 is 1 ulp already
 // sqrt(x), x >= 0, to about 1 ulp: v_rsq_f64 seed, Goldschmidt step + residual correction.  x is clamped away
 // from zero (sqrt(1e-300) = 1e-150 stands in for 0; depths below VERY_SMALL never reach a division by it).
 __device__ __forceinline__ double sqrt_fast(double x)
@@ -88,7 +83,7 @@ __device__ __forceinline__ double sqrt_fast(double x)
 	const double d = __builtin_fma(-g, g, x);
 	return __builtin_fma(d, h, g);
 }
-__device__ __forceinline__ float sqrt_fast(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32: 1 ulp, no denormal rescaling
 // x^(-1/3), x > 0: fp32 exp2/log2 seed (relative error ~1e-6), two Newton steps y <- y + y(1 - x y^3)/3.
 __device__ __forceinline__ double rcbrt_fast(double x)
 {
