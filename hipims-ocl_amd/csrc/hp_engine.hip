@@ -538,7 +538,9 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 			while (rseg > shortest && groups * ((updated_rows + rseg - 1) / rseg) < 350) rseg /= 2;
 			return rseg;
 		};
-		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, 16, 2);
+		// fp32 rows are cheap enough for a tile's three-row fill and extra south face to show: 32-row tiles measured
+		// 13 % (S-DAM) to 47 % (S-RAIN 8192^2) ahead of 16; fp64 is flat or slightly worse beyond 18
+		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? 32 : 16, 2);
 		d->inertial_rseg = d->march_rseg;
 		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 32, 4);
 	}
