@@ -55,7 +55,7 @@ def make_newcastle(tmpdir, duration=7200, frequency=600, scheme="Godunov"):
     os.makedirs(os.path.join(root, "boundaries"), exist_ok=True)
     shutil.copy(os.path.join(GOLDEN, "NewcastleCentreDEM_2m.img"), os.path.join(root, "topography"))
     with open(os.path.join(root, "boundaries", "rainfall.csv"), "w") as f:
-        f.write("Time (s),Rainfall intensity (mm/hr)\n0,70\n3600,70\n7200,0\n10800,0\n")
+        f.write("Time (s),Rainfall intensity (mm/hr)\n0,70\n3600,70\n7200,0\n10800,0\n14400,0\n18000,0\n")
     with open(os.path.join(root, "boundaries", "drainage.csv"), "w") as f:
         f.write("Time (s),Drainage losses (mm/hr)\n0,12\n100000000,12\n")
     path = os.path.join(root, "newcastle-centre.xml")

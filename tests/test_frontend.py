@@ -3,6 +3,7 @@ on the CPU with the oracle as the engine."""
 import os
 
 import numpy as np
+import pytest
 
 import oracle
 from conftest import GOLDEN
@@ -34,7 +35,7 @@ def test_configuration_and_initial_conditions(tmp_path):
     assert (cfg.duration, cfg.output_frequency, cfg.precision, cfg.courant, cfg.friction) == (7200.0, 600.0, "f64", 0.5, True)
     assert cfg.closed_edges == {"north", "south", "east", "west"} and len(cfg.boundaries) == 2
     rain = next(b for b in cfg.boundaries if b.value == "rain-intensity")
-    assert rain.series.shape == (4, 2) and rain.series[1, 0] - rain.series[0, 0] == 3600.0
+    assert rain.series.shape == (6, 2) and rain.series[1, 0] - rain.series[0, 0] == 3600.0
     state, bed, man, res = frontend.build_domain(cfg)
     assert bed.shape == (195, 342) and res == 2.0 and (man == 0.03).all()
     assert (bed[0] == 9999.9).all() and (bed[:, -1] == 9999.9).all()
@@ -157,3 +158,23 @@ def test_cli_fails_loudly_without_a_gpu(tmp_path):
                                                         os.environ.get("PYTHONPATH", "")]), HIPIMS_MI_NO_TORCH="1")
     r = subprocess.run([sys.executable, "-m", "hipims_mi", "-c", xml, "-s"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and ("no usable HIP device" in r.stderr or "HP_ERR" in r.stderr or "hip" in r.stderr.lower())
+
+
+REFERENCE_EXAMPLE = "/root/reference/test/newcastle-centre.xml"
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_EXAMPLE), reason="reference checkout not present (only in the build container)")
+def test_the_reference_example_directory_parses_as_is(tmp_path):
+    """Drop-in check on the reference's OWN model directory, untouched (read-only): its XML, its CSV series and its HFA
+    raster give the same configuration and initial conditions as the fixture directory the other tests build."""
+    ref = frontend.parse_configuration(REFERENCE_EXAMPLE)
+    mine = frontend.parse_configuration(make_newcastle(tmp_path))
+    assert (ref.duration, ref.output_frequency, ref.precision, ref.scheme, ref.courant, ref.friction, ref.dry_threshold) == \
+           (mine.duration, mine.output_frequency, mine.precision, mine.scheme, mine.courant, mine.friction, mine.dry_threshold)
+    assert ref.closed_edges == mine.closed_edges and len(ref.boundaries) == len(mine.boundaries) == 2
+    for a, b in zip(sorted(ref.boundaries, key=lambda x: x.value), sorted(mine.boundaries, key=lambda x: x.value)):
+        assert a.kind == b.kind and a.value == b.value and np.array_equal(a.series, b.series)
+    assert [w for w, _ in ref.targets] == [w for w, _ in mine.targets]
+    sa, ba, ma, ra = frontend.build_domain(ref)
+    sb, bb, mb, rb = frontend.build_domain(mine)
+    assert ra == rb and np.array_equal(ba, bb) and np.array_equal(ma, mb) and np.array_equal(sa, sb)
