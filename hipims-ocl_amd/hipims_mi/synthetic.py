@@ -92,3 +92,30 @@ def s_rain_rows(cols, rows, row_lo, row_hi, dx=2.0, dtype=np.float32, seed=7, gr
     grids = rng.uniform(0.0, 120.0, (slices, grid_cells, grid_cells))
     rain = dict(grids=grids.astype(dtype), resolution=resolution, off_x=0.0, off_y=0.0, interval=interval)
     return state.astype(dtype), bed.astype(dtype), np.full((n, cols), 0.03, dtype), rain
+
+
+def sloshing_bowl(n=200, dx=40.0, h0=10.0, a=3000.0, b=5.0, g=9.81):
+    """Planar free surface sloshing round a frictionless parabolic bowl (Thacker's solution; the reference's model
+    builder ships it as tools/model-builder/tests/TestSloshingBowl.js:92-118, there with rows counted north-down).
+    Returns (bed, fsl(t), state(t), period): bed = h0 r^2 / a^2, eta = h0 - (b s / g)(x cos st + y sin st),
+    (u, v) = (b sin st, -b cos st), s = sqrt(2 g h0) / a -- in this package's south-up, v-positive-north convention."""
+    s = np.sqrt(2.0 * g * h0) / a
+    xs = (np.arange(n) - n / 2 + 0.5) * dx
+    x, y = np.meshgrid(xs, xs)
+    bed = h0 * (x ** 2 + y ** 2) / a ** 2
+
+    def fsl(t):
+        f = h0 - (b * s / g) * (np.cos(s * t) * x + np.sin(s * t) * y)
+        return np.where(f > bed, f, bed)
+
+    def state(t):
+        z = fsl(t)
+        d = z - bed
+        st = np.zeros((n, n, 4))
+        st[..., 0] = z
+        st[..., 1] = z
+        st[..., 2] = d * b * np.sin(s * t)
+        st[..., 3] = -d * b * np.cos(s * t)
+        return st
+
+    return bed, fsl, state, 2.0 * np.pi / s
