@@ -119,3 +119,18 @@ def sloshing_bowl(n=200, dx=40.0, h0=10.0, a=3000.0, b=5.0, g=9.81):
         return st
 
     return bed, fsl, state, 2.0 * np.pi / s
+
+
+def emerging_bed_dam_break(cols=640, rows=8, dx=0.05, h0=1.0, alpha=np.pi / 60.0, g=9.81):
+    """Dam break onto a dry bed that rises at angle alpha (Xing et al. 2010; the reference's model builder ships it as
+    tools/model-builder/tests/TestDamBreakEmergingBed.js:62-69): dam at x = 0, still water of level h0 to its left.
+    Returns (state, bed, x of the cell centres, front(t)) with the analytic front position
+    x_f = 2 t sqrt(g h0 cos alpha) - g t^2 tan(alpha) / 2."""
+    xs = (np.arange(cols) - cols / 2 + 0.5) * dx
+    bed = np.tile(xs * np.tan(alpha), (rows, 1))
+    depth = np.where(xs <= 0, np.maximum(0.0, h0 - xs * np.tan(alpha)), 0.0)
+    state = np.zeros((rows, cols, 4))
+    state[..., 0] = bed + depth
+    state[..., 1] = state[..., 0]
+    _walls(state, bed)
+    return state, bed, xs, (lambda t: 2 * t * np.sqrt(g * h0 * np.cos(alpha)) - 0.5 * g * t * t * np.tan(alpha))

@@ -587,3 +587,20 @@ def test_sloshing_bowl_analytic(scheme):
             deep = (out[..., 0] - bed) > 1.0
             assert abs((out[..., 2][deep] / (out[..., 0] - bed)[deep]).mean() - 5.0) < 0.1
     dom.close()
+
+
+def test_emerging_bed_front_analytic():
+    """The reference's TestDamBreakEmergingBed case on the GPU: same front as the oracle (to a cell), bounded by the
+    analytic position."""
+    st, bed, xs, front = syn.emerging_bed_dam_break()
+    dom, ref = make_pair(st.shape[1], st.shape[0], st, bed, np.zeros(bed.shape), dx=0.05, friction=False)
+    for s, target, upd in ((dom, dom.set_target_time, dom.update_timestep), (ref, ref.set_target, ref.update_timestep)):
+        target(1.0)
+    while 1.0 - dom.read_scalars()["time"] > 1e-9:
+        dom.step_batch(20)
+    while 1.0 - ref.scalars()["t"] > 1e-9:
+        ref.run(20)
+    xg = xs[(dom.download()[4, :, 0] - bed[4]) > 1e-3].max()
+    xr = xs[(ref.download()[4, :, 0] - bed[4]) > 1e-3].max()
+    assert abs(xg - xr) <= 0.05 + 1e-12 and 0.6 * front(1.0) < xg < front(1.0)
+    compare(dom, ref)

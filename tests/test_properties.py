@@ -77,3 +77,24 @@ def test_sloshing_bowl_follows_the_analytic_solution():
     assert abs(u.mean() - 5.0) < 0.1 and abs(v.mean()) < 0.3           # (u, v) = (b, 0) analytically
     # the initial condition really was the other orientation
     assert np.sqrt(np.mean((fsl(0.0) - ref)[wet] ** 2)) > 2.0
+
+
+def test_dam_break_front_on_an_emerging_bed():
+    """Known answer (the reference's TestDamBreakEmergingBed.js): the wet front of a dam break climbing a
+    dry slope.  The analytic front is a vanishing film; a first-order finite-volume front trails it (here by about
+    30 %), never overtakes it, and decelerates the same way."""
+    st, bed, xs, front = syn.emerging_bed_dam_break()
+    sim = oracle.OracleSim(st.shape[1], st.shape[0], dx=0.05, friction=False)
+    sim.upload(st, bed, np.zeros(bed.shape))
+    got = []
+    for t in (0.5, 1.0, 1.5):
+        sim.set_target(t)
+        if sim.scalars()["dt"] <= 0:
+            sim.update_timestep()
+        while t - sim.scalars()["t"] > 1e-9:
+            sim.run(20)
+        d = sim.download()[4, :, 0] - bed[4]
+        got.append(xs[d > 1e-3].max())
+    for t, x in zip((0.5, 1.0, 1.5), got):
+        assert 0.6 * front(t) < x < front(t)
+    assert got[1] - got[0] > got[2] - got[1] > 0           # advancing and decelerating, like x_f(t)
