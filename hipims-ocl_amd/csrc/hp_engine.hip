@@ -8,6 +8,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +60,7 @@ struct hp_domain {
 	double           manning_value = 0.0;
 	bool             need_full_reduce = true;         // the remembered maximum is stale (upload / link import)
 	bool             edge_dirty = true;               // edge-ring maxima must be re-priced
+	bool             bdy_on_ring = false;             // a cell boundary imposes values on never-written ring cells: re-price every iteration
 	int              adv_fresh = 1;                   // does hp_step_end's advance kernel read a new maximum?
 	int              march_rseg = 16;                 // rows per wavefront tile of godunov_march
 	int              muscl_rseg = 32;                 // ... of muscl_march (two warm-up rows per tile)
@@ -74,7 +76,8 @@ struct hp_domain {
 	// flux-kernel timing samples
 	int              timing_stride = 0;
 	uint64_t         timing_counter = 0;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;   // pool, created by hp_kernel_timing
+	size_t           timing_used = 0;
 	long             own_lo = 0, own_hi = 0;          // rows this rank owns (CFL reduction range)
 	// halo overlap (strip decomposition): the row segments next to the ghost rows run on their own stream so the
 	// neighbours' halo transfer can start while the interior segments are still being computed
@@ -334,15 +337,20 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		if (muscl || !q1 || dst_is_primary) cfl_mode = 1; // price what lands in dst
 		else if (has_bdy)          cfl_mode = 2;         // primary = source, changed in place by the boundaries
 		else                       cfl_mode = 0;         // primary untouched: last maximum still holds
-		if (cfl_mode != 0 && d->edge_dirty)
+		// the ring maxima are cached from the last upload -- unless a cell boundary rewrites ring cells in place
+		// (bdy_cell accepts any cell; tst_Reduce re-reads every cell each iteration, CLDynamicTimestep.clc:166-249)
+		if (cfl_mode != 0 && (d->edge_dirty || (has_bdy && d->bdy_on_ring)))
 			{ d->fork_is_advance = false; if ((rc = price_edge_ring<T>(d)) != HP_OK) return rc; }
 	}
 
-	const bool sample = d->timing_stride > 0 && (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
+	// flux-kernel timing: every `stride`-th launch is bracketed by a pair of events taken from a pool created by
+	// hp_kernel_timing (nothing is created inside a timed region; once the pool is used up sampling stops)
+	const bool sample = d->timing_stride > 0 && d->timing_used < d->timing_events.size() &&
+	                    (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (sample) {
-		HIP_TRY(hipEventCreate(&e0));
-		HIP_TRY(hipEventCreate(&e1));
+		e0 = d->timing_events[d->timing_used].first;
+		e1 = d->timing_events[d->timing_used].second;
 		HIP_TRY(hipEventRecord(e0, d->stream));
 	}
 	if (d->halo_overlap) {
@@ -361,7 +369,7 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	} else if ((rc = launch_flux<T, STRICT>(d, src, dst, cfl_mode, PART_ALL, d->stream)) != HP_OK) return rc;
 	if (sample) {
 		HIP_TRY(hipEventRecord(e1, d->stream));
-		d->timing_events.emplace_back(e0, e1);
+		d->timing_used++;
 	}
 
 	d->adv_fresh = 0;
@@ -418,13 +426,15 @@ template <typename T> int write_scalars_initial(hp_domain* d)
 	return HP_OK;
 }
 
+// One time-control scalar rewritten in stream order, without blocking: the value travels as a kernel argument, so
+// no host staging buffer has to outlive the call (the reference enqueues these writes non-blocking too,
+// CSchemeGodunov.cpp:1166-1176, :1213-1232).
+template <typename T> __global__ void store_scalar(T* where, const T value) { *where = value; }
+
 template <typename T> int set_scalar_field(hp_domain* d, size_t offset, double value)
 {
-	T v = (T)value;
-	std::memcpy((char*)d->host_scalars + 256, &v, sizeof v);
-	HIP_TRY(hipMemcpyAsync((char*)d->scalars + offset, (char*)d->host_scalars + 256, sizeof v, hipMemcpyHostToDevice,
-	                       d->stream));
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	hipLaunchKernelGGL(store_scalar<T>, dim3(1), dim3(1), 0, d->stream, (T*)((char*)d->scalars + offset), (T)value);
+	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
 
@@ -731,6 +741,16 @@ int hp_boundary_add_gridded(hp_domain_t* d, int definition, const void* grids, u
 	if (rc != HP_OK) return rc;
 	if (!grids || entries == 0 || grid_rows == 0 || grid_cols == 0 || !(resolution > 0) || !(interval > 0))
 		return fail(HP_ERR_INVALID, "bad gridded boundary");
+	{
+		// bdy_Gridded indexes floor((x dx - off) / res) without a range check (CLBoundaries.clc:231-236): a grid that
+		// does not cover the interior cells reads outside the buffer.  Rejected here instead.
+		const double dx = d->desc.dx;
+		const double x_lo = 1.0 * dx - offset_x, x_hi = (double)(d->desc.cols - 2) * dx - offset_x;
+		const double y_lo = 1.0 * dx - offset_y, y_hi = (double)(d->desc.global_rows - 2) * dx - offset_y;
+		if (x_lo < 0.0 || y_lo < 0.0 || std::floor(x_hi / resolution) >= (double)grid_cols ||
+		    std::floor(y_hi / resolution) >= (double)grid_rows)
+			return fail(HP_ERR_INVALID, "gridded boundary does not cover the domain's interior cells");
+	}
 	Boundary b{};
 	b.kind = 1; b.definition = definition; b.entries = entries; b.grows = grid_rows; b.gcols = grid_cols;
 	b.resolution = resolution; b.off_x = offset_x; b.off_y = offset_y; b.interval = interval;
@@ -750,8 +770,16 @@ int hp_boundary_add_cell(hp_domain_t* d, int depth_definition, int discharge_def
 	if (depth_definition < 0 || depth_definition > 3 || discharge_definition < 0 || discharge_definition > 3)
 		return fail(HP_ERR_INVALID, "unknown cell boundary definition");
 	const uint64_t global_cells = (uint64_t)d->desc.cols * (uint64_t)d->desc.global_rows;
-	for (uint64_t i = 0; i < count; ++i)
-		if (cells[i] >= global_cells) return fail(HP_ERR_INVALID, "cell boundary id outside the grid");
+	bool on_ring = false;
+	{
+		const uint64_t w = (d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK) ? 2 : 1, cols = (uint64_t)d->desc.cols,
+		               grows = (uint64_t)d->desc.global_rows;
+		for (uint64_t i = 0; i < count; ++i) {
+			if (cells[i] >= global_cells) return fail(HP_ERR_INVALID, "cell boundary id outside the grid");
+			const uint64_t gy = cells[i] / cols, x = cells[i] - gy * cols;
+			on_ring = on_ring || x < w || x + w >= cols || gy < w || gy + w >= grows;
+		}
+	}
 	if (length > (double)(entries - 1) * interval + 1e-9)
 		return fail(HP_ERR_INVALID, "cell boundary series shorter than its length (interpolation reads entry n+1)");
 	Boundary b{};
@@ -763,6 +791,7 @@ int hp_boundary_add_cell(hp_domain_t* d, int depth_definition, int discharge_def
 	HIP_TRY(hipMalloc(&b.data, bytes));
 	HIP_TRY(hipMemcpy(b.data, series, bytes, hipMemcpyHostToDevice));
 	d->bdy.push_back(b);
+	d->bdy_on_ring = d->bdy_on_ring || on_ring;
 	return HP_OK;
 }
 
@@ -773,6 +802,7 @@ int hp_boundary_clear(hp_domain_t* d)
 	HIP_TRY(hipStreamSynchronize(d->stream));
 	for (auto& b : d->bdy) { hipFree(b.data); hipFree(b.cells); }
 	d->bdy.clear();
+	d->bdy_on_ring = false;
 	return HP_OK;
 }
 
@@ -815,6 +845,9 @@ int hp_update_timestep(hp_domain_t* d)
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	if (d->desc.dynamic_dt && d->desc.global_rows != d->desc.rows)
+		return fail(HP_ERR_UNSUPPORTED, "hp_update_timestep on a row strip: the maximum must be all-reduced across "
+		                                "ranks not available through this call)");
 	// tst_Reduce reads the primary buffer (arg wiring CSchemeGodunov.cpp:922, :927), then tst_UpdateTimestep
 	if (d->desc.precision == 8) {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
@@ -903,6 +936,7 @@ int hp_is_busy(hp_domain_t* d, int* busy)
 {
 	if (!d || !busy) return fail(HP_ERR_INVALID, "null argument");
 	hipError_t e = hipStreamQuery(d->stream);
+	if (e == hipSuccess && d->stream_halo) e = hipStreamQuery(d->stream_halo);       // halo segments of a split step
 	if (e == hipSuccess) { *busy = 0; return HP_OK; }
 	if (e == hipErrorNotReady) { *busy = 1; return HP_OK; }
 	return fail(HP_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
@@ -911,6 +945,7 @@ int hp_is_busy(hp_domain_t* d, int* busy)
 int hp_device_ptr(hp_domain_t* d, int which, void** ptr)
 {
 	if (!d || !ptr) return fail(HP_ERR_INVALID, "null argument");
+	d->fork_is_advance = false;          // the caller may queue work on these buffers behind the last advance_time
 	switch (which) {
 	case HP_PTR_STATE_NEXT_SRC: *ptr = d->state[d->use_alt]; return HP_OK;
 	case HP_PTR_STATE_OTHER:    *ptr = d->state[d->use_alt ^ 1]; return HP_OK;
@@ -925,6 +960,7 @@ int hp_device_ptr(hp_domain_t* d, int which, void** ptr)
 int hp_stream(hp_domain_t* d, void** hip_stream)
 {
 	if (!d || !hip_stream) return fail(HP_ERR_INVALID, "null argument");
+	d->fork_is_advance = false;
 	*hip_stream = (void*)d->stream;
 	return HP_OK;
 }
@@ -968,8 +1004,14 @@ int hp_kernel_timing(hp_domain_t* d, int enable_stride)
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	HIP_TRY(hipStreamSynchronize(d->stream));
-	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-	d->timing_events.clear();
+	constexpr size_t POOL = 16;                                          // samples per measurement: sparse on purpose
+	while (enable_stride > 0 && d->timing_events.size() < POOL) {
+		hipEvent_t a, b;
+		HIP_TRY(hipEventCreate(&a));
+		HIP_TRY(hipEventCreate(&b));
+		d->timing_events.emplace_back(a, b);
+	}
+	d->timing_used = 0;
 	d->timing_counter = 0;
 	d->timing_stride = enable_stride > 0 ? enable_stride : 0;
 	return HP_OK;
@@ -983,9 +1025,9 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples)
 	HIP_TRY(hipStreamSynchronize(d->stream));
 	double total = 0.0;
 	uint32_t n = 0;
-	for (auto& ev : d->timing_events) {
+	for (size_t i = 0; i < d->timing_used; ++i) {
 		float ms = 0.f;
-		HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+		HIP_TRY(hipEventElapsedTime(&ms, d->timing_events[i].first, d->timing_events[i].second));
 		total += ms;
 		++n;
 	}

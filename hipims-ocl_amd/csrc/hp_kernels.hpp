@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256) void bdy_uniform(const Params<T> p, const Scal
 	const T t = sc->t, dt_real = sc->dt, dt = sc->t_hydro;
 	if (dt < T(1.0) || dt_real <= T(0)) return;                                  // :165-166 (uniform over the grid)
 	if (t >= b.length) return;                                                    // :168
-	const unsigned long ts = (unsigned long)floor_(t / b.interval);               // :172-173
+	unsigned long ts = (unsigned long)floor_(t / b.interval);                     // :172-173
+	if (ts >= b.entries) ts = b.entries - 1;          // a series shorter than its `length`: hold the last entry (the reference reads past the buffer)
 	const T rate = b.series[2 * ts + 1];
 	const T amount = rate / T(3600000.0) * dt;
 	const size_t cells = (size_t)p.cols * p.rows;

@@ -219,7 +219,8 @@ int hp_stream_halo(hp_domain_t* d, void** hip_stream);
  * Bracket a region of the domain's stream with HIP events and return the elapsed milliseconds. */
 int hp_timer_start(hp_domain_t* d);
 int hp_timer_stop(hp_domain_t* d, float* elapsed_ms);  /* BLOCKS until the stop event completes */
-/* Average device time of the dominant (flux) kernel: every `stride`-th launch is bracketed with events. */
+/* Average device time of the dominant (flux) kernel: every `stride`-th launch is bracketed with events from a pool of
+ * 16 pairs created by this call (so nothing is created inside a timed region); sampling stops when the pool is used up. */
 int hp_kernel_timing(hp_domain_t* d, int enable_stride);
 int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples);   /* BLOCKS */
 

@@ -28,3 +28,16 @@ def golden_dir():
 def load_golden(name):
     import numpy as np
     return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def record(name, **numbers):
+    """Append achieved parity numbers to gpurun_out/parity_numbers.jsonl (scratch on the GPU box, merged back by
+    gpurun) so that DESIGN.md can quote what the tolerances are actually met with."""
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_numbers.jsonl"), "a") as f:
+            f.write(json.dumps(dict(case=name, **{k: (float(v) if hasattr(v, "__float__") else v) for k, v in numbers.items()})) + "\n")
+    except OSError:
+        pass

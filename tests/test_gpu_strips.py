@@ -177,7 +177,7 @@ def test_bench_multi_rank_branch_rehearsal():
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = _torchrun(2, [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--cols", "512",
-                      "--rows", "1024"], env_extra={"HIPIMS_MI_BACKEND": "gloo"})
+                      "--rows", "1024", "--repeats", "1", "--prewarm-s", "0"], env_extra={"HIPIMS_MI_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                     # rank 0 only
