@@ -160,6 +160,23 @@ def trajectories(precision, tag, mad=False):
     save(f"f6_f7_trajectories_{tag}", **out)
 
 
+def fp32_bracket():
+    """The reference's OWN compiler-dependent spread in single precision: the F6/F7 rough-bed case through its fp32
+    program built as shipped (-cl-mad-enable, COCLProgram.cpp:73).  MUSCL-Hancock on wet/dry terrain is chaotic at
+    fp32 resolution (thresholds of 1e-10 m against a level ulp of 3e-8 m): strict and shipped builds part by
+    RMSE 2.8e-4 m / max 1.2e-2 m after 200 iterations, Godunov by 5e-8 m."""
+    st, bed, man = syn.s_rough(64, 64, dtype=np.float32, manning=None)
+    out = {}
+    for scheme, sname in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch")):
+        sim = oracle.RefSim(64, 64, scheme=scheme, precision="f32", mad=True)
+        sim.upload(st, bed, man)
+        sim.set_target(1e9)
+        sim.run(200)
+        out[f"{sname}_q_state200"] = sim.download()
+        out[f"{sname}_q_t"] = np.array(sim.scalars()["t"])
+    save("f6_f7_bracket_f32_mad", **out)
+
+
 def time_control(precision, tag):
     """F8: tst_Advance_Normal / tst_UpdateTimestep scalar traces driven with prescribed wave speeds."""
     real = np.float64 if precision == "f64" else np.float32
@@ -408,6 +425,7 @@ def disabled_cells(tag="f64"):
 JOBS = [
     ("f1", lambda: [function_level(p, p) for p in ("f64", "f32")]),      # f1..f5
     ("f6", lambda: [trajectories(p, p) for p in ("f64", "f32")] + [trajectories("f64", "f64_mad", mad=True)]),
+    ("f6b", fp32_bracket),
     ("f8", lambda: [time_control(p, p) for p in ("f64", "f32")]),
     ("f9", lambda: [rain(p, p) for p in ("f64", "f32")]),
     ("f11", lambda: [cell_boundary(p, p) for p in ("f64", "f32")]),

@@ -46,8 +46,19 @@ def test_fp32_rough_bed_vs_oracle_and_fixture(scheme, key, kernel, mode):
     r, m = rmse_max(depth_of(out, bed), depth_of(ref.download(), bed))
     t_gpu, t_ref = dom.read_scalars()["time"], ref.scalars()["t"]
     record("fp32_rough64_200", scheme=scheme, kernel=kernel, mode=MODE_NAME[mode], rmse=r, max=m, t_gpu=t_gpu, t_ref=t_ref)
-    assert r < 1e-4, (r, m)
     assert abs(t_gpu - t_ref) <= 1e-4 * t_ref
+    if scheme == hp.SCHEME_MUSCL_HANCOCK:
+        # MUSCL-Hancock on wet/dry terrain is chaotic at fp32 resolution (dry thresholds of 1e-10 m against a level ulp
+        # of 3e-8 m): the reference's own fp32 program built strict and as shipped (-cl-mad-enable, COCLProgram.cpp:73)
+        # parts by RMSE 2.8e-4 m / max 1.2e-2 m on this very case (fixture f6_f7_bracket_f32_mad).  The engine is held
+        # to that bracket (STRICT, which rounds like the strict build, to the 1e-4 of SURVEY 8d).
+        gm = load_golden("f6_f7_bracket_f32_mad")
+        br, bm = rmse_max(depth_of(g["mch_q_state200"], bed), depth_of(gm["mch_q_state200"], bed))
+        assert 1e-4 < br < 1e-3                                        # the reference's own spread, as recorded
+        limit = 1e-4 if mode == hp.MATH_STRICT else 1.5 * br
+        assert r < limit and m < (1.5 * bm if mode == hp.MATH_FAST else 1e-2), (r, m, br, bm)
+    else:
+        assert r < 1e-4, (r, m)
     if scheme == hp.SCHEME_GODUNOV:
         # the fixture is what the reference's fp32 program produced (MUSCL's is order dependent on rough terrain, Q6)
         r2, m2 = rmse_max(depth_of(out, bed), depth_of(g[f"{key}_state200"], bed))
@@ -95,7 +106,7 @@ def test_fp32_rain_fixture(kernel, mode):
         dg, dr = depth_of(out, g["bed"]), depth_of(g[f"{name}_state"], g["bed"])
         r, m = rmse_max(dg, dr)
         t_gpu, t_ref = dom.read_scalars()["time"], float(g[f"{name}_t"])
-        record("fp32_rain_f9", name=name, kernel=kernel, mode=MODE_NAME[mode], rmse=r, max=m, mean_depth=float(dr.mean()),
+        record("fp32_rain_f9", boundary=name, kernel=kernel, mode=MODE_NAME[mode], rmse=r, max=m, mean_depth=float(dr.mean()),
                t_gpu=t_gpu, t_ref=t_ref)
         assert dr.max() > 1e-4 and np.isfinite(out).all()
         assert r < 1e-4 and r < 0.05 * dr.mean(), (name, r, m, dr.mean())
