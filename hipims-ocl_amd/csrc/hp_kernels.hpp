@@ -190,8 +190,22 @@ __device__ __forceinline__ float buf_load_scalar(__amdgpu_buffer_rsrc_t r, const
 {
 	return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
-__device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff)
+// Store-data hazard.  On gfx950 a 16-byte buffer store reads its data VGPRs over several cycles AFTER it has issued;
+// a VALU instruction that overwrites one of them in the very next slot corrupts what lanes 12-15 of every 16-lane row
+// store (seen in round 2 as depth instead of level in z, fp32, 4096^2 and up, when `h = z - zb` of the CFL epilogue
+// reused z's register directly behind the store: the compiler's hazard recogniser exempts stores whose soffset is an
+// SGPR, as ours is).  The data registers are therefore kept alive through two wait states behind the store.
+__device__ __forceinline__ void store_data_fence(const hp_u32x4& a)
 {
+	asm volatile("s_nop 1" : : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w) : "memory");
+}
+
+// `voff` selects per lane between the cell's offset and HP_OOB (dropped by the range check); it is pinned in a VGPR so
+// that the compiler cannot turn the select into two exec-masked stores (memory instructions under divergent control
+// flow make the s_waitcnt vmcnt bookkeeping conservative).
+__device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgpu_buffer_rsrc_t r, unsigned voff, const unsigned soff)
+{
+	asm volatile("" : "+v"(voff));
 	hp_u32x4 a, b;
 	a.x = (unsigned)__double2loint(s.z);  a.y = (unsigned)__double2hiint(s.z);
 	a.z = (unsigned)__double2loint(s.zmax); a.w = (unsigned)__double2hiint(s.zmax);
@@ -199,25 +213,50 @@ __device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgp
 	b.z = (unsigned)__double2loint(s.qy); b.w = (unsigned)__double2hiint(s.qy);
 	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, 0);
 	__builtin_amdgcn_raw_buffer_store_b128(b, r, (int)voff + 16, (int)soff, 0);
+	store_data_fence(a);
+	store_data_fence(b);
 }
-__device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff)
+__device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu_buffer_rsrc_t r, unsigned voff, const unsigned soff)
 {
+	asm volatile("" : "+v"(voff));
 	hp_u32x4 a;
 	a.x = __float_as_uint(s.z); a.y = __float_as_uint(s.zmax); a.z = __float_as_uint(s.qx); a.w = __float_as_uint(s.qy);
 	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, 0);
+	store_data_fence(a);
 }
 
 constexpr int MARCH_COLS = 62;          // updated columns per wavefront (lanes 1..62)
 
+// Neighbour-lane moves.  A lane's column neighbours live in the adjacent lanes of the same wavefront; their values
+// arrive through DPP wavefront shifts (one v_mov_b32_dpp per dword, a VALU instruction) instead of a trip through the
+// LDS crossbar (ds_bpermute: an LDS instruction, an address VGPR and an lgkmcnt wait per batch).  Lanes without a
+// neighbour (63 for east, 0 for west) keep their own value -- they are halo lanes, and keeping a sane value there
+// keeps them out of the way of the wave-uniform fast paths.  (Directions verified on MI355X: tools/dpp_probe.)
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;     // dst[i] = src[i+1] / dst[i] = src[i-1]
+template <int CTRL> __device__ __forceinline__ int lane_move(const int v)
+{
+	return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ float lane_move(const float v)
+{
+	return __int_as_float(lane_move<CTRL>(__float_as_int(v)));
+}
+template <int CTRL> __device__ __forceinline__ double lane_move(const double v)
+{
+	return __hiloint2double(lane_move<CTRL>(__double2hiint(v)), lane_move<CTRL>(__double2loint(v)));
+}
+template <typename V> __device__ __forceinline__ V from_east(const V v) { return lane_move<DPP_WAVE_SHL1>(v); }   // lane + 1
+template <typename V> __device__ __forceinline__ V from_west(const V v) { return lane_move<DPP_WAVE_SHR1>(v); }   // lane - 1
+
 template <typename T> struct RowRegs { State4<T> c; T zb, n; };
 
 template <typename T>
-__device__ __forceinline__ Side<T> shfl_side(const Side<T>& s, const int src_lane)
+__device__ __forceinline__ Side<T> side_from_east(const Side<T>& s)
 {
 	Side<T> r;
-	r.eta = __shfl(s.eta, src_lane, 64); r.zb = __shfl(s.zb, src_lane, 64);
-	r.qx = __shfl(s.qx, src_lane, 64);   r.qy = __shfl(s.qy, src_lane, 64);
-	r.u0 = __shfl(s.u0, src_lane, 64);   r.v0 = __shfl(s.v0, src_lane, 64);
+	r.eta = from_east(s.eta); r.zb = from_east(s.zb);
+	r.qx = from_east(s.qx);   r.qy = from_east(s.qy);
+	r.u0 = from_east(s.u0);   r.v0 = from_east(s.v0);
 	return r;
 }
 
@@ -279,7 +318,6 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	const long x = strip * MARCH_COLS + lane;
 	const long xc = (x < p.cols) ? x : (p.cols - 1);                               // clamp halo lanes past the grid
 	const bool out_x = lane >= 1 && lane <= MARCH_COLS && x <= p.cols - 2;         // x >= 1 is implied
-	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
 
 	const T dt = sc->dt, vs = p.vs;
 	const bool skip_step = dt <= T(0);                                             // CLSchemeGodunov.clc:201-206
@@ -338,15 +376,15 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 
 		if (!skip_step) {
 			// east face first: its result has to travel to the next lane while the north face is solved
-			const Side<T> sE = shfl_side(sC, lane_e);
+			const Side<T> sE = side_from_east(sC);
 			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sC, sE, vs);
 			const FaceFlux<T> fE = fx.forL, forW = fx.forR;
 			FaceFlux<T> fW;
-			fW.f0 = __shfl(forW.f0, lane_w, 64); fW.fx = __shfl(forW.fx, lane_w, 64);
-			fW.fy = __shfl(forW.fy, lane_w, 64); fW.eta_nb = __shfl(forW.eta_nb, lane_w, 64);
-			fW.zb_nb = __shfl(forW.zb_nb, lane_w, 64);
+			fW.f0 = from_west(forW.f0); fW.fx = from_west(forW.fx);
+			fW.fy = from_west(forW.fy); fW.eta_nb = from_west(forW.eta_nb);
+			fW.zb_nb = from_west(forW.zb_nb);
 			const bool dryC = (rc.c.z - rc.zb) < vs;
-			const int flags = __shfl((int)forW.stop | ((int)dryC << 1), lane_w, 64);
+			const int flags = from_west((int)forW.stop | ((int)dryC << 1));
 			fW.stop = (flags & 1) != 0;
 			const bool dryW = (flags & 2) != 0;
 			const bool dryE = (sE.eta - sE.zb) < vs;
@@ -437,10 +475,14 @@ template <typename T>
 __device__ __forceinline__ Raw<T> raw_of(const RowRegs<T>& r) { return Raw<T>{r.c.z, r.c.zmax, r.c.qx, r.c.qy, r.zb}; }
 
 template <typename T>
-__device__ __forceinline__ Raw<T> shfl_raw(const Raw<T>& r, const int src_lane)
+__device__ __forceinline__ Raw<T> raw_from_east(const Raw<T>& r)
 {
-	return Raw<T>{__shfl(r.z, src_lane, 64), __shfl(r.zmax, src_lane, 64), __shfl(r.qx, src_lane, 64),
-	              __shfl(r.qy, src_lane, 64), __shfl(r.zb, src_lane, 64)};
+	return Raw<T>{from_east(r.z), from_east(r.zmax), from_east(r.qx), from_east(r.qy), from_east(r.zb)};
+}
+template <typename T>
+__device__ __forceinline__ Raw<T> raw_from_west(const Raw<T>& r)
+{
+	return Raw<T>{from_west(r.z), from_west(r.zmax), from_west(r.qx), from_west(r.qy), from_west(r.zb)};
 }
 
 // waves per SIMD the register allocator is asked to make room for: the FAST fp64 flavour fits three once its waiting
@@ -468,7 +510,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	const long x = strip * MUSCL_COLS + lane;
 	const long xc = (x < p.cols) ? x : (p.cols - 1);
 	const bool out_x = lane >= 2 && lane <= MUSCL_COLS + 1 && x <= p.cols - 3;
-	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
 
 	const T dt = sc->dt, vs = p.vs;
 	const bool skip_step = dt <= T(0);                                             // :576-577, :69-70
@@ -497,7 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	};
 	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w) {
 		const Raw<T> c = raw_of(mid);
-		const Raw<T> e = shfl_raw(c, lane_e), w = shfl_raw(c, lane_w);
+		const Raw<T> e = raw_from_east(c), w = raw_from_west(c);
 		dry_e = e.zmax < vs;                                                       // :633 tests Zmax, not depth (Q6)
 		dry_w = w.zmax < vs;
 		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs);
@@ -554,14 +595,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			// east face: my E-face state against the east neighbour's W-face state
 			const Side<T> sE_mine = side_from_face<STRICT>(pc_e, rc.c.qx, rc.c.qy, vs);
 			const Side<T> sW_mine = side_from_face<STRICT>(pc_w, rc.c.qx, rc.c.qy, vs);
-			const Side<T> sE_nb = shfl_side(sW_mine, lane_e);
+			const Side<T> sE_nb = side_from_east(sW_mine);
 			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sE_mine, sE_nb, vs);
 			const FaceFlux<T> fE = fx.forL, forW = fx.forR;
 			FaceFlux<T> fW;
-			fW.f0 = __shfl(forW.f0, lane_w, 64); fW.fx = __shfl(forW.fx, lane_w, 64);
-			fW.fy = __shfl(forW.fy, lane_w, 64); fW.eta_nb = __shfl(forW.eta_nb, lane_w, 64);
-			fW.zb_nb = __shfl(forW.zb_nb, lane_w, 64);
-			fW.stop = __shfl((int)forW.stop, lane_w, 64) != 0;
+			fW.f0 = from_west(forW.f0); fW.fx = from_west(forW.fx);
+			fW.fy = from_west(forW.fy); fW.eta_nb = from_west(forW.eta_nb);
+			fW.zb_nb = from_west(forW.zb_nb);
+			fW.stop = from_west((int)forW.stop) != 0;
 
 			// north face: my N-face state against the north neighbour's S-face state
 			const Side<T> sN_mine = side_from_face<STRICT>(pc_n, rc.c.qx, rc.c.qy, vs);
@@ -638,7 +679,6 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 	const long x = strip * MARCH_COLS + lane;
 	const long xc = (x < p.cols) ? x : (p.cols - 1);
 	const bool out_x = lane >= 1 && lane <= MARCH_COLS && x <= p.cols - 2;
-	const int lane_e = (lane < 63) ? lane + 1 : 63, lane_w = (lane > 0) ? lane - 1 : 0;
 
 	const T dt = sc->dt, vs = p.vs;
 	const bool skip_step = dt <= T(0);                                             // :61-62
@@ -683,14 +723,14 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 		State4<T> out = rc.c;
 		bool write = out_x;
 
-		const T zE = __shfl(rc.c.z, lane_e, 64), bE = __shfl(rc.zb, lane_e, 64), qxE = __shfl(rc.c.qx, lane_e, 64);
-		const T zW = __shfl(rc.c.z, lane_w, 64), bW = __shfl(rc.zb, lane_w, 64);
+		const T zE = from_east(rc.c.z), bE = from_east(rc.zb), qxE = from_east(rc.c.qx);
+		const T zW = from_west(rc.c.z), bW = from_west(rc.zb);
 		const T qN = flux(rc.n, rn.c.qy, rn.c.z, rn.zb, rc.c.z, rc.zb);            // :104-112
 		const T qE = flux(rc.n, qxE, zE, bE, rc.c.z, rc.zb);                       // :114-122
 		T qS, qW;
 		if (uniform_n) {                                                           // wave-uniform
 			qS = qS_carry;
-			qW = __shfl(qE, lane_w, 64);
+			qW = from_west(qE);
 		} else {
 			qS = flux(rc.n, rc.c.qy, rc.c.z, rc.zb, zS, bS);                       // :124-132
 			qW = flux(rc.n, rc.c.qx, rc.c.z, rc.zb, zW, bW);                       // :134-142

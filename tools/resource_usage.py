@@ -21,8 +21,8 @@ for line in out.splitlines():
         cur[k.strip()] = v.strip()
 names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-print(f"{'kernel':70s} VGPR AGPR SGPR scratch   LDS occ")
+print(f"{'kernel':70s} VGPR AGPR SGPR scratch   LDS occ  sgpr-spill vgpr-spill")
 for r, n in zip(rows, names):
     n = re.sub(r"\(.*", "", n).replace("void hp::", "")
     if flt in n:
-        print(f"{n:70s} {r.get('VGPRs','?'):>4} {r.get('AGPRs','?'):>4} {r.get('SGPRs','?'):>4} {r.get('ScratchSize [bytes/lane]','?'):>7} {r.get('LDS Size [bytes/block]','?'):>5} {r.get('Occupancy [waves/SIMD]','?'):>3}")
+        print(f"{n:70s} {r.get('VGPRs','?'):>4} {r.get('AGPRs','?'):>4} {r.get('TotalSGPRs','?'):>4} {r.get('ScratchSize [bytes/lane]','?'):>7} {r.get('LDS Size [bytes/block]','?'):>5} {r.get('Occupancy [waves/SIMD]','?'):>3} {r.get('SGPRs Spill','?'):>10} {r.get('VGPRs Spill','?'):>10}")
