@@ -535,9 +535,21 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 	Faces<T> f; f.n = cc; f.e = cc; f.s = cc; f.w = cc;
 	const bool first = (c.z - c.zb < T(1E-5)) || n.zmax <= T(-9998.0) || e.zmax <= T(-9998.0) ||
 	                   s.zmax <= T(-9998.0) || w.zmax <= T(-9998.0);                    // :325-330
+
+	Face4<T> sx, sy;                                                                    // :343-346
+	sx.z = sx.h = sx.qx = sx.qy = sy.z = sy.h = sy.qx = sy.qy = T(0);
+	if (!first) { sx = limiter<STRICT>(w, c, e, vs); sy = limiter<STRICT>(s, c, n, vs); }
+	// Quiescent water (wave-uniform fast path).  Where every limited slope of every lane is zero -- still or uniformly
+	// moving water over a flat bed, wet/dry fronts (no slopes there, :26-46), first-order cells -- the four face states
+	// equal the cell state, the face fluxes cancel pairwise, the bed-slope term is g/2 (2 eta)(zb - zb) = 0, the half step
+	// changes nothing and the re-extrapolated faces are the cell state again: exactly, in both arithmetic flavours
+	// (+-0.5 * 0 + c = c; x - x = 0; 0 * anything finite = 0).  The rest of the predictor is skipped for the whole
+	// wavefront.  Flood models are mostly such water (and dry land) most of the time.
+	const bool flat = sx.z == T(0) && sx.h == T(0) && sx.qx == T(0) && sx.qy == T(0) &&
+	                  sy.z == T(0) && sy.h == T(0) && sy.qx == T(0) && sy.qy == T(0);
+	if (__all(first || flat)) return f;
 	if (first) return f;
 
-	const Face4<T> sx = limiter<STRICT>(w, c, e, vs), sy = limiter<STRICT>(s, c, n, vs);   // :343-346
 	f.n = face_extrapolate<STRICT>(c.zb, cc, sy, T(+0.5));                                         // :349-352
 	f.e = face_extrapolate<STRICT>(c.zb, cc, sx, T(+0.5));
 	f.s = face_extrapolate<STRICT>(c.zb, cc, sy, T(-0.5));
