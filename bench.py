@@ -4,8 +4,9 @@
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 N = 1 : BASELINE.json configs[1], 4096 x 4096, one MI355X.
 N > 1 : one process per GPU (torch.distributed.run), 1-D row strips with per-step ghost-row exchange and an 8-byte
-        MAX all-reduce over RCCL; weak scaling along the configs' ladder 4096^2 -> 8192x4096 -> 8192^2 -> 16384x8192
-        (configs[3] at N = 8), i.e. 16,777,216 cells per GPU at every N.
+        MAX all-reduce over RCCL, the per-iteration loop run by the library itself (hp_strip_step_batch); weak scaling
+        along the configs' ladder 4096^2 -> 8192x4096 -> 8192^2 -> 16384x8192 (configs[3] at N = 8), i.e. 16,777,216
+        cells per GPU at every N.  `--scaling strong` cuts the 4096^2 grid into N strips instead.
 
 The timed region starts with all inputs resident in HBM.  After the W warm-up steps an untimed, time-based pre-warm
 (--prewarm-s) settles clocks and caches; then EXACTLY K steps are timed `--repeats` times (barrier + device sync on
@@ -32,9 +33,11 @@ BYTES_PER_CELL_STEP = {"f64": 80.0, "f32": 40.0}      # read sta
 LADDER = {1: (4096, 4096), 2: (8192, 4096), 4: (8192, 8192), 8: (16384, 8192)}
 
 
-def grid_for(n_gpus, cols, rows):
+def grid_for(n_gpus, cols, rows, scaling="weak"):
     if cols and rows:
         return cols, rows
+    if scaling == "strong":
+        return LADDER[1]                 # configs[1]'s 4096 x 4096 cut into N strips (north_star's strong-scaling target)
     if n_gpus in LADDER:
         return LADDER[n_gpus]
     return 4096, 4096 * n_gpus
@@ -131,6 +134,8 @@ def main():
     ap.add_argument("--kernel", choices=["auto", "basic"], default="auto")
     ap.add_argument("--workload", choices=["s-dam", "s-rain"], default="s-dam",
                     help="s-dam: BASELINE configs[1..3]; s-rain: configs[4] (initially dry terrain + gridded rainfall, dx = 2 m)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = 16.8 Mcell per GPU along the configs' ladder (default); strong = 4096^2 cut into N strips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-manning-leg", action="store_true")
     ap.add_argument("--repeats", type=int, default=3, help="timed repeats of --steps steps; the median is reported")
@@ -148,7 +153,7 @@ def main():
 
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    cols, rows = grid_for(world, args.cols, args.rows)
+    cols, rows = grid_for(world, args.cols, args.rows, args.scaling)
     scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
     # the partial-inertial scheme is only meaningful for a gentle step (2.0 m | 1.6 m instead of 10 m | 1 m)
     levels = (2.0, 1.6) if args.scheme == "inertial" else (10.0, 1.0)
@@ -235,14 +240,14 @@ def main():
         out = {
             "metric": "Mcell-steps/sec fp64 Godunov+HLLC, 4096^2 grid, 1/2/4/8 MI355X; % HBM roofline",
             "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "repeats_ms_per_step": [r[0] / args.steps * 1e3 for r in runs],
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{'S-RAIN gridded-rainfall on dry terrain' if args.workload == 's-rain' else 'S-DAM flat-DEM dam-break'} "
                                    f"{cols}x{rows}{'' if levels[0] == 10.0 else ' (levels %g|%g m)' % levels}, "
                                    f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
-                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
+                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + (f", per-iteration loop: {getattr(runner, 'loop', 'batch call')}" if world > 1 else "") + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
                                                                 else " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"),
                        "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

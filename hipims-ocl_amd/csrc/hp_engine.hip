@@ -6,6 +6,8 @@
 #include "../../include/hipims_mi.h"
 #include "hp_kernels.hpp"
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library itself is dlopen'ed (hp_comm_load)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -20,6 +22,20 @@ using namespace hp;
 namespace {
 
 thread_local std::string g_last_error;
+
+// RCCL entry points, resolved by hp_comm_load
+struct Rccl {
+	void* handle = nullptr;
+	decltype(&ncclGetUniqueId)   GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank)  CommInitRank = nullptr;
+	decltype(&ncclCommDestroy)   CommDestroy = nullptr;
+	decltype(&ncclGroupStart)    GroupStart = nullptr;
+	decltype(&ncclGroupEnd)      GroupEnd = nullptr;
+	decltype(&ncclSend)          Send = nullptr;
+	decltype(&ncclRecv)          Recv = nullptr;
+	decltype(&ncclAllReduce)     AllReduce = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+} g_rccl;
 
 int fail(int code, const std::string& msg)
 {
@@ -85,6 +101,10 @@ struct hp_domain {
 	hipStream_t      stream_halo = nullptr;
 	hipEvent_t       ev_fork = nullptr, ev_halo = nullptr;
 	bool             fork_is_advance = false;         // ev_fork was recorded BY the last advance_time launch
+	// strip decomposition driven from C++ (hp_strip_*): one RCCL communicator over the ranks, strip neighbours = rank +- 1
+	ncclComm_t       comm = nullptr;
+	int              comm_rank = 0, comm_world = 1;
+	hipEvent_t       ev_xchg = nullptr;               // ghost rows of the iteration in flight have arrived
 };
 
 namespace {
@@ -120,23 +140,38 @@ template <typename T> int apply_boundaries(hp_domain* d, void* target)
 	const bool truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
 	size_t want = ((size_t)p.cols * p.rows + 255) / 256;
 	const dim3 block(256), grid((unsigned)(want < 1024 ? want : 1024));
+	// consecutive uniform / gridded boundaries go out as ONE launch (bdy_area); cell boundaries keep their place in
+	// the order added (the reference's order is unspecified, quirk Q7; ours is the order of the hp_boundary_add_* calls)
+	AreaBdyList<T> list;
+	list.count = 0;
+	auto flush = [&]() {
+		if (list.count == 0) return;
+		hipLaunchKernelGGL(bdy_area<T>, grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars, list, (State4<T>*)target,
+		                   (const T*)d->bed, truncated);
+		list.count = 0;
+	};
 	for (const Boundary& b : d->bdy) {
 		if (b.kind == 2) {
+			flush();
 			CellBdy<T> c{(const unsigned long long*)b.cells, b.count, (const T*)b.data, b.entries, b.definition,
 			             b.discharge_def, (T)b.interval, (T)b.length};
 			hipLaunchKernelGGL(bdy_cell<T>, dim3((unsigned)((b.count + 63) / 64)), dim3(64), 0, d->stream, p,
 			                   (const Scalars<T>*)d->scalars, c, (State4<T>*)target, (const T*)d->bed);
-		} else if (b.kind == 0) {
-			UniformBdy<T> u{(const T*)b.data, (uint32_t)b.entries, b.definition, (T)b.interval, (T)b.length};
-			hipLaunchKernelGGL(bdy_uniform<T>, grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars, u,
-			                   (State4<T>*)target, (const T*)d->bed, truncated);
+			continue;
+		}
+		if (list.count == AREA_BDY_MAX) flush();
+		AreaBdy<T>& a = list.b[list.count++];
+		a = AreaBdy<T>{};
+		if (b.kind == 0) {
+			a.kind = 0;
+			a.u = UniformBdy<T>{(const T*)b.data, (uint32_t)b.entries, b.definition, (T)b.interval, (T)b.length};
 		} else {
-			GriddedBdy<T> g{(const T*)b.data, b.entries, b.grows, b.gcols, b.definition,
-			                (T)b.resolution, (T)b.off_x, (T)b.off_y, (T)b.interval};
-			hipLaunchKernelGGL(bdy_gridded<T>, grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars, g,
-			                   (State4<T>*)target, truncated);
+			a.kind = 1;
+			a.g = GriddedBdy<T>{(const T*)b.data, b.entries, b.grows, b.gcols, b.definition,
+			                    (T)b.resolution, (T)b.off_x, (T)b.off_y, (T)b.interval};
 		}
 	}
+	flush();
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -632,6 +667,8 @@ int hp_domain_destroy(hp_domain_t* d)
 	if (d->ev_stop) hipEventDestroy(d->ev_stop);
 	if (d->ev_fork) hipEventDestroy(d->ev_fork);
 	if (d->ev_halo) hipEventDestroy(d->ev_halo);
+	if (d->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(d->comm);
+	if (d->ev_xchg) hipEventDestroy(d->ev_xchg);
 	if (d->stream_halo) hipStreamDestroy(d->stream_halo);
 	if (d->stream) hipStreamDestroy(d->stream);
 	delete d;
@@ -979,6 +1016,179 @@ int hp_stream_halo(hp_domain_t* d, void** hip_stream)
 	*hip_stream = (void*)d->stream_halo;
 	return HP_OK;
 }
+
+} // extern "C"
+
+// ---- RCCL, loaded at run time: the engine has no link-time dependency on a collective library, and a process that
+//      already carries one (torch bundles its own librccl, bound to its own HIP runtime) keeps using that copy ----
+namespace {
+
+int rccl_ready()
+{
+	return g_rccl.handle ? HP_OK : fail(HP_ERR_STATE, "no collective library loaded: call hp_comm_load first");
+}
+#define RCCL_TRY(expr)                                                                                 \
+	do {                                                                                               \
+		ncclResult_t r_ = (expr);                                                                      \
+		if (r_ != ncclSuccess)                                                                         \
+			return fail(HP_ERR_HIP, std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error")); \
+	} while (0)
+
+// ghost rows per interior side
+inline long strip_ghosts(const hp_domain* d) { return d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK ? 2 : 1; }
+
+// Ghost-row exchange of the iteration in flight + the all-reduce of the wave-speed maximum, queued behind the flux
+// launches of hp_step_begin (CDomainLink::pullFromBuffer / pushToBuffer + MPI_Allreduce(MIN), CMPIManager.cpp:852-861).
+int strip_exchange(hp_domain* d, bool reduce)
+{
+	const long g = strip_ghosts(d), rows = d->desc.rows;
+	const size_t row_elems = (size_t)d->desc.cols * 4, count = (size_t)g * row_elems;
+	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
+	char* state = (char*)d->state[d->use_alt ^ 1];                    // the buffer the iteration in flight writes
+	const size_t row_bytes = row_elems * d->esize;
+	const bool south = d->comm_rank > 0, north = d->comm_rank < d->comm_world - 1;
+	// the rows the neighbours need come from the halo part of the step: the transfer is ordered after that stream only
+	hipStream_t xs = d->halo_overlap ? d->stream_halo : d->stream;
+	if (south || north) {
+		RCCL_TRY(g_rccl.GroupStart());
+		if (south) {
+			RCCL_TRY(g_rccl.Send(state + (size_t)g * row_bytes, count, type, d->comm_rank - 1, d->comm, xs));            // my first owned rows
+			RCCL_TRY(g_rccl.Recv(state, count, type, d->comm_rank - 1, d->comm, xs));                                     // into my south ghost rows
+		}
+		if (north) {
+			RCCL_TRY(g_rccl.Send(state + (size_t)(rows - 2 * g) * row_bytes, count, type, d->comm_rank + 1, d->comm, xs));  // my last owned rows
+			RCCL_TRY(g_rccl.Recv(state + (size_t)(rows - g) * row_bytes, count, type, d->comm_rank + 1, d->comm, xs));       // into my north ghost rows
+		}
+		RCCL_TRY(g_rccl.GroupEnd());
+		if (xs != d->stream) {
+			HIP_TRY(hipEventRecord(d->ev_xchg, xs));
+			HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_xchg, 0));      // hp_step_end (and the next iteration) need the rows
+		}
+	}
+	// the maximum is new only when the reduction priced a buffer that changed (hp_step_needs_reduction); the decision
+	// is the same on every rank (same iteration parity), so either all ranks enter the collective or none does
+	if (reduce && d->comm_world > 1)
+		RCCL_TRY(g_rccl.AllReduce(d->cfl_slot, d->cfl_slot, 1, type, ncclMax, d->comm, d->stream));
+	return HP_OK;
+}
+} // namespace
+
+extern "C" {
+
+int hp_comm_load(const char* library_path)
+{
+	if (g_rccl.handle) return HP_OK;
+	const char* candidates[] = {library_path, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+	void* h = nullptr;
+	for (const char* c : candidates) {
+		if (!c || !*c) continue;
+		h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+		if (h) break;
+	}
+	if (!h) return fail(HP_ERR_UNSUPPORTED, std::string("cannot load the RCCL library: ") + (dlerror() ? dlerror() : "not found"));
+	Rccl r;
+	r.handle = h;
+#define SYM(name) r.name = (decltype(r.name))dlsym(h, "nccl" #name); if (!r.name) { dlclose(h); return fail(HP_ERR_UNSUPPORTED, "RCCL library lacks nccl" #name); }
+	SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(GroupStart) SYM(GroupEnd) SYM(Send) SYM(Recv) SYM(AllReduce) SYM(GetErrorString)
+#undef SYM
+	g_rccl = r;
+	return HP_OK;
+}
+
+int hp_comm_unique_id(void* id_out)
+{
+	int rc = rccl_ready();
+	if (rc != HP_OK) return rc;
+	if (!id_out) return fail(HP_ERR_INVALID, "id_out == NULL");
+	static_assert(sizeof(ncclUniqueId) == HP_COMM_ID_BYTES, "HP_COMM_ID_BYTES");
+	ncclUniqueId id;
+	RCCL_TRY(g_rccl.GetUniqueId(&id));
+	std::memcpy(id_out, &id, sizeof id);
+	return HP_OK;
+}
+
+int hp_strip_comm_init(hp_domain_t* d, const void* id, int rank, int world)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if ((rc = rccl_ready()) != HP_OK) return rc;
+	if (!id || world < 1 || rank < 0 || rank >= world) return fail(HP_ERR_INVALID, "bad communicator arguments");
+	if (d->comm) return fail(HP_ERR_STATE, "the domain already has a communicator");
+	// the strip's place in the global grid must agree with its rank: neighbours are rank - 1 (south) and rank + 1 (north)
+	const bool has_south = d->desc.row_offset > 0, has_north = d->desc.row_offset + d->desc.rows < d->desc.global_rows;
+	if (has_south != (rank > 0) || has_north != (rank < world - 1))
+		return fail(HP_ERR_INVALID, "rank does not match the strip's position in the global grid");
+	ncclUniqueId uid;
+	std::memcpy(&uid, id, sizeof uid);
+	RCCL_TRY(g_rccl.CommInitRank(&d->comm, world, uid, rank));
+	d->comm_rank = rank; d->comm_world = world;
+	if (!d->ev_xchg) HIP_TRY(hipEventCreateWithFlags(&d->ev_xchg, hipEventDisableTiming));
+	d->halo_overlap = world > 1;
+	return HP_OK;
+}
+
+int hp_strip_comm_destroy(hp_domain_t* d)
+{
+	if (!d) return HP_OK;
+	if (d->comm) {
+		hipStreamSynchronize(d->stream);
+		if (d->stream_halo) hipStreamSynchronize(d->stream_halo);
+		if (g_rccl.CommDestroy) g_rccl.CommDestroy(d->comm);
+		d->comm = nullptr;
+	}
+	d->comm_world = 1; d->comm_rank = 0;
+	return HP_OK;
+}
+
+int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
+{
+	const bool fork_ready = d && d->fork_is_advance;
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!d->comm) return fail(HP_ERR_STATE, "hp_strip_step_batch without hp_strip_comm_init");
+	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	d->fork_is_advance = fork_ready;
+	for (uint32_t i = 0; i < n_iterations; ++i) {
+		if ((rc = dispatch_begin(d)) != HP_OK) return rc;
+		if ((rc = strip_exchange(d, d->adv_fresh != 0)) != HP_OK) return rc;
+		if ((rc = dispatch_end(d)) != HP_OK) return rc;
+		// the exchange sits between advance_time and the next flux launch on the stream graph: its event, not
+		// advance_time's, is what the next halo launch may fork from only if nothing else was queued -- keep it simple
+		// and let hp_step_begin record its own fork event whenever a transfer was queued on the domain's stream
+		if (!d->halo_overlap) d->fork_is_advance = false;
+	}
+	return HP_OK;
+}
+
+int hp_strip_update_timestep(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!d->comm) return fail(HP_ERR_STATE, "hp_strip_update_timestep without hp_strip_comm_init");
+	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	// tst_Reduce over the owned rows of the primary buffer, the maximum over all strips, then tst_UpdateTimestep on every
+	// rank redundantly (CSchemeGodunov.cpp:1189-1195, :1254-1260 with CMPIManager's reduction in between)
+	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
+	if (d->desc.precision == 8) {
+		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+	} else {
+		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+	}
+	if (d->desc.dynamic_dt && d->comm_world > 1)
+		RCCL_TRY(g_rccl.AllReduce(d->cfl_slot, d->cfl_slot, 1, type, ncclMax, d->comm, d->stream));
+	if (d->desc.precision == 8)
+		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
+		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, 1);
+	else
+		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
+		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, 1);
+	HIP_TRY(hipGetLastError());
+	return HP_OK;
+}
+
+} // extern "C"
+
+extern "C" {
 
 int hp_timer_start(hp_domain_t* d)
 {

@@ -919,6 +919,75 @@ __global__ __launch_bounds__(256) void bdy_gridded(const Params<T> p, const Scal
 	}
 }
 
+// All consecutive uniform / gridded boundaries of an iteration in ONE launch: a cell is read once, every boundary is
+// applied to it in the order added (each exactly as bdy_uniform / bdy_gridded would, gate and all), and written once.
+// Per cell this is the same sequence of operations as the separate launches, so results are bit-identical; what goes
+// away is one launch and one 64 B/cell pass per boundary (the reference's example model has two: rain and drainage).
+constexpr int AREA_BDY_MAX = 8;
+template <typename T> struct AreaBdy {
+	int kind;                      // 0 uniform, 1 gridded
+	UniformBdy<T> u;
+	GriddedBdy<T> g;
+};
+template <typename T> struct AreaBdyList { int count; AreaBdy<T> b[AREA_BDY_MAX]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void bdy_area(const Params<T> p, const Scalars<T>* __restrict__ sc, const AreaBdyList<T> list,
+                                                State4<T>* __restrict__ state, const T* __restrict__ bed, const bool truncated)
+{
+	const T t = sc->t, dt_real = sc->dt, dt = sc->t_hydro;
+	if (dt < T(1.0)) return;                                                      // CLBoundaries.clc:165, :224 (uniform over the grid)
+	// per boundary: is it active this iteration, and (uniform) how much does it add / remove
+	bool active[AREA_BDY_MAX];
+	T amount[AREA_BDY_MAX];
+	unsigned long slice[AREA_BDY_MAX];
+	bool any = false;
+	for (int k = 0; k < list.count; ++k) {
+		const AreaBdy<T>& b = list.b[k];
+		active[k] = false; amount[k] = T(0); slice[k] = 0;
+		if (b.kind == 0) {
+			if (dt_real <= T(0) || t >= b.u.length) continue;                     // :165-168
+			unsigned long ts = (unsigned long)floor_(t / b.u.interval);           // :172-173
+			if (ts >= b.u.entries) ts = b.u.entries - 1;
+			amount[k] = b.u.series[2 * ts + 1] / T(3600000.0) * dt;
+			active[k] = true;
+		} else {
+			unsigned long ts = (unsigned long)floor_(t / b.g.interval);           // :228
+			if (ts >= b.g.entries) ts = b.g.entries - 1;
+			slice[k] = ts;
+			active[k] = true;
+		}
+		any = any || active[k];
+	}
+	if (!any) return;
+	const size_t cells = (size_t)p.cols * p.rows;
+	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x) {
+		const long y = (long)(id / p.cols), x = (long)(id - (size_t)y * p.cols);
+		const long gy = y + p.row_offset;
+		if (!bdy_in_range(p, x, gy, truncated)) continue;
+		State4<T> c = state[id];
+		if (c.zmax <= T(-9999.0)) continue;                                       // :168-169, :220-221 (first half)
+		const T zb = bed[id];
+		for (int k = 0; k < list.count; ++k) {
+			if (!active[k]) continue;
+			const AreaBdy<T>& b = list.b[k];
+			if (b.kind == 0) {
+				if (b.u.definition == 0) c.z += amount[k];                        // :176-177
+				if (b.u.definition == 1) c.z = fmax_(zb, c.z - amount[k]);        // :179-180
+			} else {
+				if (c.z == T(-9999.0)) continue;                                  // :220-221 (second half; re-tested as the level changes)
+				const T col = floor_((((T)x * p.dx) - b.g.off_x) / b.g.resolution);   // :231-232
+				const T row = floor_((((T)gy * p.dx) - b.g.off_y) / b.g.resolution);
+				const unsigned long cell = (b.g.grows * b.g.gcols) * slice[k] + (b.g.gcols * (unsigned long)row) + (unsigned long)col;
+				const T rate = b.g.grids[cell];
+				if (b.g.definition == 0) c.z += rate / T(3600000.0) * dt;         // :238-239
+				if (b.g.definition == 2) c.z += rate / (p.dx * p.dx) * dt;        // :241-242
+			}
+		}
+		state[id] = c;
+	}
+}
+
 // bdy_Cell (Boundaries/CLBoundaries.clc:23-128): imposed depth / level / discharge / velocity / volume on a list of
 // cells with linear interpolation in time.  Cell ids are global; a strip applies the ones it stores (ghost rows too).
 template <typename T> struct CellBdy {

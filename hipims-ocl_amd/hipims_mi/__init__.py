@@ -33,7 +33,8 @@ EXPORTS = [
     "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_add_cell", "hp_boundary_clear", "hp_set_target_time", "hp_set_time",
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
     "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_set_halo_overlap",
-    "hp_stream_halo", "hp_timer_start",
+    "hp_stream_halo", "hp_comm_load", "hp_comm_unique_id", "hp_strip_comm_init", "hp_strip_step_batch", "hp_strip_update_timestep",
+    "hp_strip_comm_destroy", "hp_timer_start",
     "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read",
 ]
 
@@ -116,6 +117,12 @@ def load_library(path: str | None = None):
     lib.hp_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.hp_set_halo_overlap.argtypes = [C.c_void_p, C.c_int]
     lib.hp_stream_halo.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.hp_comm_load.argtypes = [C.c_char_p]
+    lib.hp_comm_unique_id.argtypes = [C.c_void_p]
+    lib.hp_strip_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.hp_strip_step_batch.argtypes = [C.c_void_p, C.c_uint32]
+    lib.hp_strip_update_timestep.argtypes = [C.c_void_p]
+    lib.hp_strip_comm_destroy.argtypes = [C.c_void_p]
     lib.hp_timer_start.argtypes = [C.c_void_p]
     lib.hp_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.hp_kernel_timing.argtypes = [C.c_void_p, C.c_int]
@@ -129,6 +136,30 @@ def load_library(path: str | None = None):
 def _check(lib, rc, what):
     if rc != 0:
         raise HipimsError(f"{what} failed ({rc}): {lib.hp_last_error().decode(errors='replace')}")
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_load(path: str | None = None):
+    """Load the collective library for the C++ strip loop (hp_strip_*).  In a torch process the copy torch carries is
+    used, so that one RCCL (bound to one HIP runtime) serves the whole process."""
+    lib = load_library()
+    if path is None:
+        try:
+            import torch
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            path = cand if os.path.exists(cand) else None
+        except ImportError:
+            path = None
+    _check(lib, lib.hp_comm_load(path.encode() if path else None), "hp_comm_load")
+
+
+def comm_unique_id() -> bytes:
+    lib = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib, lib.hp_comm_unique_id(buf), "hp_comm_unique_id")
+    return buf.raw
 
 
 def device_count() -> int:
@@ -286,6 +317,20 @@ class Domain:
         f = C.c_int(0)
         _check(self.lib, self.lib.hp_step_needs_reduction(self.h, C.byref(f)), "hp_step_needs_reduction")
         return bool(f.value)
+
+    # ---- the strip loop in C++ over RCCL (hp_strip_*) ----
+    def strip_comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == COMM_ID_BYTES
+        _check(self.lib, self.lib.hp_strip_comm_init(self.h, unique_id, rank, world), "hp_strip_comm_init")
+
+    def strip_step_batch(self, n):
+        _check(self.lib, self.lib.hp_strip_step_batch(self.h, int(n)), "hp_strip_step_batch")
+
+    def strip_update_timestep(self):
+        _check(self.lib, self.lib.hp_strip_update_timestep(self.h), "hp_strip_update_timestep")
+
+    def strip_comm_destroy(self):
+        _check(self.lib, self.lib.hp_strip_comm_destroy(self.h), "hp_strip_comm_destroy")
 
     def run(self, n):
         """Run n iterations and return the timestep USED by each (one blocking read per iteration: tests only)."""

@@ -25,6 +25,7 @@ run with several processes on ONE GPU, where RCCL refuses to put two ranks; it i
 from __future__ import annotations
 
 import contextlib
+import os
 
 import numpy as np
 
@@ -155,7 +156,7 @@ class StripRunner:
     CPU tests substitute an oracle-backed engine; the default builds the HIP engine."""
 
     def __init__(self, cols, rows, scheme=SCHEME_GODUNOV, precision="f64", rank=0, world=1, device=0,
-                 engine_factory=None, backend=None, init_process_group=True, overlap=None, **kw):
+                 engine_factory=None, backend=None, init_process_group=True, overlap=None, loop=None, **kw):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -179,6 +180,21 @@ class StripRunner:
             if backend == "nccl":
                 kwargs["device_id"] = torch.device("cuda", device)
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        # who runs the per-iteration loop: "cxx" = the library itself over RCCL (hp_strip_step_batch: a handful of
+        # enqueues per iteration, no Python in the loop), "torch" = this class over torch.distributed.  The C++ loop
+        # needs RCCL, i.e. one GPU per rank; rehearsals on a shared GPU (gloo) and the CPU tests use the torch loop.
+        if loop is None:
+            loop = os.environ.get("HIPIMS_MI_STRIP_LOOP", "cxx" if (engine_factory is None and backend == "nccl") else "torch")
+        self.loop = loop
+        if loop == "cxx":
+            if engine_factory is not None or backend != "nccl":
+                raise ValueError("the C++ strip loop runs on the HIP engine over RCCL only")
+            from . import comm_load, comm_unique_id
+            comm_load()
+            box = [comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)        # the id travels by the host's own means (here: torch)
+            self.domain.strip_comm_init(box[0], rank, world)
         self.south = rank - 1 if rank > 0 else None
         self.north = rank + 1 if rank < world - 1 else None
         self.staged = engine_factory is None and backend == "gloo"      # device buffers, host transport (rehearsal)
@@ -273,6 +289,9 @@ class StripRunner:
             req.wait()
 
     def step(self, n):
+        if self.loop == "cxx":
+            self.domain.strip_step_batch(n)
+            return
         dist = self.dist
         for _ in range(n):
             self.engine.step_begin()
@@ -308,6 +327,8 @@ class StripRunner:
         return np.concatenate(out, axis=0)
 
     def close(self):
+        if self.loop == "cxx":
+            self.domain.strip_comm_destroy()
         self.engine.close()
         if self.dist.is_initialized():
             self.dist.destroy_process_group()

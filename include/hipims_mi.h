@@ -215,6 +215,23 @@ int hp_stream(hp_domain_t* d, void** hip_stream);     /* the domain's hipStream_
 int hp_set_halo_overlap(hp_domain_t* d, int on);
 int hp_stream_halo(hp_domain_t* d, void** hip_stream);
 
+/* ---- the strip loop driven from C++ (one process per GPU).  The per-iteration protocol above -- flux launches, ghost
+ *      rows to and from the two strip neighbours, all-reduce(MAX) of the wave speed, time advance -- queued by the
+ *      library itself on RCCL, so that a C++ host (HiPIMS's CModel / CMPIManager) needs no collective code of its own and
+ *      the host cost per iteration is a handful of enqueues.  Replaces CDomainLink::pullFromBuffer / pushToBuffer
+ *      (Domain/Links/CDomainLink.cpp:168-270) and CMPIManager's block exchange and MPI_Allreduce(MIN)
+ *      (MPI/CMPIManager.cpp:555-709, :852-861).  Ranks are ordered south to north: rank k's neighbours are k-1 and k+1.
+ *      The collective library is loaded at run time (dlopen): pass the copy the process already uses (a torch process:
+ *      torch/lib/librccl.so), or NULL for the system's.  The unique id is created on rank 0 and handed to the other
+ *      ranks by the host's own means (MPI_Bcast in HiPIMS, a torch broadcast in this repository's tests). ---- */
+#define HP_COMM_ID_BYTES 128
+int hp_comm_load(const char* rccl_library_path);
+int hp_comm_unique_id(void* id_out /* HP_COMM_ID_BYTES */);
+int hp_strip_comm_init(hp_domain_t* d, const void* id, int rank, int world);   /* collective: every rank calls it; turns the halo overlap on */
+int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations);               /* hp_step_batch for a strip */
+int hp_strip_update_timestep(hp_domain_t* d);                                 /* hp_update_timestep for a strip (collective) */
+int hp_strip_comm_destroy(hp_domain_t* d);
+
 /* ---- measurement hooks (no reference counterpart; COCLDevice has no profiling queue, COCLDevice.cpp:283-288) ----
  * Bracket a region of the domain's stream with HIP events and return the elapsed milliseconds. */
 int hp_timer_start(hp_domain_t* d);

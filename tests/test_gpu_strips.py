@@ -135,6 +135,47 @@ def test_single_rank_nccl_runner_matches_batch_call():
     assert np.array_equal(out, single.download())
 
 
+@pytest.mark.parametrize("scheme", [hp.SCHEME_GODUNOV, hp.SCHEME_MUSCL_HANCOCK])
+def test_cxx_strip_loop_single_rank_matches_batch_call(scheme):
+    """The per-iteration loop run by the library itself over RCCL (hp_comm_load / hp_strip_comm_init /
+    hp_strip_step_batch) with a 1-rank communicator: library loading, unique id, communicator, the all-reduce on the
+    engine's CFL word in stream order -- everything but a neighbour.  Bit-identical to the plain batch call."""
+    import socket
+    import torch
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cols, rows, steps = 300, 180, 120
+    st, bed, man = syn.s_rough(cols, rows, manning=None)
+    r = strips.StripRunner(cols, rows, scheme=scheme, rank=0, world=1, loop="cxx")
+    try:
+        assert r.loop == "cxx"
+        r.upload_global(st, bed, man)
+        r.set_target_time(3.0)                       # runs into the sync point: skipped iterations included
+        r.step(steps)
+        r.barrier()
+        out, sc = r.gather_owned(), r.engine.scalars()
+        r.set_target_time(6.0)
+        r.domain.strip_update_timestep()             # resume from the sync point through the collective form
+        r.step(40)
+        r.barrier()
+        out2, sc2 = r.gather_owned(), r.engine.scalars()
+    finally:
+        r.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    single = hp.Domain(cols, rows, scheme=scheme)
+    single.upload(st, bed, man)
+    single.set_target_time(3.0)
+    single.step_batch(steps)
+    ss = single.read_scalars()
+    assert np.array_equal(out, single.download()) and sc["t"] == ss["time"] and sc["batch_skipped"] == ss["batch_skipped"] > 0
+    single.set_target_time(6.0)
+    single.update_timestep()
+    single.step_batch(40)
+    assert np.array_equal(out2, single.download()) and sc2["t"] == single.read_scalars()["time"]
+
+
 def _torchrun(nproc, script_args, env_extra=None, timeout=600):
     import socket
     import subprocess

@@ -16,7 +16,7 @@ with socket.socket() as s:
     s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 st, bed, man = syn.s_dam(cols, rows)
-r = strips.StripRunner(cols, rows, rank=0, world=1)
+r = strips.StripRunner(cols, rows, rank=0, world=1, loop="torch")
 r.upload_global(st, bed, man); r.set_target_time(1e9)
 def timed(fn, n):
     fn(20); r.barrier(); t0 = time.perf_counter(); fn(n); r.barrier(); return (time.perf_counter() - t0) / n * 1e6

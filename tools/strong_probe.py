@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""One-GPU probe of what ONE rank of a strong-scaling run executes per iteration: the 4096 x 514 strip of the 8-GPU
+split of 4096^2 (default; any shape as argv), through (a) the plain batch call, (b) the library's own strip loop
+(hp_strip_step_batch over a 1-rank RCCL communicator: the all-reduce is real, there is no neighbour), (c) the same with
+the step split into halo and interior launches on two streams.  Prints device time per iteration and the host's
+enqueue cost per iteration (the call returns without waiting)."""
+import os, sys, time, socket
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hipims-ocl_amd"))
+import numpy as np
+import torch
+import hipims_mi as hp
+from hipims_mi import strips, synthetic as syn
+
+cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4096, 514)
+steps = 400
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+st, bed, man = syn.s_dam(cols, rows)
+r = strips.StripRunner(cols, rows, rank=0, world=1, loop="cxx")
+r.upload_global(st, bed, man); r.set_target_time(1e9)
+
+def timed(fn, n):
+    fn(50); r.barrier()
+    t0 = time.perf_counter(); fn(n); host = (time.perf_counter() - t0) / n * 1e6
+    r.barrier(); return (time.perf_counter() - t0) / n * 1e6, host
+
+print("strip %d x %d (%.2f Mcell)" % (cols, rows, cols * rows / 1e6))
+for name, fn, overlap in (("(a) hp_step_batch", lambda n: r.domain.step_batch(n), False),
+                          ("(b) hp_strip_step_batch", lambda n: r.domain.strip_step_batch(n), False),
+                          ("(c) hp_strip_step_batch, split launches", lambda n: r.domain.strip_step_batch(n), True)):
+    r.domain.set_halo_overlap(overlap)
+    dev, host = timed(fn, steps)
+    print("%-42s: %6.1f us/iteration on the device, %5.1f us/iteration host enqueue" % (name, dev, host))
+r.close()
