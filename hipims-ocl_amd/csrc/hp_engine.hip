@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -37,9 +38,14 @@ struct Rccl {
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 } g_rccl;
 
+std::atomic<hp_log_sink_t> g_log_sink{nullptr};
+std::atomic<void*>         g_log_user{nullptr};
+
 int fail(int code, const std::string& msg)
 {
 	g_last_error = msg;
+	if (hp_log_sink_t sink = g_log_sink.load(std::memory_order_acquire))
+		sink(HP_LOG_MODEL_STOP, g_last_error.c_str(), g_log_user.load(std::memory_order_acquire));
 	return code;
 }
 
@@ -490,6 +496,14 @@ extern "C" {
 int hp_abi_version(void) { return HP_ABI_VERSION; }
 
 const char* hp_last_error(void) { return g_last_error.c_str(); }
+
+int hp_set_log_sink(hp_log_sink_t sink, void* user)
+{
+	g_log_sink.store(nullptr, std::memory_order_release);
+	g_log_user.store(user, std::memory_order_release);
+	g_log_sink.store(sink, std::memory_order_release);
+	return HP_OK;
+}
 
 int hp_device_count(int* count)
 {

@@ -28,7 +28,7 @@ DISCHARGE_IGNORE, DISCHARGE_IS_DISCHARGE, DISCHARGE_IS_VELOCITY, DISCHARGE_IS_VO
 PTR_STATE_NEXT_SRC, PTR_STATE_OTHER, PTR_BED, PTR_MANNING, PTR_CFL_MAX, PTR_SCALARS = range(6)
 
 EXPORTS = [
-    "hp_abi_version", "hp_device_count", "hp_device_info", "hp_last_error", "hp_domain_desc_default",
+    "hp_abi_version", "hp_device_count", "hp_device_info", "hp_last_error", "hp_set_log_sink", "hp_domain_desc_default",
     "hp_domain_create", "hp_domain_destroy", "hp_domain_upload", "hp_domain_download", "hp_domain_upload_rows",
     "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_add_cell", "hp_boundary_clear", "hp_set_target_time", "hp_set_time",
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
@@ -41,6 +41,23 @@ EXPORTS = [
 
 class HipimsError(RuntimeError):
     pass
+
+
+LOG_SINK = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)     # hp_log_sink_t
+_log_sink_ref = None
+
+
+def set_log_sink(callback):
+    """Route every failing call's message to `callback(level, text)` (the reference's model::doError ->
+    CLog::writeError place, main.cpp:631-652).  None removes the sink."""
+    global _log_sink_ref
+    lib = load_library()
+    if callback is None:
+        sink = C.cast(None, LOG_SINK)
+    else:
+        sink = LOG_SINK(lambda level, msg, _user: callback(int(level), msg.decode(errors="replace")))
+    _check(lib, lib.hp_set_log_sink(sink, None), "hp_set_log_sink")
+    _log_sink_ref = sink          # keep the trampoline alive while the library may call it
 
 
 class DeviceInfo(C.Structure):
@@ -88,6 +105,7 @@ def load_library(path: str | None = None):
                           f"(make -C hipims-ocl_amd/csrc); there is no CPU fallback")
     lib = C.CDLL(path)
     lib.hp_last_error.restype = C.c_char_p
+    lib.hp_set_log_sink.argtypes = [LOG_SINK, C.c_void_p]
     lib.hp_domain_desc_default.restype = None
     lib.hp_domain_desc_default.argtypes = [C.POINTER(DomainDesc)]
     lib.hp_domain_create.argtypes = [C.POINTER(DomainDesc), C.POINTER(C.c_void_p)]

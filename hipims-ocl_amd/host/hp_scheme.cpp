@@ -4,6 +4,7 @@
 #include "hp_scheme.hpp"
 
 #include <algorithm>
+#include <utility>
 #include <cmath>
 
 namespace hipims_mi {
@@ -48,6 +49,15 @@ void CSchemeMI::addBoundaryGridded(int definition, const std::vector<double>& gr
 	boundaries.push_back({1, definition, grids, entries, gridRows, gridCols, interval, 0, resolution, offsetX, offsetY});
 }
 
+void CSchemeMI::addBoundaryCell(int depthDefinition, int dischargeDefinition, const std::vector<uint64_t>& cells,
+                                const std::vector<double>& series, double interval, double length)
+{
+	PendingBoundary b{2, depthDefinition, series, series.size() / 4, 0, 0, interval, length, 0, 0, 0};
+	b.dischargeDefinition = dischargeDefinition;
+	b.cells = cells;
+	boundaries.push_back(std::move(b));
+}
+
 // prepare1OExecDimensions / Constants / Code / Memory / Kernels / Boundaries collapse into one descriptor
 void CSchemeMI::prepareAll()
 {
@@ -70,8 +80,11 @@ void CSchemeMI::prepareAll()
 	for (const PendingBoundary& b : boundaries) {
 		const int rc = b.kind == 0
 			? hp_boundary_add_uniform(hpDomain, b.definition, b.data.data(), (uint32_t)b.entries, b.interval, b.length)
-			: hp_boundary_add_gridded(hpDomain, b.definition, b.data.data(), b.entries, b.rows, b.cols, b.resolution,
-			                          b.offx, b.offy, b.interval);
+			: b.kind == 1
+			? hp_boundary_add_gridded(hpDomain, b.definition, b.data.data(), b.entries, b.rows, b.cols, b.resolution,
+			                          b.offx, b.offy, b.interval)
+			: hp_boundary_add_cell(hpDomain, b.definition, b.dischargeDefinition, b.cells.data(), b.cells.size(),
+			                       b.data.data(), b.entries, b.interval, b.length);
 		if (!check(rc, "hp_boundary_add")) return;
 	}
 	dCurrentTimestep = dTimestep;

@@ -58,10 +58,15 @@ public:
 	void   setSyncMethod(unsigned char m)    { ucSyncMethod = m; }
 	void   setRollbackLimit(unsigned int n)  { uiRollbackLimit = n; }
 	void   setMathMode(int m)                { iMathMode = m; }
-	// CBoundaryUniform / CBoundaryGridded (atmospheric time series)
+	// CBoundaryUniform / CBoundaryGridded (atmospheric time series) and CBoundaryCell (per-cell level / discharge series,
+	// Boundaries/CBoundaryCell.cpp:140-330: `cells` are ids into cellStates, series = entries x {t, depth/FSL, Qx|Q, Qy})
 	void   addBoundaryUniform(int definition, const std::vector<double>& timeValuePairs, double interval, double length);
 	void   addBoundaryGridded(int definition, const std::vector<double>& grids, uint64_t entries, uint64_t gridRows,
 	                          uint64_t gridCols, double resolution, double offsetX, double offsetY, double interval);
+	void   addBoundaryCell(int depthDefinition, int dischargeDefinition, const std::vector<uint64_t>& cells,
+	                       const std::vector<double>& series, double interval, double length);
+	// model::doError's place (main.cpp:631-652): every failure of the library is also handed to this sink
+	static void setLogSink(hp_log_sink_t sink, void* user) { hp_set_log_sink(sink, user); }
 
 	// ---- the CScheme virtuals CModel drives (CScheme.h:82-129) ----
 	bool   isReady() const                   { return bReady; }
@@ -125,7 +130,8 @@ private:
 	bool         bCellStatesSynced = true;
 
 	struct PendingBoundary { int kind, definition; std::vector<double> data; uint64_t entries, rows, cols;
-	                         double interval, length, resolution, offx, offy; };
+	                         double interval, length, resolution, offx, offy;
+	                         int dischargeDefinition = 0; std::vector<uint64_t> cells; };   // kind 0 uniform, 1 gridded, 2 cell
 	std::vector<PendingBoundary> boundaries;
 };
 

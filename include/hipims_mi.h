@@ -94,6 +94,18 @@ int hp_device_count(int* count);
 int hp_device_info(int device, hp_device_info_t* info);
 const char* hp_last_error(void);
 
+/* Optional log sink, the place model::doError (src/main.cpp:631-652 -> CLog::writeError) has in the reference: every
+ * failing call hands its message to `sink` with the reference's error level (common.h:62-68; failures of this
+ * library are kLevelModelStop = 2) before returning its code, so an adapter can forward to pManager->log without
+ * polling hp_last_error().  Process-wide; NULL removes it.  Called on the thread that made the failing call. */
+#define HP_LOG_FATAL        1
+#define HP_LOG_MODEL_STOP   2
+#define HP_LOG_CONTINUE     4
+#define HP_LOG_WARNING      8
+#define HP_LOG_INFORMATION 16
+typedef void (*hp_log_sink_t)(int level, const char* message, void* user);
+int hp_set_log_sink(hp_log_sink_t sink, void* user);
+
 /* ---- domain: CScheme::prepareAll + the registerConstant set
  *      (Schemes/CSchemeGodunov.cpp:386-470, :666-784; XML parameters :128-333, CScheme.cpp:46-55) ---- */
 typedef struct {

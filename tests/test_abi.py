@@ -55,3 +55,21 @@ def test_descriptor_validation_precedes_device_use():
     h = C.c_void_p()
     assert lib.hp_domain_create(C.byref(d), C.byref(h)) == -1
     assert b"size mismatch" in lib.hp_last_error()
+
+
+def test_log_sink_receives_failures_with_the_reference_error_level():
+    # model::doError(..., kLevelModelStop) is where the reference sends such failures (main.cpp:631-652)
+    lib = hipims_mi.load_library()
+    seen = []
+    hipims_mi.set_log_sink(lambda level, text: seen.append((level, text)))
+    try:
+        d = hipims_mi.DomainDesc()
+        lib.hp_domain_desc_default(C.byref(d))
+        d.struct_size = 4
+        h = C.c_void_p()
+        assert lib.hp_domain_create(C.byref(d), C.byref(h)) == -1
+    finally:
+        hipims_mi.set_log_sink(None)
+    assert len(seen) == 1 and seen[0][0] == 2 and "size mismatch" in seen[0][1]
+    assert lib.hp_domain_create(C.byref(d), C.byref(h)) == -1          # sink removed: no further callbacks
+    assert len(seen) == 1

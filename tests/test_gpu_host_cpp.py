@@ -14,12 +14,16 @@ pytestmark = pytest.mark.gpu
 EXE = os.path.join(PKG, "lib", "run_dambreak")
 
 
-def python_protocol(cols, rows, duration, freq, scheme, batch):
+def python_protocol(cols, rows, duration, freq, scheme, batch, inflow=False):
     """CSchemeGodunov::runSimulation + Threaded_runBatch (CSchemeGodunov.cpp:1374-1453, :1147-1372) as the C++ mirror
     implements them, with a fixed queue size."""
     st, bed, man = syn.s_dam(cols, rows)
     dom = hp.Domain(cols, rows, scheme=scheme, t_end=duration)
     dom.upload(st, bed, man)
+    if inflow:                                                      # run_dambreak's "inflow" option
+        cells = [y * cols + 1 for y in range(rows // 4, 3 * rows // 4)]
+        series = [[0.0, 0.0, 40.0, 0.0], [1.0, 0.0, 120.0, 0.0], [2.0, 0.0, 120.0, 0.0]]
+        dom.add_cell(hp.DEPTH_IGNORE, hp.DISCHARGE_IS_VOLUME, cells, series, 1.0, 2.0)
     out, target, cur_target = [], freq, 0.0
     sc = dom.read_scalars()
     while sc["time"] < duration - 1e-9:
@@ -61,6 +65,30 @@ def test_cpp_host_driver_matches_python_binding(scheme_name, scheme):
     if scheme == hp.SCHEME_GODUNOV:
         assert max(vols) - min(vols) < 1e-6 * vols[0]                 # closed basin
     assert "Mcell-steps/s" in res.stderr
+
+
+def test_cpp_host_cell_boundary_matches_python_binding():
+    """CSchemeMI::addBoundaryCell (CBoundaryCell's place) -> hp_boundary_add_cell: an inflow hydrograph raises the volume,
+    and the C++ and Python hosts agree on every output time."""
+    cols, rows, duration, freq, batch = 320, 160, 1.5, 0.5, 25
+    res = subprocess.run([EXE, str(cols), str(rows), str(duration), str(freq), "godunov", str(batch), "inflow"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    lines = [l.split() for l in res.stdout.strip().splitlines()]
+    ref = python_protocol(cols, rows, duration, freq, hp.SCHEME_GODUNOV, batch, inflow=True)
+    assert len(lines) == len(ref) == 3
+    for (t_py, sum_py), l in zip(ref, lines):
+        assert abs(float(l[0]) - t_py) < 1e-9
+        assert abs(float(l[4]) - sum_py) <= 1e-9 * abs(sum_py)
+    vols = [float(l[3]) for l in lines]
+    assert vols[0] < vols[1] < vols[2]                              # water is coming in
+    closed = subprocess.run([EXE, str(cols), str(rows), str(duration), str(freq), "godunov", str(batch)],
+                            capture_output=True, text=True, timeout=300)
+    v_closed = float(closed.stdout.strip().splitlines()[-1].split()[3])
+    # "volume" adds Q*dt/dx^2 of depth to EACH listed cell (CLBoundaries.clc:67-98): the hydrograph integral to t=1.5 is
+    # 0.5*(40+120)*1 + 120*0.5 = 140 m3 per cell, sampled at each step's start time (rectangle rule -> within 1 %)
+    expected = 140.0 * len(range(rows // 4, 3 * rows // 4))
+    assert abs((vols[-1] - v_closed) - expected) < 0.01 * expected
 
 
 def test_cpp_host_automatic_queue_runs():
