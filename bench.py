@@ -8,9 +8,11 @@ N > 1 : one process per GPU (torch.distributed.run), 1-D row strips with per-ste
         along the configs' ladder 4096^2 -> 8192x4096 -> 8192^2 -> 16384x8192 (configs[3] at N = 8), i.e. 16,777,216
         cells per GPU at every N.  `--scaling strong` cuts the 4096^2 grid into N strips instead.
 
-The timed region starts with all inputs resident in HBM.  After the W warm-up steps an untimed, time-based pre-warm
-(--prewarm-s) settles clocks and caches; then EXACTLY K steps are timed `--repeats` times (barrier + device sync on
-both sides of each) and the MEDIAN repeat is reported.  `roofline` prices the flux kernel from HIP events recorded on
+The timed region starts with all inputs resident in HBM.  An untimed, time-based pre-warm (--prewarm-s) settles clocks
+and caches; the state is then put back from a device-side checkpoint (hp_state_restore), W untimed warm-up steps run,
+and EXACTLY K steps are timed (barrier + device sync on both sides).  That is done `--repeats` times -- every repeat
+times the same steps [W, W+K) of the workload from t = 0 -- and the MEDIAN repeat is reported.  `--evolve-steps E`
+moves the timed window to [W+E, W+E+K): a developed flood instead of the first moments after the dam has gone.  `roofline` prices the flux kernel from HIP events recorded on
 the domain's own stream (sparse samples, events created before the timed region); `roofline_manning_array` is the
 same kernel with a spatially varying Manning array; `cpu_baseline` times the reference's kernel sources compiled for
 the host (oracle/_ref) / the plain-C oracle on the host cores.
@@ -139,7 +141,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-manning-leg", action="store_true")
     ap.add_argument("--repeats", type=int, default=3, help="timed repeats of --steps steps; the median is reported")
-    ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed time-based pre-warm after the --warmup steps")
+    ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed time-based pre-warm (the state is restored afterwards)")
+    ap.add_argument("--evolve-steps", type=int, default=0, help="untimed steps after the warm-up: time a developed flood")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,20 +189,26 @@ def main():
     del st, bed, man
     runner.set_target_time(1e9)
 
-    # ---- untimed: the W warm-up steps the contract asks for, then a time-based pre-warm so that a short run (the
-    #      driver's 20 steps are 6 ms of GPU time) is not measured on clocks and caches that have not settled ----
-    runner.step(args.warmup)
+    # ---- untimed: a time-based pre-warm so that a short run (the driver's 20 steps are 6 ms of GPU time) is not
+    #      measured on clocks and caches that have not settled.  The pre-warm advances the flood by however many steps
+    #      fit into its time -- a faster kernel would hand the timed region a more developed (more expensive) flood --
+    #      so the state is then put back from a device-side checkpoint: what is timed is always steps [W, W+K) of the
+    #      workload from t = 0, whatever the hardware did before ----
+    runner.save()
     runner.barrier()
     t_warm = time.perf_counter()
     while time.perf_counter() - t_warm < args.prewarm_s:
         runner.step(25)
         runner.barrier()
 
-    # ---- timed: `repeats` x EXACTLY K steps, each bracketed by barrier + device sync; the median repeat is reported.
-    #      The flux kernel is sampled sparsely (<= 16 launches per repeat, events created beforehand) ----
+    # ---- `repeats` x (restore, W untimed warm-up steps, EXACTLY K timed steps bracketed by barrier + device sync);
+    #      the median repeat is reported.  The flux kernel is sampled sparsely (<= 16 launches per repeat, events
+    #      created beforehand) ----
     stride = max(1, args.steps // 12) | 1              # odd: both CFL flavours of the kernel get sampled
     runs = []
     for _ in range(max(1, args.repeats)):
+        runner.restore()
+        runner.step(args.warmup + args.evolve_steps)
         runner.domain.kernel_timing(stride)
         runner.barrier()
         t0 = time.perf_counter()
@@ -219,9 +228,10 @@ def main():
     if world == 1 and args.workload == "s-dam" and not args.no_manning_leg:
         rng = np.random.default_rng(11)
         man = (0.03 + rng.uniform(-0.005, 0.005, (rows, cols))).astype(real)
+        runner.restore()
         runner.domain.upload(manning=man)
         del man
-        runner.step(25)
+        runner.step(args.warmup + args.evolve_steps)
         runner.domain.kernel_timing(stride)
         runner.barrier()
         t0 = time.perf_counter()
@@ -249,6 +259,7 @@ def main():
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
                        "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + (f", per-iteration loop: {getattr(runner, 'loop', 'batch call')}" if world > 1 else "") + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
                                                                 else " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"),
+                       "timed_steps": [args.warmup + args.evolve_steps, args.warmup + args.evolve_steps + args.steps],
                        "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -108,6 +108,12 @@ struct hp_domain {
 	hipEvent_t       ev_fork = nullptr, ev_halo = nullptr;
 	bool             fork_is_advance = false;         // ev_fork was recorded BY the last advance_time launch
 	// strip decomposition driven from C++ (hp_strip_*): one RCCL communicator over the ranks, strip neighbours = rank +- 1
+	// device-side checkpoint (hp_state_save / hp_state_restore)
+	void*            saved_state = nullptr;
+	void*            saved_scalars = nullptr;         // Scalars<T> + the four CFL slots
+	bool             saved_valid = false;
+	bool             saved_full_reduce = true, saved_edge_dirty = true;
+	int              saved_use_alt = 0;
 	ncclComm_t       comm = nullptr;
 	int              comm_rank = 0, comm_world = 1;
 	hipEvent_t       ev_xchg = nullptr;               // ghost rows of the iteration in flight have arrived
@@ -676,6 +682,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
 	hipFree(d->scalars); hipFree(d->cfl_slot);
+	hipFree(d->saved_state); hipFree(d->saved_scalars);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
 	if (d->ev_stop) hipEventDestroy(d->ev_stop);
@@ -732,6 +739,49 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 		return HP_OK;
 	}
 	return fail(HP_ERR_INVALID, "unknown array id");
+}
+
+// saveCurrentState / rollbackSimulation without the PCIe round trip: the copy stays in HBM
+int hp_state_save(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (d->in_step) return fail(HP_ERR_STATE, "hp_state_save between hp_step_begin and hp_step_end");
+	const size_t bytes = d->cells * 4 * d->esize;
+	const size_t sc_bytes = d->desc.precision == 8 ? sizeof(Scalars<double>) : sizeof(Scalars<float>);
+	if (!d->saved_state) {
+		HIP_TRY(hipMalloc(&d->saved_state, bytes));
+		HIP_TRY(hipMalloc(&d->saved_scalars, sc_bytes + 4 * d->esize));
+	}
+	HIP_TRY(hipMemcpyAsync(d->saved_state, d->state[d->use_alt], bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->saved_scalars, d->scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync((char*)d->saved_scalars + sc_bytes, d->cfl_slot, 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
+	d->saved_full_reduce = d->need_full_reduce;
+	d->saved_edge_dirty = d->edge_dirty;
+	d->saved_use_alt = d->use_alt;
+	d->saved_valid = true;
+	return HP_OK;
+}
+
+int hp_state_restore(hp_domain_t* d)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (d->in_step) return fail(HP_ERR_STATE, "hp_state_restore between hp_step_begin and hp_step_end");
+	if (!d->saved_valid) return fail(HP_ERR_STATE, "hp_state_restore without a saved state");
+	const size_t bytes = d->cells * 4 * d->esize;
+	const size_t sc_bytes = d->desc.precision == 8 ? sizeof(Scalars<double>) : sizeof(Scalars<float>);
+	// both ping-pong buffers, as rollbackSimulation writes them (CSchemeGodunov.cpp:1496-1499); the ping-pong phase and
+	// the remembered CFL maxima return to what they were, so the steps that follow repeat the original ones bit for bit
+	HIP_TRY(hipMemcpyAsync(d->state[0], d->saved_state, bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->state[1], d->saved_state, bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->scalars, d->saved_scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
+	d->use_alt = d->saved_use_alt;
+	d->need_full_reduce = d->saved_full_reduce;
+	d->edge_dirty = d->saved_edge_dirty;
+	d->fork_is_advance = false;
+	return HP_OK;
 }
 
 int hp_domain_download(hp_domain_t* d, int which, void* host, int64_t row0, int64_t nrows)

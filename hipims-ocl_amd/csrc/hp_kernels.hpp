@@ -536,31 +536,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		else           r.n = buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
 		return r;
 	};
-	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w) {
+	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w,
+	                   bool& quiet) {
 		const Raw<T> c = raw_of(mid);
 		const Raw<T> e = raw_from_east(c), w = raw_from_west(c);
 		dry_e = e.zmax < vs;                                                       // :633 tests Zmax, not depth (Q6)
 		dry_w = w.zmax < vs;
-		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs);
+		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs, quiet);
+	};
+	// A "quiet" row (muscl_predict's wave-uniform fast path: all four face states of every lane equal the cell state)
+	// needs neither the LDS round trip of its face values nor three separate sides: one side built from the cell state
+	// serves its E, W and N faces -- the same values the general path would produce, with a third of the reciprocals.
+	auto cell_side = [&](const RowRegs<T>& r) {
+		Face4<T> cc; cc.z = r.c.z; cc.h = r.c.z - r.zb; cc.qx = r.c.qx; cc.qy = r.c.qy;
+		return side_from_face<STRICT>(cc, r.c.qx, r.c.qy, vs);
 	};
 
-	RowRegs<T> rc = load_row(y0);
-	RowRegs<T> rn = load_row(y0 + 1);                                              // y0+1 <= rows-2
+	RowRegs<T> rA = load_row(y0);
+	RowRegs<T> rB = load_row(y0 + 1);                                              // y0+1 <= rows-2
 	RowRegs<T> rP = load_row((y0 + 2 < p.rows) ? (y0 + 2) : (p.rows - 1)), rQ;    // landing sets of the row two ahead
 
 	FaceFlux<T> fS = {};
 	bool dryE = false, dryW = false, dryS;
+	bool quiet_c = false;                                                          // the row being corrected is a quiet row
 	{
+		const RowRegs<T>& rc = rA; const RowRegs<T>& rn = rB;
 		const RowRegs<T> rs2 = load_row(y0 - 2);
 		const RowRegs<T> rs = load_row(y0 - 1);
 		dryS = rs.c.zmax < vs;
 		if (!skip_step) {
-			bool de, dw;
-			const Faces<T> ps = predict(rs2, rs, rc, de, dw);
-			const Faces<T> pc = predict(rs, rc, rn, dryE, dryW);
+			bool de, dw, qs;
+			const Faces<T> ps = predict(rs2, rs, rc, de, dw, qs);
+			const Faces<T> pc = predict(rs, rc, rn, dryE, dryW, quiet_c);
+			if (!quiet_c) {
 			stash[0][lane] = pc.n.z; stash[1][lane] = pc.n.h; stash[2][lane] = pc.n.qx; stash[3][lane] = pc.n.qy;
 			stash[4][lane] = pc.e.z; stash[5][lane] = pc.e.h; stash[6][lane] = pc.e.qx; stash[7][lane] = pc.e.qy;
 			stash[8][lane] = pc.w.z; stash[9][lane] = pc.w.h; stash[10][lane] = pc.w.qx; stash[11][lane] = pc.w.qy;
+			}
 			const Side<T> sS = side_from_face<STRICT>(ps.n, rs.c.qx, rs.c.qy, vs);
 			const Side<T> sC = side_from_face<STRICT>(pc.s, rc.c.qx, rc.c.qy, vs);
 			fS = face_solve<AXIS_Y, STRICT, true, true>(sS, sC, vs).forR;
@@ -568,24 +580,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	}
 
 	// one row: `rc` is corrected, `rn` is its northern neighbour, `rnn` the row after (landed last iteration),
-	// `pre` receives the prefetch of row y+3; the row in flight is never copied (see K1)
-	auto row_step = [&](const long y, const RowRegs<T>& rnn, RowRegs<T>& pre) {
+	// `pre` receives the prefetch of row y+3; the row in flight is never copied (see K1).  On return `rn` is the row to
+	// correct next and `rc`'s registers hold ITS northern neighbour (back from LDS): the caller swaps the two names.
+	auto row_step = [&](const long y, RowRegs<T>& rc, RowRegs<T>& rn, const RowRegs<T>& rnn, RowRegs<T>& pre) {
 		pre = load_row((y + 3 < p.rows) ? (y + 3) : (p.rows - 1));                 // prefetch (clamped)
 		State4<T> out = rc.c;
+		const T zb_c = rc.zb;
 
 		if (!skip_step) {
 			// predictor of the next row (needs rows y, y+1, y+2)
-			bool dryE_n, dryW_n;
-			const Faces<T> pn = predict(rc, rn, rnn, dryE_n, dryW_n);
+			bool dryE_n, dryW_n, quiet_n;
+			const Faces<T> pn = predict(rc, rn, rnn, dryE_n, dryW_n, quiet_n);
 			// the current row's faces come back from LDS only now that the predictor's temporaries are dead, and the
 			// next row's take their place there
-			Face4<T> pc_n, pc_e, pc_w;
-			pc_n.z = stash[0][lane]; pc_n.h = stash[1][lane]; pc_n.qx = stash[2][lane]; pc_n.qy = stash[3][lane];
-			pc_e.z = stash[4][lane]; pc_e.h = stash[5][lane]; pc_e.qx = stash[6][lane]; pc_e.qy = stash[7][lane];
-			pc_w.z = stash[8][lane]; pc_w.h = stash[9][lane]; pc_w.qx = stash[10][lane]; pc_w.qy = stash[11][lane];
-			stash[0][lane] = pn.n.z; stash[1][lane] = pn.n.h; stash[2][lane] = pn.n.qx; stash[3][lane] = pn.n.qy;
-			stash[4][lane] = pn.e.z; stash[5][lane] = pn.e.h; stash[6][lane] = pn.e.qx; stash[7][lane] = pn.e.qy;
-			stash[8][lane] = pn.w.z; stash[9][lane] = pn.w.h; stash[10][lane] = pn.w.qx; stash[11][lane] = pn.w.qy;
+			Side<T> sE_mine, sW_mine, sN_mine;
+			if (quiet_c) {
+				sE_mine = cell_side(rc);
+				sW_mine = sE_mine; sN_mine = sE_mine;
+			} else {
+				Face4<T> pc_n, pc_e, pc_w;
+				pc_n.z = stash[0][lane]; pc_n.h = stash[1][lane]; pc_n.qx = stash[2][lane]; pc_n.qy = stash[3][lane];
+				pc_e.z = stash[4][lane]; pc_e.h = stash[5][lane]; pc_e.qx = stash[6][lane]; pc_e.qy = stash[7][lane];
+				pc_w.z = stash[8][lane]; pc_w.h = stash[9][lane]; pc_w.qx = stash[10][lane]; pc_w.qy = stash[11][lane];
+				sE_mine = side_from_face<STRICT>(pc_e, rc.c.qx, rc.c.qy, vs);
+				sW_mine = side_from_face<STRICT>(pc_w, rc.c.qx, rc.c.qy, vs);
+				sN_mine = side_from_face<STRICT>(pc_n, rc.c.qx, rc.c.qy, vs);
+			}
+			if (!quiet_n) {
+				stash[0][lane] = pn.n.z; stash[1][lane] = pn.n.h; stash[2][lane] = pn.n.qx; stash[3][lane] = pn.n.qy;
+				stash[4][lane] = pn.e.z; stash[5][lane] = pn.e.h; stash[6][lane] = pn.e.qx; stash[7][lane] = pn.e.qy;
+				stash[8][lane] = pn.w.z; stash[9][lane] = pn.w.h; stash[10][lane] = pn.w.qx; stash[11][lane] = pn.w.qy;
+			}
 			const Face4<T> pn_s = pn.s;
 			// the row two ahead has served the predictor; it is next needed as the northern row of the next iteration
 			stash[12][lane] = rnn.c.z; stash[13][lane] = rnn.c.zmax; stash[14][lane] = rnn.c.qx; stash[15][lane] = rnn.c.qy;
@@ -593,8 +618,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			if (!UNIFORM_N) stash[17][lane] = rnn.n;
 
 			// east face: my E-face state against the east neighbour's W-face state
-			const Side<T> sE_mine = side_from_face<STRICT>(pc_e, rc.c.qx, rc.c.qy, vs);
-			const Side<T> sW_mine = side_from_face<STRICT>(pc_w, rc.c.qx, rc.c.qy, vs);
 			const Side<T> sE_nb = side_from_east(sW_mine);
 			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sE_mine, sE_nb, vs);
 			const FaceFlux<T> fE = fx.forL, forW = fx.forR;
@@ -605,7 +628,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			fW.stop = from_west((int)forW.stop) != 0;
 
 			// north face: my N-face state against the north neighbour's S-face state
-			const Side<T> sN_mine = side_from_face<STRICT>(pc_n, rc.c.qx, rc.c.qy, vs);
 			const Side<T> sN_nb = side_from_face<STRICT>(pn_s, rn.c.qx, rn.c.qy, vs);
 			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sN_mine, sN_nb, vs);
 			const FaceFlux<T> fN = fy.forL;
@@ -621,29 +643,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			fS = fy.forR;
 			dryS = rc.c.zmax < vs;
 			dryE = dryE_n; dryW = dryW_n;
+			quiet_c = quiet_n;
 		}
 
 		buf_store_state(out, srd_dst, out_x ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);
 		if (CFL_MODE == 1 && out_x) {
-			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
+			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, zb_c, p.qs);
 			if (s > vmax) vmax = s;
 		}
-		rc = rn;                     // a copy of a row that has already been used
-		if (!skip_step) {
-			rn.c.z = stash[12][lane]; rn.c.zmax = stash[13][lane]; rn.c.qx = stash[14][lane]; rn.c.qy = stash[15][lane];
-			rn.zb = stash[16][lane];
-			rn.n = UNIFORM_N ? p.manning_value : stash[17][lane];
+		if (!skip_step) {            // row y+2 comes back into the registers of the row that is finished
+			rc.c.z = stash[12][lane]; rc.c.zmax = stash[13][lane]; rc.c.qx = stash[14][lane]; rc.c.qy = stash[15][lane];
+			rc.zb = stash[16][lane];
+			rc.n = UNIFORM_N ? p.manning_value : stash[17][lane];
 		} else {
-			rn = rnn;
+			rc = rnn;
 		}
 	};
 
 	long y = y0;
 	for (; y + 2 <= y1; y += 2) {
-		row_step(y, rP, rQ);
-		row_step(y + 1, rQ, rP);
+		row_step(y, rA, rB, rP, rQ);
+		row_step(y + 1, rB, rA, rQ, rP);
 	}
-	if (y < y1) row_step(y, rP, rQ);
+	if (y < y1) row_step(y, rA, rB, rP, rQ);
 
 	if (CFL_MODE != 0) {
 		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }

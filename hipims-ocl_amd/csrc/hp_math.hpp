@@ -528,13 +528,24 @@ __device__ __forceinline__ Face4<T> face_extrapolate(const T zb, const Face4<T>&
 // mch_1st (:301-382): limited slopes, face extrapolation, half-step evolution, re-extrapolation
 template <bool STRICT, typename T>
 __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>& n, const Raw<T>& e, const Raw<T>& s,
-                                                  const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs)
+                                                  const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs,
+                                                  bool& quiet_row)
 {
 	const T g = gravity<T>();
 	Face4<T> cc; cc.z = c.z; cc.h = c.z - c.zb; cc.qx = c.qx; cc.qy = c.qy;           // :333
 	Faces<T> f; f.n = cc; f.e = cc; f.s = cc; f.w = cc;
 	const bool first = (c.z - c.zb < T(1E-5)) || n.zmax <= T(-9998.0) || e.zmax <= T(-9998.0) ||
 	                   s.zmax <= T(-9998.0) || w.zmax <= T(-9998.0);                    // :325-330
+
+	// Cheapest sufficient test for a quiet row (see below): a cell whose four neighbours carry exactly its own level, bed
+	// and discharges has all differences zero, hence all limited slopes zero -- sixteen compares instead of the eight
+	// limiter evaluations that would discover the same thing.
+	const bool same = n.z == c.z && n.zb == c.zb && n.qx == c.qx && n.qy == c.qy &&
+	                  e.z == c.z && e.zb == c.zb && e.qx == c.qx && e.qy == c.qy &&
+	                  s.z == c.z && s.zb == c.zb && s.qx == c.qx && s.qy == c.qy &&
+	                  w.z == c.z && w.zb == c.zb && w.qx == c.qx && w.qy == c.qy;
+	quiet_row = __all(first || same);
+	if (quiet_row) return f;
 
 	Face4<T> sx, sy;                                                                    // :343-346
 	sx.z = sx.h = sx.qx = sx.qy = sy.z = sy.h = sy.qx = sy.qy = T(0);
@@ -547,7 +558,8 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 	// wavefront.  Flood models are mostly such water (and dry land) most of the time.
 	const bool flat = sx.z == T(0) && sx.h == T(0) && sx.qx == T(0) && sx.qy == T(0) &&
 	                  sy.z == T(0) && sy.h == T(0) && sy.qx == T(0) && sy.qy == T(0);
-	if (__all(first || flat)) return f;
+	quiet_row = __all(first || flat);       // wave-uniform: every lane's four faces ARE its cell state
+	if (quiet_row) return f;
 	if (first) return f;
 
 	f.n = face_extrapolate<STRICT>(c.zb, cc, sy, T(+0.5));                                         // :349-352

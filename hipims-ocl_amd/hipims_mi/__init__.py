@@ -29,7 +29,7 @@ PTR_STATE_NEXT_SRC, PTR_STATE_OTHER, PTR_BED, PTR_MANNING, PTR_CFL_MAX, PTR_SCAL
 
 EXPORTS = [
     "hp_abi_version", "hp_device_count", "hp_device_info", "hp_last_error", "hp_set_log_sink", "hp_domain_desc_default",
-    "hp_domain_create", "hp_domain_destroy", "hp_domain_upload", "hp_domain_download", "hp_domain_upload_rows",
+    "hp_domain_create", "hp_domain_destroy", "hp_domain_upload", "hp_domain_download", "hp_domain_upload_rows", "hp_state_save", "hp_state_restore",
     "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_add_cell", "hp_boundary_clear", "hp_set_target_time", "hp_set_time",
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
     "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_set_halo_overlap",
@@ -113,6 +113,8 @@ def load_library(path: str | None = None):
     lib.hp_domain_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.hp_domain_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64]
     lib.hp_domain_upload_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+    lib.hp_state_save.argtypes = [C.c_void_p]
+    lib.hp_state_restore.argtypes = [C.c_void_p]
     lib.hp_boundary_add_uniform.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_double, C.c_double]
     lib.hp_boundary_add_gridded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                             C.c_double, C.c_double, C.c_double, C.c_double]
@@ -281,6 +283,13 @@ class Domain:
         _check(self.lib, self.lib.hp_domain_upload_rows(self.h, a.ctypes.data_as(C.c_void_p), row0, a.shape[0]),
                "hp_domain_upload_rows")
         self.sync()
+
+    def state_save(self):
+        """Device-side checkpoint of cell states + time-control block (saveCurrentState without the PCIe trip)."""
+        _check(self.lib, self.lib.hp_state_save(self.h), "hp_state_save")
+
+    def state_restore(self):
+        _check(self.lib, self.lib.hp_state_restore(self.h), "hp_state_restore")
 
     # ---- boundaries ----
     def add_uniform(self, definition, series, interval, length):

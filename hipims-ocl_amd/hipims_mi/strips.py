@@ -141,6 +141,12 @@ class SingleRunner:
     def step(self, n):
         self.domain.step_batch(n)
 
+    def save(self):
+        self.domain.state_save()
+
+    def restore(self):
+        self.domain.state_restore()
+
     def barrier(self):
         self.domain.sync()
 
@@ -303,6 +309,13 @@ class StripRunner:
             for req in halo:
                 req.wait()                             # domain stream (or the host, with gloo) waits for the rows
             self.engine.step_end()
+
+    def save(self):
+        """Device-side checkpoint of this rank's strip (ghost rows included: they are consistent at iteration ends)."""
+        self.engine.domain.state_save()
+
+    def restore(self):
+        self.engine.domain.state_restore()
 
     def barrier(self):
         self.engine.sync()
