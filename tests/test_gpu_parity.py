@@ -11,7 +11,7 @@ import pytest
 
 import hipims_mi as hp
 import oracle
-from conftest import load_golden
+from conftest import load_golden, record
 from hipims_mi import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -186,6 +186,10 @@ def test_newcastle_example_rain_drainage(mode, tmp_path):
     dom.set_target_time(1e9)
     dom.step_batch(900)
     dg = np.maximum(0, dom.download()[..., 0] - bed)
+    record("c1_newcastle_900", mode="strict" if mode == hp.MATH_STRICT else "fast",
+           rmse=float(np.sqrt(np.mean((dg - dr) ** 2))), max=float(np.abs(dg - dr).max()),
+           dt_rel=abs(dom.read_scalars()["time"] - float(g["t"])) / float(g["t"]),
+           bracket_rmse=float(bracket_rmse), bracket_max=float(bracket_max), bracket_t=float(bracket_t))
     assert np.sqrt(np.mean((dg - dr) ** 2)) < 3 * bracket_rmse and np.abs(dg - dr).max() < 3 * bracket_max
     # elapsed time: the CFL-limiting cell is a single thin-film cell, so dt inherits the flips more directly: 10x bracket
     assert abs(dom.read_scalars()["time"] - float(g["t"])) < 10 * bracket_t * float(g["t"])
