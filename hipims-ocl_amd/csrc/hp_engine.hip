@@ -607,7 +607,10 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		// 13 % (S-DAM) to 47 % (S-RAIN 8192^2) ahead of 16; fp64 is flat or slightly worse beyond 18
 		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? 32 : 16, 2);
 		d->inertial_rseg = d->march_rseg;
-		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 32, 4);
+		// K2 after the inert-row cut (round 2): a tile of still water or dry land costs a fifth of a tile on the flood front,
+		// so fp64 wants more, shorter tiles for the dispatcher to balance (16-20 rows: 0.319 ms against 0.355 at 32 on the
+		// 4096^2 dam break, 0.355 against 0.395 on the developed flood, +2-5 % at 8192^2 and 16384 x 1028); fp32 stays at 32
+		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? 32 : 16, 4);
 	}
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);

@@ -537,12 +537,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		return r;
 	};
 	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w,
-	                   bool& quiet) {
+	                   bool& quiet, bool& same) {
 		const Raw<T> c = raw_of(mid);
 		const Raw<T> e = raw_from_east(c), w = raw_from_west(c);
 		dry_e = e.zmax < vs;                                                       // :633 tests Zmax, not depth (Q6)
 		dry_w = w.zmax < vs;
-		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs, quiet);
+		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs, quiet, same);
 	};
 	// A "quiet" row (muscl_predict's wave-uniform fast path: all four face states of every lane equal the cell state)
 	// needs neither the LDS round trip of its face values nor three separate sides: one side built from the cell state
@@ -559,15 +559,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	FaceFlux<T> fS = {};
 	bool dryE = false, dryW = false, dryS;
 	bool quiet_c = false;                                                          // the row being corrected is a quiet row
+	bool quiet_s = false, same_c = false;                                          // ... the row south of it; every lane's neighbourhood is one state
+	bool fS_ok = true;                                                             // fS holds the south face of the row being corrected
 	{
 		const RowRegs<T>& rc = rA; const RowRegs<T>& rn = rB;
 		const RowRegs<T> rs2 = load_row(y0 - 2);
 		const RowRegs<T> rs = load_row(y0 - 1);
 		dryS = rs.c.zmax < vs;
 		if (!skip_step) {
-			bool de, dw, qs;
-			const Faces<T> ps = predict(rs2, rs, rc, de, dw, qs);
-			const Faces<T> pc = predict(rs, rc, rn, dryE, dryW, quiet_c);
+			bool de, dw, ss;
+			const Faces<T> ps = predict(rs2, rs, rc, de, dw, quiet_s, ss);
+			const Faces<T> pc = predict(rs, rc, rn, dryE, dryW, quiet_c, same_c);
 			if (!quiet_c) {
 			stash[0][lane] = pc.n.z; stash[1][lane] = pc.n.h; stash[2][lane] = pc.n.qx; stash[3][lane] = pc.n.qy;
 			stash[4][lane] = pc.e.z; stash[5][lane] = pc.e.h; stash[6][lane] = pc.e.qx; stash[7][lane] = pc.e.qy;
@@ -589,34 +591,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 
 		if (!skip_step) {
 			// predictor of the next row (needs rows y, y+1, y+2)
-			bool dryE_n, dryW_n, quiet_n;
-			const Faces<T> pn = predict(rc, rn, rnn, dryE_n, dryW_n, quiet_n);
+			bool dryE_n, dryW_n, quiet_n, same_n;
+			const Faces<T> pn = predict(rc, rn, rnn, dryE_n, dryW_n, quiet_n, same_n);
+			const Face4<T> pn_s = pn.s;
+
+			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :594-595
+			const bool dryC = (rc.c.z - rc.zb) < vs;                                  // :597-598
+			const bool dryN = rn.c.zmax < vs;
+			const bool dry5 = dryC && dryN && dryE && dryS && dryW;                   // :638
+
+			// Inert rows (wave-uniform).  Two kinds of row provably come out of the corrector exactly as they went in:
+			//  dry land -- every lane's cell and its four neighbours are dry (dry5): the reference does not update such
+			//    cells at all (:638), so no face of the row is needed for the row itself;
+			//  still water -- every lane's cell and its four neighbours hold ONE wet state with zero discharge, and the
+			//    rows north and south are quiet (their face states are their cell states): the four faces of a cell are
+			//    then solved on identical left/right states, opposite faces return identical values, every flux
+			//    difference is x - x = +0, the bed-slope term is (zb - zb) = +0 times something finite, friction does
+			//    not act on zero discharge, and Z - dt*(+0) = Z, Q - dt*(+0) = Q bit for bit (FAST and STRICT alike;
+			//    only Zmax may still have to follow Z).
+			// Such a row skips both face solves and the update.  The one thing another row may want from it is its north
+			// face (the next row's south flux): a dry row solves it unless the next row is dry land as well (known
+			// here: that row's five dry tests need rows y..y+2, all in registers); a still row never does -- if the
+			// next row turns out not to be inert, it re-derives that face from its own cell state, which the still
+			// row's `same` test has shown to be the still row's state too (same values in, same bits out).
+			const bool wet_q0 = (rc.c.z - rc.zb) > vs && rc.c.qx == T(0) && rc.c.qy == T(0);
+			const bool inertD = __all(dry5);
+			const bool inertS = same_c && quiet_n && quiet_s && __all(wet_q0);
+			const bool dry5_n = ((rn.c.z - rn.zb) < vs) && (rnn.c.zmax < vs) && dryE_n && (rc.c.zmax < vs) && dryW_n;
+			const bool inertD_n = __all(dry5_n);
+
+			const bool inert = inertS || inertD;
+
 			// the current row's faces come back from LDS only now that the predictor's temporaries are dead, and the
 			// next row's take their place there
 			Side<T> sE_mine, sW_mine, sN_mine;
-			if (quiet_c) {
-				sE_mine = cell_side(rc);
-				sW_mine = sE_mine; sN_mine = sE_mine;
-			} else {
-				Face4<T> pc_n, pc_e, pc_w;
-				pc_n.z = stash[0][lane]; pc_n.h = stash[1][lane]; pc_n.qx = stash[2][lane]; pc_n.qy = stash[3][lane];
-				pc_e.z = stash[4][lane]; pc_e.h = stash[5][lane]; pc_e.qx = stash[6][lane]; pc_e.qy = stash[7][lane];
-				pc_w.z = stash[8][lane]; pc_w.h = stash[9][lane]; pc_w.qx = stash[10][lane]; pc_w.qy = stash[11][lane];
-				sE_mine = side_from_face<STRICT>(pc_e, rc.c.qx, rc.c.qy, vs);
-				sW_mine = side_from_face<STRICT>(pc_w, rc.c.qx, rc.c.qy, vs);
-				sN_mine = side_from_face<STRICT>(pc_n, rc.c.qx, rc.c.qy, vs);
+			if (!inert) {
+				if (quiet_c) {
+					sE_mine = cell_side(rc);
+					sW_mine = sE_mine; sN_mine = sE_mine;
+				} else {
+					Face4<T> pc_n, pc_e, pc_w;
+					pc_n.z = stash[0][lane]; pc_n.h = stash[1][lane]; pc_n.qx = stash[2][lane]; pc_n.qy = stash[3][lane];
+					pc_e.z = stash[4][lane]; pc_e.h = stash[5][lane]; pc_e.qx = stash[6][lane]; pc_e.qy = stash[7][lane];
+					pc_w.z = stash[8][lane]; pc_w.h = stash[9][lane]; pc_w.qx = stash[10][lane]; pc_w.qy = stash[11][lane];
+					sE_mine = side_from_face<STRICT>(pc_e, rc.c.qx, rc.c.qy, vs);
+					sW_mine = side_from_face<STRICT>(pc_w, rc.c.qx, rc.c.qy, vs);
+					sN_mine = side_from_face<STRICT>(pc_n, rc.c.qx, rc.c.qy, vs);
+				}
 			}
 			if (!quiet_n) {
 				stash[0][lane] = pn.n.z; stash[1][lane] = pn.n.h; stash[2][lane] = pn.n.qx; stash[3][lane] = pn.n.qy;
 				stash[4][lane] = pn.e.z; stash[5][lane] = pn.e.h; stash[6][lane] = pn.e.qx; stash[7][lane] = pn.e.qy;
 				stash[8][lane] = pn.w.z; stash[9][lane] = pn.w.h; stash[10][lane] = pn.w.qx; stash[11][lane] = pn.w.qy;
 			}
-			const Face4<T> pn_s = pn.s;
 			// the row two ahead has served the predictor; it is next needed as the northern row of the next iteration
 			stash[12][lane] = rnn.c.z; stash[13][lane] = rnn.c.zmax; stash[14][lane] = rnn.c.qx; stash[15][lane] = rnn.c.qy;
 			stash[16][lane] = rnn.zb;
 			if (!UNIFORM_N) stash[17][lane] = rnn.n;
 
+			if (inert) {
+				if (inertD && !inertD_n) {
+					const Side<T> sN_dry = cell_side(rc);                                 // a dry row is a quiet row
+					const Side<T> sN_nb = side_from_face<STRICT>(pn_s, rn.c.qx, rn.c.qy, vs);
+					fS = face_solve<AXIS_Y, STRICT, true, true>(sN_dry, sN_nb, vs).forR;
+					fS_ok = true;
+				} else {
+					fS_ok = false;
+				}
+				if (inertS && out.z > out.zmax && out.zmax > T(-9990.0)) out.zmax = out.z;   // :791-796, all that is left of the update
+			} else {
+			if (!fS_ok) {                                   // the row below was a still row: its state is this row's state
+				const Side<T> cs = cell_side(rc);
+				fS = face_solve<AXIS_Y, STRICT, true, true>(cs, cs, vs).forR;
+			}
 			// east face: my E-face state against the east neighbour's W-face state
 			const Side<T> sE_nb = side_from_east(sW_mine);
 			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sE_mine, sE_nb, vs);
@@ -632,18 +679,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sN_mine, sN_nb, vs);
 			const FaceFlux<T> fN = fy.forL;
 
-			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :594-595
-			const bool dryC = (rc.c.z - rc.zb) < vs;                                  // :597-598
-			const bool dryN = rn.c.zmax < vs;
-			const bool dry5 = dryC && dryN && dryE && dryS && dryW;                   // :638
 			const State4<T> upd = godunov_update<STRICT, true>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx,
 			                                                    vs, with_friction);
 			if (!disabled && !dry5) out = upd;
 
 			fS = fy.forR;
+			fS_ok = true;
+			}
+
 			dryS = rc.c.zmax < vs;
 			dryE = dryE_n; dryW = dryW_n;
-			quiet_c = quiet_n;
+			quiet_s = quiet_c; quiet_c = quiet_n; same_c = same_n;
 		}
 
 		buf_store_state(out, srd_dst, out_x ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);

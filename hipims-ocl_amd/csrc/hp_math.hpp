@@ -529,7 +529,7 @@ __device__ __forceinline__ Face4<T> face_extrapolate(const T zb, const Face4<T>&
 template <bool STRICT, typename T>
 __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>& n, const Raw<T>& e, const Raw<T>& s,
                                                   const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs,
-                                                  bool& quiet_row)
+                                                  bool& quiet_row, bool& same_row)
 {
 	const T g = gravity<T>();
 	Face4<T> cc; cc.z = c.z; cc.h = c.z - c.zb; cc.qx = c.qx; cc.qy = c.qy;           // :333
@@ -545,6 +545,7 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 	                  s.z == c.z && s.zb == c.zb && s.qx == c.qx && s.qy == c.qy &&
 	                  w.z == c.z && w.zb == c.zb && w.qx == c.qx && w.qy == c.qy;
 	quiet_row = __all(first || same);
+	same_row = __all(same);                  // every lane's neighbourhood is one state (used by the kernel's inert-row test)
 	if (quiet_row) return f;
 
 	Face4<T> sx, sy;                                                                    // :343-346

@@ -295,3 +295,57 @@ def test_state_restore_without_save_is_an_error():
     with pytest.raises(hp.HipimsError, match="without a saved state"):
         d.state_restore()
     d.close()
+
+
+# ---- K2 inert rows (still water / dry land skip both face solves and the update): exactness ----
+def _inert_mix(cols, rows):
+    """Still lake (west), dry sloping land (east), a dam-break front between them, a drop falling into the lake, a dry
+    island in it, disabled cells, and rows of moving water: every transition between inert and live rows occurs."""
+    y, x = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    bed = np.where(x > 0.55 * cols, 0.02 * (x - 0.55 * cols), 0.0)                # flat under the lake, rising land
+    bed[(x - 0.2 * cols) ** 2 + (y - 0.5 * rows) ** 2 < 16] = 3.0               # island
+    z = np.maximum(bed, np.where(x < 0.55 * cols, 2.0, 0.0))
+    z[(x - 0.35 * cols) ** 2 + (y - 0.3 * rows) ** 2 < 9] += 0.25                # the drop
+    st = np.zeros((rows, cols, 4)); st[..., 0] = z; st[..., 1] = z
+    band = (y > 0.75 * rows) & (x < 0.5 * cols)
+    st[..., 2][band] = 0.3                                                        # uniformly moving water: quiet but not inert
+    st[5:9, 20:26, 1] = -9999.0                                                   # nulls inside the still lake
+    syn._walls(st, bed)
+    return st, bed, np.full((rows, cols), 0.03)
+
+
+@pytest.mark.parametrize("cols,rows", [(200, 96), (130, 70)])
+def test_muscl_inert_rows_are_exact_strict_vs_oracle(cols, rows):
+    st, bed, man = _inert_mix(cols, rows)
+    quirks = oracle.QUIRKS_REFERENCE & ~oracle.Q6_MUSCL_SERIAL
+    ref = oracle.OracleSim(cols, rows, scheme=hp.SCHEME_MUSCL_HANCOCK, friction=False, quirks=quirks)
+    dom = hp.Domain(cols, rows, scheme=hp.SCHEME_MUSCL_HANCOCK, friction=False, math_mode=hp.MATH_STRICT)
+    for s in (ref, dom):
+        s.upload(st, bed, man)
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    for _ in range(4):                                       # the front and the ripples eat into the inert regions
+        ref.run(40); dom.step_batch(40)
+        assert np.array_equal(dom.download(), ref.download())
+        assert dom.read_scalars()["time"] == ref.scalars()["t"]
+    dom.close()
+
+
+def test_muscl_inert_rows_fast_matches_oracle_and_keeps_the_lake_still():
+    cols, rows = 260, 128
+    st, bed, man = _inert_mix(cols, rows)
+    quirks = oracle.QUIRKS_REFERENCE & ~oracle.Q6_MUSCL_SERIAL
+    ref = oracle.OracleSim(cols, rows, scheme=hp.SCHEME_MUSCL_HANCOCK, quirks=quirks)
+    dom = hp.Domain(cols, rows, scheme=hp.SCHEME_MUSCL_HANCOCK)
+    for s in (ref, dom):
+        s.upload(st, bed, man)
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    ref.run(60); dom.step_batch(60)
+    out, want = dom.download(), ref.download()
+    dg, dr = np.maximum(0, out[..., 0] - bed), np.maximum(0, want[..., 0] - bed)
+    assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
+    assert abs(dom.read_scalars()["time"] - ref.scalars()["t"]) < 1e-9
+    quiet = (want[..., [0, 2, 3]] == st[..., [0, 2, 3]]).all(-1) & (st[..., 0] - bed > 0.1)
+    assert quiet.sum() > 3000                                # lake water the ripples have not reached yet ...
+    assert np.array_equal(out[quiet][..., [0, 2, 3]], st[quiet][..., [0, 2, 3]])     # ... keeps its bits on the GPU too
+    assert np.array_equal(out[5:9, 20:26], st[5:9, 20:26])   # nulls carried through
+    dom.close()
