@@ -1,0 +1,147 @@
+// fake_rccl -- TEST DOUBLE for the collective library behind hp_strip_* (tests only; never shipped or linked by the
+// product).  RCCL refuses two ranks on one device, and the GPU boxes the tests run on have one: this library gives
+// the nine entry points hp_comm_load resolves the semantics they have in RCCL for RANKS THAT ARE THREADS OF ONE
+// PROCESS sharing one GPU, so that hp_strip_step_batch's multi-rank logic (which rows go where, stream ordering,
+// which iterations all-reduce) runs with 2-4 real ranks (tests/strip_threads_worker.py).
+//   ncclSend / ncclRecv inside a group: the receiver copies device-to-device on ITS stream after the sender's stream
+//   has reached the send (event), and the sender's stream then waits for the copy (event) -- the ordering RCCL gives.
+//   ncclAllReduce(MAX, 1 element): through the host, with a generation barrier over the ranks.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace {
+struct Parcel { const void* buf = nullptr; size_t bytes = 0; hipEvent_t ready = nullptr, done = nullptr; bool posted = false, copied = false; };
+struct Shared {
+	std::mutex m;
+	std::condition_variable cv;
+	std::map<std::pair<int, int>, std::vector<Parcel>> box;      // (src, dst) -> parcels in flight, FIFO
+	int world = 0, arrived = 0;
+	unsigned long long generation = 0;
+	double acc = 0.0, result = 0.0;
+};
+struct Op { bool send; void* buf; size_t bytes; int peer; hipStream_t stream; };
+thread_local std::vector<Op> t_ops;
+thread_local int t_depth = 0;
+size_t type_size(ncclDataType_t t) { return t == ncclDouble ? 8 : 4; }
+}
+
+struct ncclComm { int rank, world; Shared* sh; };
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id)
+{
+	Shared* sh = new Shared;                                      // lives for the test process
+	std::memset(id, 0, sizeof *id);
+	std::memcpy(id->internal, &sh, sizeof sh);
+	return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int world, ncclUniqueId id, int rank)
+{
+	Shared* sh;
+	std::memcpy(&sh, id.internal, sizeof sh);
+	{ std::lock_guard<std::mutex> l(sh->m); sh->world = world; }
+	*comm = new ncclComm{rank, world, sh};
+	return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm) { delete comm; return ncclSuccess; }
+const char* ncclGetErrorString(ncclResult_t) { return "fake_rccl error"; }
+ncclResult_t ncclGroupStart() { ++t_depth; return ncclSuccess; }
+
+static ncclResult_t flush(ncclComm_t comm)
+{
+	Shared* sh = comm->sh;
+	std::vector<Op> ops; ops.swap(t_ops);
+	// 1. post every send: the parcel becomes visible together with an event that marks the sender's stream position
+	for (const Op& o : ops) if (o.send) {
+		Parcel p; p.buf = o.buf; p.bytes = o.bytes; p.posted = true;
+		if (hipEventCreateWithFlags(&p.ready, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
+		if (hipEventCreateWithFlags(&p.done, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
+		if (hipEventRecord(p.ready, o.stream) != hipSuccess) return ncclUnhandledCudaError;
+		std::lock_guard<std::mutex> l(sh->m);
+		sh->box[{comm->rank, o.peer}].push_back(p);
+		sh->cv.notify_all();
+	}
+	// 2. every receive: wait for the matching parcel, copy on the receiver's stream behind the sender's event
+	for (const Op& o : ops) if (!o.send) {
+		std::unique_lock<std::mutex> l(sh->m);
+		auto& q = sh->box[{o.peer, comm->rank}];
+		size_t idx = 0;
+		sh->cv.wait(l, [&] { for (idx = 0; idx < q.size(); ++idx) if (q[idx].posted && !q[idx].copied) return true; return false; });
+		Parcel& p = q[idx];
+		if (p.bytes != o.bytes) return ncclInvalidArgument;
+		if (hipStreamWaitEvent(o.stream, p.ready, 0) != hipSuccess) return ncclUnhandledCudaError;
+		if (hipMemcpyAsync(o.buf, p.buf, p.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess) return ncclUnhandledCudaError;
+		if (hipEventRecord(p.done, o.stream) != hipSuccess) return ncclUnhandledCudaError;
+		p.copied = true;
+		sh->cv.notify_all();
+	}
+	// 3. every send: the sender's stream must not run ahead of the copy out of its buffer
+	for (const Op& o : ops) if (o.send) {
+		std::unique_lock<std::mutex> l(sh->m);
+		auto& q = sh->box[{comm->rank, o.peer}];
+		sh->cv.wait(l, [&] { return !q.empty() && q.front().copied; });
+		Parcel p = q.front();
+		q.erase(q.begin());
+		l.unlock();
+		if (hipStreamWaitEvent(o.stream, p.done, 0) != hipSuccess) return ncclUnhandledCudaError;
+		hipEventDestroy(p.ready);                                 // destruction is deferred by the runtime until completion
+		hipEventDestroy(p.done);
+	}
+	return ncclSuccess;
+}
+
+static thread_local ncclComm_t t_comm = nullptr;
+ncclResult_t ncclGroupEnd()
+{
+	if (--t_depth > 0) return ncclSuccess;
+	return t_comm ? flush(t_comm) : ncclSuccess;
+}
+
+ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
+{
+	t_comm = comm;
+	t_ops.push_back({true, const_cast<void*>(buf), count * type_size(type), peer, stream});
+	return t_depth > 0 ? ncclSuccess : flush(comm);
+}
+
+ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
+{
+	t_comm = comm;
+	t_ops.push_back({false, buf, count * type_size(type), peer, stream});
+	return t_depth > 0 ? ncclSuccess : flush(comm);
+}
+
+ncclResult_t ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm,
+                           hipStream_t stream)
+{
+	if (count != 1 || op != ncclMax) return ncclInvalidArgument;
+	double v = 0.0; float vf = 0.0f;
+	if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+	if (type == ncclDouble) { if (hipMemcpy(&v, sendbuf, 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError; }
+	else { if (hipMemcpy(&vf, sendbuf, 4, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError; v = vf; }
+	Shared* sh = comm->sh;
+	double result;
+	{
+		std::unique_lock<std::mutex> l(sh->m);
+		const unsigned long long gen = sh->generation;
+		if (sh->arrived == 0 || v > sh->acc) sh->acc = v;
+		if (++sh->arrived == comm->world) { sh->result = sh->acc; sh->arrived = 0; ++sh->generation; sh->cv.notify_all(); }
+		else sh->cv.wait(l, [&] { return sh->generation != gen; });
+		result = sh->result;
+	}
+	if (type == ncclDouble) { if (hipMemcpy(recvbuf, &result, 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError; }
+	else { vf = (float)result; if (hipMemcpy(recvbuf, &vf, 4, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError; }
+	return ncclSuccess;
+}
+
+}

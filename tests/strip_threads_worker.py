@@ -1,0 +1,86 @@
+"""Worker of tests/test_gpu_strips.py::test_cxx_strip_loop_with_several_ranks: runs hp_strip_step_batch -- the library's own
+per-iteration strip loop -- with WORLD ranks that are threads of this process sharing the one GPU, over the in-process
+test double of the collective library (tests/fake_rccl), and compares the gathered strips with the single domain
+bit for bit.   usage: strip_threads_worker.py <world> <scheme 0|1|2> <f64|f32> <overlap 0|1> <rain 0|1>"""
+import os
+import sys
+import threading
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hipims-ocl_amd")]
+os.environ["HIPIMS_MI_NO_TORCH"] = "1"
+import numpy as np  # noqa: E402
+
+import hipims_mi as hp  # noqa: E402
+from hipims_mi import strips, synthetic as syn  # noqa: E402
+
+world, scheme, precision, overlap, rain_on = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+cols, rows, steps = 300, 157, 90
+real = np.float64 if precision == "f64" else np.float32
+g = strips.ghost_rows(scheme)
+if rain_on:
+    st, bed, man, rain = syn.s_rain_rows(cols, rows, 0, rows, dx=2.0, dtype=real)
+    dx = 2.0
+else:
+    st, bed, man = syn.s_rough(cols, rows, dtype=real)
+    rain, dx = None, 1.0
+
+
+def attach(dom):
+    if rain is not None:
+        dom.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"], rain["off_y"], rain["interval"])
+
+
+single = hp.Domain(cols, rows, dx=dx, scheme=scheme, precision=precision)
+single.upload(st, bed, man); attach(single); single.set_target_time(1e9)
+single.update_timestep()
+single.step_batch(steps)
+want, want_sc = single.download(), single.read_scalars()
+single.close()
+
+lib = hp.load_library()
+hp._check(lib, lib.hp_comm_load(os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so").encode()), "hp_comm_load")
+uid = hp.comm_unique_id()
+parts = strips.partition(rows, world, g)
+got, scal, errors = [None] * world, [None] * world, []
+start = threading.Barrier(world)
+
+
+def rank_main(r):
+    try:
+        own_lo, own_hi, lo, hi = parts[r]
+        dom = hp.Domain(cols, hi - lo, dx=dx, scheme=scheme, precision=precision, global_rows=rows, row_offset=lo)
+        dom.upload(st[lo:hi], bed[lo:hi], man[lo:hi]); attach(dom)
+        dom.set_halo_overlap(bool(overlap))
+        dom.strip_comm_init(uid, r, world)
+        dom.set_target_time(1e9)
+        start.wait()
+        dom.strip_update_timestep()                       # tst_Reduce + all-reduce + tst_UpdateTimestep, as after any upload
+        for n in (1, 2, steps - 3):                       # odd and even batch lengths: both ping-pong phases at batch ends
+            dom.strip_step_batch(n)
+        dom.sync()
+        got[r] = dom.download()[own_lo - lo:own_hi - lo]
+        scal[r] = dom.read_scalars()
+        dom.strip_comm_destroy()
+        dom.close()
+    except Exception as e:                                # noqa: BLE001
+        errors.append((r, repr(e)))
+        try:
+            start.abort()
+        except Exception:                                 # noqa: BLE001
+            pass
+
+
+threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+for t in threads:
+    t.start()
+for t in threads:
+    t.join(300)
+if errors or any(t.is_alive() for t in threads):
+    print("FAILED", errors, [t.is_alive() for t in threads], flush=True); os._exit(2)
+out = np.concatenate(got, axis=0)
+same = np.array_equal(out.view(np.uint8), want.view(np.uint8))
+times = {(s["time"], s["timestep"]) for s in scal}
+print("ranks", world, "scheme", scheme, precision, "overlap", overlap, "rain", rain_on, "bit-identical", same, "times", times,
+      "single", (want_sc["time"], want_sc["timestep"]), flush=True)
+os._exit(0 if same and times == {(want_sc["time"], want_sc["timestep"])} else 1)

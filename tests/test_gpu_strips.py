@@ -226,3 +226,25 @@ def test_bench_multi_rank_branch_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and d["value"] > 0
     assert "REHEARSAL" in d["config"]["parallelism"] and "cpu_baseline" not in d
     assert d["config"]["successful_iterations"] == 35 and d["roofline"]["cells_per_launch"] == 512 * (512 + 1)
+
+
+@pytest.mark.parametrize("world,scheme,precision,overlap,rain", [
+    (2, hp.SCHEME_GODUNOV, "f64", 1, 0), (3, hp.SCHEME_GODUNOV, "f64", 0, 0), (4, hp.SCHEME_GODUNOV, "f32", 1, 1),
+    (2, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0), (2, hp.SCHEME_INERTIAL, "f64", 1, 0),
+    (3, hp.SCHEME_GODUNOV, "f64", 1, 1)])
+def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, rain):
+    """hp_strip_step_batch / hp_strip_update_timestep with 2-4 REAL ranks: the ranks are threads of one process sharing
+    the GPU, the collective library is the in-process test double tests/fake_rccl (RCCL itself refuses two ranks on
+    one device).  Everything on the engine's side of the nine ncclXxx entry points is the production code: which rows
+    are sent and received where, on which stream, behind which events, and which iterations all-reduce.  The gathered
+    strips must equal the single domain bit for bit, and every rank must report the single domain's time and dt."""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", lib,
+                               os.path.join(os.path.dirname(lib), "fake_rccl.cpp")])
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "strip_threads_worker.py"), str(world),
+                          str(scheme), precision, str(overlap), str(rain)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "bit-identical True" in res.stdout
