@@ -45,12 +45,15 @@ def grid_for(n_gpus, cols, rows, scaling="weak"):
     return 4096, 4096 * n_gpus
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the flux kernel from the newest committed PMC summary (profiles/*_pmc.json,
-    produced by tools/profile_bench.sh + tools/summarize_profile.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes)."""
+def pmc_traffic(kernel_substr, scheme):
+    """HBM bytes per launch of the flux kernel from the newest committed PMC summary of THIS workload (profiles/
+    rNN*_<scheme>4096_pmc.json, produced by tools/profile_bench.sh + tools/summarize_profile.py from the default bench
+    command: FETCH_SIZE x2 + WRITE_SIZE, separate passes)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{scheme}4096_*pmc.json"))):
+        if "developed" in os.path.basename(f):
+            continue
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
@@ -282,7 +285,7 @@ def main():
             and args.workload == "s-dam" \
             and args.math == "fast" and world == 1
         if default_cfg:
-            tr = pmc_traffic(args.scheme + "_march<false")
+            tr = pmc_traffic(args.scheme + "_march<false", args.scheme)
             if tr:
                 out["roofline"]["traffic"] = tr[0] / 1e9 / (k_ms * 1e-3) if k_ms > 0 else None   # GB/s, same unit as achieved
                 out["roofline"]["traffic_bytes_per_launch"] = tr[0]
