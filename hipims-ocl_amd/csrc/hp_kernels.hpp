@@ -431,6 +431,41 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	};
 
 	long y = y0;
+	// Dry land at the start of the tile (most tiles of a flood domain away from the water, entirely).  While every lane's
+	// cell and the cells north and south of it are dry -- for the updated lanes 1..62 the east and west neighbours are
+	// lanes of this wave, so all five dry tests of :248-255 hold -- the reference updates nothing (:254-255): neither the
+	// east faces nor the update are needed, and the north face (the next row's south flux, should that row turn out to
+	// be live) lies between two dry cells: the dry-dry form of the solver, taken directly (face_dry_for_right, the
+	// same statements face_solve executes for such a lane).  The run ends at the first row that is not dry throughout;
+	// the general loop below takes over from there and is not touched by any of this.
+	if (!skip_step) {
+		while (y < y1) {
+			const RowRegs<T>& rn = rP;
+			const bool dryC = (rc.c.z - rc.zb) < vs, dryN = (rn.c.z - rn.zb) < vs;
+			if (!__all(dryC && dryN && dryS)) break;
+			rQ = load_row((y + 2 < p.rows) ? (y + 2) : (p.rows - 1));
+			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
+			const bool write = out_x && disabled;                                      // nulls are carried, dry cells untouched (Q3)
+			if (out_x && !disabled) stale_rows |= 1ull << (unsigned)(y - y0);
+			const Side<T> sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
+			fS = face_dry_for_right<AXIS_Y, STRICT>(sC, sN, vs);
+			buf_store_state(rc.c, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+			if (CFL_MODE == 1) {
+				if (write) {
+					const T s = cfl_speed<STRICT>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
+					if (s > vmax) vmax = s;
+				}
+			} else if (CFL_MODE == 2) {
+				if (out_x) {
+					const T s = cfl_speed<STRICT>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
+					if (s > vmax) vmax = s;
+				}
+			}
+			dryS = dryC;
+			rc = rP; sC = sN; rP = rQ;
+			++y;
+		}
+	}
 	for (; y + 2 <= y1; y += 2) {
 		row_step(y, rP, rQ);
 		row_step(y + 1, rQ, rP);

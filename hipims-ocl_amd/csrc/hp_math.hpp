@@ -387,6 +387,34 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 	return out;
 }
 
+// The face between two DRY cells as the cell on its right / north side sees it: exactly what face_solve returns in
+// .forR for a lane whose two reconstructed depths are below VERY_SMALL (its dry-dry branch, CLSolverHLLC.clc:45-61) --
+// the same statements in the same order, without the wet solve around them.  A cell's depth bounds its face depth
+// (h_face = max(eta - max(zbL, zbR), 0) <= eta - zb), so two dry cells always take that branch.  Used by K1 on rows
+// that are dry land throughout, where this face is the only product of the row anyone may still need.
+template <int AXIS, bool STRICT, typename T>
+__device__ __forceinline__ FaceFlux<T> face_dry_for_right(const Side<T>& L, const Side<T>& R, const T vs)
+{
+	T zbm, hL, hR, shR;
+	if (STRICT) {
+		zbm = (L.zb > R.zb ? L.zb : R.zb);
+		hL = (L.eta - zbm > T(0) ? (L.eta - zbm) : T(0));
+		hR = (R.eta - zbm > T(0) ? (R.eta - zbm) : T(0));
+		shR = zbm - R.eta; if (shR < T(0)) shR = T(0);
+	} else {
+		zbm = fmax_(L.zb, R.zb);
+		hL = fmax_(L.eta - zbm, T(0));
+		hR = fmax_(R.eta - zbm, T(0));
+		shR = fmax_(zbm - R.eta, T(0));
+	}
+	const T etaL = hL + zbm, etaR = hR + zbm;
+	const T vnL = (AXIS == AXIS_X ? L.u0 : L.v0), vnR = (AXIS == AXIS_X ? R.u0 : R.v0);
+	const T qrawR = (AXIS == AXIS_X ? R.qx : R.qy);
+	const bool shared = (hR <= vs && vnL < T(0)) || (hL <= vs && vnR > T(0));
+	const bool stopR = shared || (hR <= vs && qrawR < T(0));
+	return finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
+}
+
 // Point-implicit Manning friction (Schemes/CLFriction.clc:26-72)
 template <bool STRICT, typename T>
 __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, const T n, const T dt, const T vs)
