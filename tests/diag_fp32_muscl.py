@@ -2,7 +2,7 @@
 where and when do they part?  (diagnostic, GPU box)"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ (uses the oracle: test infrastructure)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hipims-ocl_amd")]
 import hipims_mi as hp
 import oracle
