@@ -596,6 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	bool quiet_c = false;                                                          // the row being corrected is a quiet row
 	bool quiet_s = false, same_c = false;                                          // ... the row south of it; every lane's neighbourhood is one state
 	bool fS_ok = true;                                                             // fS holds the south face of the row being corrected
+	bool still_priced = false;                 // the row below was a still row whose (one) wave speed is already in vmax
 	{
 		const RowRegs<T>& rc = rA; const RowRegs<T>& rn = rB;
 		const RowRegs<T> rs2 = load_row(y0 - 2);
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		pre = load_row((y + 3 < p.rows) ? (y + 3) : (p.rows - 1));                 // prefetch (clamped)
 		State4<T> out = rc.c;
 		const T zb_c = rc.zb;
+		bool skip_cfl = false;
 
 		if (!skip_step) {
 			// predictor of the next row (needs rows y, y+1, y+2)
@@ -694,7 +696,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 					fS_ok = false;
 				}
 				if (inertS && out.z > out.zmax && out.zmax > T(-9990.0)) out.zmax = out.z;   // :791-796, all that is left of the update
+				// CFL epilogue: dry cells price at zero; a still row has ONE state across the wave, and if the still row below
+				// (the same state, by its neighbourhood test) has already put that wave speed into vmax, pricing it again
+				// cannot change the maximum
+				skip_cfl = inertD || still_priced;
+				still_priced = inertS && (still_priced || __any(out_x && out.zmax > T(-9999.0)));
 			} else {
+			still_priced = false;
 			if (!fS_ok) {                                   // the row below was a still row: its state is this row's state
 				const Side<T> cs = cell_side(rc);
 				fS = face_solve<AXIS_Y, STRICT, true, true>(cs, cs, vs).forR;
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		}
 
 		buf_store_state(out, srd_dst, out_x ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);
-		if (CFL_MODE == 1 && out_x) {
+		if (CFL_MODE == 1 && !skip_cfl && out_x) {
 			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, zb_c, p.qs);
 			if (s > vmax) vmax = s;
 		}
