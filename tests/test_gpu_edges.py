@@ -129,3 +129,19 @@ def test_long_run_stays_finite_and_conservative(scheme, levels):
     assert (out[inner][..., 1] >= out[inner][..., 0]).all()
     assert sc["batch_successful"] == steps and sc["batch_skipped"] == 0 and sc["time"] > 500.0
     d.close()
+
+
+def test_log_sink_reports_a_rejected_boundary_with_the_reference_level():
+    """A gridded boundary that does not cover the interior cells is rejected at hp_boundary_add_gridded (the reference
+    would read outside its buffer, CLBoundaries.clc:231-236) and the message reaches the log sink at kLevelModelStop."""
+    seen = []
+    hp.set_log_sink(lambda level, text: seen.append((level, text)))
+    try:
+        d = hp.Domain(64, 48, dx=2.0)
+        grids = np.zeros((2, 4, 4))
+        with pytest.raises(hp.HipimsError, match="does not cover"):
+            d.add_gridded(hp.GRIDDED_RAIN_INTENSITY, grids, 8.0, 0.0, 0.0, 300.0)       # 32 m of grid for 128 m of domain
+        d.close()
+    finally:
+        hp.set_log_sink(None)
+    assert seen and seen[-1][0] == 2 and "does not cover" in seen[-1][1]
