@@ -195,8 +195,19 @@ class StripRunner:
         if loop == "cxx":
             if engine_factory is not None or backend != "nccl":
                 raise ValueError("the C++ strip loop runs on the HIP engine over RCCL only")
-            from . import comm_load, comm_unique_id
-            comm_load()
+            from . import HipimsError, comm_load, comm_unique_id
+            try:
+                comm_load()
+            except HipimsError as e:
+                # every rank loads the same library the same way, so they all land here together: the run goes on with
+                # the torch loop (slower host side, same results) and says so in `loop`
+                if "HIPIMS_MI_STRIP_LOOP" in os.environ:
+                    raise
+                import sys
+                print(f"[hipims_mi] C++ strip loop unavailable ({e}); using the torch loop", file=sys.stderr, flush=True)
+                self.loop = loop = "torch"
+        if loop == "cxx":
+            from . import comm_unique_id
             box = [comm_unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(box, src=0)        # the id travels by the host's own means (here: torch)
