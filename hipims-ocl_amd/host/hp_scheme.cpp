@@ -6,12 +6,16 @@
 #include <algorithm>
 #include <utility>
 #include <cmath>
+#include <cstring>
 
 namespace hipims_mi {
 
-void DomainArrays::closeEdges()
+void DomainArrays::closeEdges(bool south, bool north)
 {
-	for (long x = 0; x < cols; ++x) { bedElevations[x] = 9999.9; bedElevations[(size_t)(rows - 1) * cols + x] = 9999.9; }
+	for (long x = 0; x < cols; ++x) {
+		if (south) bedElevations[x] = 9999.9;
+		if (north) bedElevations[(size_t)(rows - 1) * cols + x] = 9999.9;
+	}
 	for (long y = 0; y < rows; ++y) { bedElevations[(size_t)y * cols] = 9999.9; bedElevations[(size_t)y * cols + cols - 1] = 9999.9; }
 }
 
@@ -58,6 +62,13 @@ void CSchemeMI::addBoundaryCell(int depthDefinition, int dischargeDefinition, co
 	boundaries.push_back(std::move(b));
 }
 
+void CSchemeMI::setStrip(int rank, int world, const void* commId, long globalRows, long rowOffset)
+{
+	bStrip = true; iStripRank = rank; iStripWorld = world; lGlobalRows = globalRows; lRowOffset = rowOffset;
+	std::memcpy(cCommId, commId, HP_COMM_ID_BYTES);
+	bAutomaticQueue = false;                                          // batch sizes must agree across the ranks
+}
+
 // prepare1OExecDimensions / Constants / Code / Memory / Kernels / Boundaries collapse into one descriptor
 void CSchemeMI::prepareAll()
 {
@@ -76,6 +87,7 @@ void CSchemeMI::prepareAll()
 	desc.dt_fixed = dTimestep; desc.dt_initial = dTimestep;           // CSchemeGodunov.cpp:862-867
 	desc.t_end = dSimulationLength;
 	desc.math_mode = iMathMode;
+	if (bStrip) { desc.global_rows = lGlobalRows; desc.row_offset = lRowOffset; }
 	if (!check(hp_domain_create(&desc, &hpDomain), "hp_domain_create")) return;
 	for (const PendingBoundary& b : boundaries) {
 		const int rc = b.kind == 0
@@ -87,6 +99,7 @@ void CSchemeMI::prepareAll()
 			                       b.data.data(), b.entries, b.interval, b.length);
 		if (!check(rc, "hp_boundary_add")) return;
 	}
+	if (bStrip && !check(hp_strip_comm_init(hpDomain, cCommId, iStripRank, iStripWorld), "hp_strip_comm_init")) return;
 	dCurrentTimestep = dTimestep;
 	bReady = true;
 }
@@ -128,7 +141,7 @@ void CSchemeMI::runSimulation(double dTarget, double dRealTime)
 	if (dCurrentTime > dTarget + 1E-5) return;                        // :1389-1407 (warning in the reference)
 
 	// batch size: aim for about a second of work, no silly jumps, never beyond the rollback limit (:1420-1448)
-	if (bAutomaticQueue && dRealTime > 1E-5 && ucSyncMethod != syncMethod::kSyncTimestep) {
+	if (bAutomaticQueue && !bStrip && dRealTime > 1E-5 && ucSyncMethod != syncMethod::kSyncTimestep) {
 		const double dBatchDuration = dRealTime - dBatchStartedTime;
 		const unsigned int uiOld = uiQueueAdditionSize;
 		uiQueueAdditionSize = std::max(1u, std::min(uiBatchRate * 3,
@@ -150,7 +163,7 @@ void CSchemeMI::runSimulation(double dTarget, double dRealTime)
 		uiIterationsSinceSync = 0;
 		bUseForcedTimeAdvance = true;
 		if (dCurrentTimestep <= 0.0 && ucSyncMethod == syncMethod::kSyncForecast)
-			check(hp_update_timestep(hpDomain), "hp_update_timestep");   // tst_Reduce + tst_UpdateTimestep
+			check(bStrip ? hp_strip_update_timestep(hpDomain) : hp_update_timestep(hpDomain), "hp_update_timestep");   // tst_Reduce + tst_UpdateTimestep
 		if (dCurrentTime + dCurrentTimestep > dTargetTime + 1E-5) {
 			dCurrentTimestep = dTargetTime - dCurrentTime;
 			bOverrideTimestep = true;
@@ -163,7 +176,7 @@ void CSchemeMI::runSimulation(double dTarget, double dRealTime)
 	unsigned int uiQueueAmount = uiQueueAdditionSize;
 	if (ucSyncMethod == syncMethod::kSyncTimestep) uiQueueAmount = 1; // :1274-1276
 	if (uiIterationsSinceSync < uiRollbackLimit && dCurrentTime < dTargetTime) {   // :1285-1304
-		check(hp_step_batch(hpDomain, uiQueueAmount), "hp_step_batch");
+		check(bStrip ? hp_strip_step_batch(hpDomain, uiQueueAmount) : hp_step_batch(hpDomain, uiQueueAmount), "hp_step_batch");
 		uiIterationsSinceSync += uiQueueAmount;
 		bCellStatesSynced = false;
 	}
@@ -204,7 +217,8 @@ void CSchemeMI::rollbackSimulation(double dTime, double dTarget)
 	check(hp_set_time(hpDomain, dTime), "hp_set_time");
 	check(hp_set_target_time(hpDomain, dTarget), "hp_set_target_time");
 	check(hp_domain_upload(hpDomain, HP_ARRAY_STATE, pDomain->cellStates.data(), pDomain->cellCount() * 32), "upload state");
-	if (ucSyncMethod != syncMethod::kSyncTimestep) check(hp_update_timestep(hpDomain), "hp_update_timestep");
+	if (ucSyncMethod != syncMethod::kSyncTimestep)
+		check(bStrip ? hp_strip_update_timestep(hpDomain) : hp_update_timestep(hpDomain), "hp_update_timestep");
 	bUseForcedTimeAdvance = true;
 	check(hp_reset_counters(hpDomain), "hp_reset_counters");
 	check(hp_sync(hpDomain), "hp_sync");

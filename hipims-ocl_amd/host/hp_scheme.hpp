@@ -30,8 +30,9 @@ struct DomainArrays {
 		manningValues.assign((size_t)c * r, 0.0);
 	}
 	size_t cellCount() const { return (size_t)cols * rows; }
-	// CDomainCartesian::imposeBoundaryModification (Cartesian/CDomainCartesian.cpp:773-799): closed edges
-	void closeEdges();
+	// CDomainCartesian::imposeBoundaryModification (Cartesian/CDomainCartesian.cpp:773-799): closed edges; a row strip
+	// of a larger grid closes its south / north edge only where that is the grid's edge
+	void closeEdges(bool south = true, bool north = true);
 	// CDomain::getVolume
 	double volume() const;
 };
@@ -65,6 +66,14 @@ public:
 	                          uint64_t gridCols, double resolution, double offsetX, double offsetY, double interval);
 	void   addBoundaryCell(int depthDefinition, int dischargeDefinition, const std::vector<uint64_t>& cells,
 	                       const std::vector<double>& series, double interval, double length);
+	// Row-strip decomposition (the reference's multi-domain set + CDomainLink + CMPIManager, CDomainManager.cpp:139-260):
+	// this scheme is rank `rank` of `world` strips of ONE grid of `globalRows` rows; its DomainArrays hold rows
+	// [rowOffset, rowOffset + rows) including the ghost rows next to its neighbours.  `commId` is the HP_COMM_ID_BYTES
+	// blob of hp_comm_unique_id, obtained on rank 0 and handed to every rank by the host's own means (MPI_Bcast in the
+	// reference's world).  The per-iteration ghost-row exchange and the all-reduce of the wave-speed maximum then run
+	// inside the library (hp_strip_step_batch).  Every rank must ask for the same batch sizes: the automatic queue
+	// (sized from each process's own wall clock) is off in this mode.
+	void   setStrip(int rank, int world, const void* commId, long globalRows, long rowOffset);
 	// model::doError's place (main.cpp:631-652): every failure of the library is also handed to this sink
 	static void setLogSink(hp_log_sink_t sink, void* user) { hp_set_log_sink(sink, user); }
 
@@ -128,6 +137,11 @@ private:
 	unsigned long long ulCurrentCellsCalculated = 0;
 	bool         bUpdateTargetTime = false, bOverrideTimestep = false, bUseForcedTimeAdvance = true;
 	bool         bCellStatesSynced = true;
+
+	bool         bStrip = false;
+	int          iStripRank = 0, iStripWorld = 1;
+	long         lGlobalRows = 0, lRowOffset = 0;
+	char         cCommId[HP_COMM_ID_BYTES] = {};
 
 	struct PendingBoundary { int kind, definition; std::vector<double> data; uint64_t entries, rows, cols;
 	                         double interval, length, resolution, offx, offy;

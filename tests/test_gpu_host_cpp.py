@@ -96,3 +96,31 @@ def test_cpp_host_automatic_queue_runs():
     assert res.returncode == 0, res.stderr
     times = [float(l.split()[0]) for l in res.stdout.strip().splitlines()]
     assert np.allclose(times, [0.25, 0.5, 0.75, 1.0], atol=1e-9)
+
+
+@pytest.mark.parametrize("scheme_name,world", [("godunov", 2), ("godunov", 3), ("muscl", 3)])
+def test_cpp_host_strip_mode_matches_the_single_domain(scheme_name, world):
+    """CSchemeMI in strip mode (setStrip -> hp_strip_comm_init / hp_strip_step_batch / hp_strip_update_timestep): the C++
+    host runs one scheme per row strip -- ranks as threads on the one GPU, collective library = the tests' in-process
+    double -- through CModel's output-time loop; times, iteration counts, volume and level checksum of the strips
+    together equal the single domain's."""
+    exe = os.path.join(PKG, "lib", "run_strips")
+    fake = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(exe), "run_strips not built (make -C hipims-ocl_amd/csrc)"
+    if not os.path.exists(fake):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", fake,
+                               os.path.join(os.path.dirname(fake), "fake_rccl.cpp")])
+    cols, rows, duration, freq, batch = 320, 161, 1.5, 0.5, 25
+    strips_run = subprocess.run([exe, fake, str(world), str(cols), str(rows), str(duration), str(freq), scheme_name, str(batch)],
+                                capture_output=True, text=True, timeout=300)
+    assert strips_run.returncode == 0, strips_run.stdout + strips_run.stderr
+    single = subprocess.run([EXE, str(cols), str(rows), str(duration), str(freq), scheme_name, str(batch)],
+                            capture_output=True, text=True, timeout=300)
+    assert single.returncode == 0, single.stderr
+    a = [l.split() for l in strips_run.stdout.strip().splitlines()]
+    b = [l.split() for l in single.stdout.strip().splitlines()]
+    assert len(a) == len(b) == 3
+    for la, lb in zip(a, b):
+        assert float(la[0]) == float(lb[0]) and int(la[1]) == int(lb[1])              # time, successful iterations
+        assert abs(float(la[2]) - float(lb[3])) <= 1e-11 * float(lb[3])                 # volume (summation order differs)
+        assert abs(float(la[3]) - float(lb[4])) <= 1e-12 * abs(float(lb[4]))            # checksum of Z
