@@ -144,7 +144,7 @@ __global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const i
 //    move, the south-face result is carried in registers from the previous row.  Lanes 0 and 63 are halo lanes
 //    (62 updated columns per wave); the row below the segment costs one extra north-face solve per segment.
 //  * The 4-neighbour stencil therefore never re-reads a cell from memory inside a tile: W/E neighbours come
-//    from the wave's own registers via the LDS crossbar (ds_bpermute / DPP), N/S from the register pipeline.
+//    from the wave's own registers via DPP wavefront shifts, N/S from the register pipeline.
 //  * CFL_MODE fuses tst_Reduce into the epilogue: 1 = speeds of what this launch leaves in `dst`
 //    (incl. the stale value of all-dry cells the reference does not write, Q3), 2 = speeds of the source
 //    state (after the boundary kernels), 0 = none.  Edge-ring cells are priced once at upload (edge_max).
