@@ -1071,6 +1071,8 @@ __global__ __launch_bounds__(256) void bdy_area(const Params<T> p, const Scalars
 		any = any || active[k];
 	}
 	if (!any) return;
+	bool need_bed = false;                                                        // only the loss rate looks at the bed (:179-180)
+	for (int k = 0; k < list.count; ++k) need_bed = need_bed || (active[k] && list.b[k].kind == 0 && list.b[k].u.definition == 1);
 	const size_t cells = (size_t)p.cols * p.rows;
 	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x) {
 		const long y = (long)(id / p.cols), x = (long)(id - (size_t)y * p.cols);
@@ -1078,7 +1080,7 @@ __global__ __launch_bounds__(256) void bdy_area(const Params<T> p, const Scalars
 		if (!bdy_in_range(p, x, gy, truncated)) continue;
 		State4<T> c = state[id];
 		if (c.zmax <= T(-9999.0)) continue;                                       // :168-169, :220-221 (first half)
-		const T zb = bed[id];
+		const T zb = need_bed ? bed[id] : T(0);
 		for (int k = 0; k < list.count; ++k) {
 			if (!active[k]) continue;
 			const AreaBdy<T>& b = list.b[k];
