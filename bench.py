@@ -126,6 +126,45 @@ def cpu_baseline(cols, precision, scheme, levels=(10.0, 1.0), budget_s=8.0):
     return out
 
 
+def visible_gpus():
+    """GPUs this process could use, WITHOUT initialising the HIP runtime (the launcher must stay GPU-free: it starts
+    the rank processes and a process that has touched the GPU must not spawn-and-replace itself on this pool)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher's environment: start N fresh rank processes (one per GPU) through
+    torch.distributed.run BEFORE anything here has touched a GPU, relay rank 0's JSON line, exit non-zero if any rank
+    failed.  Stands where the reference starts its per-device domains in-process (Domain/CDomainManager.cpp:203-220)
+    and its MPI ranks through mpirun (MPI/CMPIManager.cpp:852-861).  Never degrades to fewer ranks than asked for."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("HIPIMS_MI_BACKEND", "nccl") != "nccl"
+    have = visible_gpus()
+    need = 1 if rehearsal else args.gpus
+    if have < need:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (RCCL wants one GPU per rank); "
+                         f"refusing to run a smaller job under an N = {args.gpus} request")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("HIPIMS_MI_NO_TORCH", None)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if proc.returncode != 0:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: a rank failed (exit code {proc.returncode})")
+    if len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: expected one JSON line for {args.gpus} ranks, got {lines!r}")
+    print(lines[0], flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,17 +187,21 @@ def main():
     ap.add_argument("--evolve-steps", type=int, default=0, help="untimed steps after the warm-up: time a developed flood")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world == 1:
         # single GPU needs no collectives: keep torch (and its bundled, older HIP runtime) out of the process
         os.environ.setdefault("HIPIMS_MI_NO_TORCH", "1")
     import hipims_mi as hp
     from hipims_mi import synthetic as syn
 
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cols, rows = grid_for(world, args.cols, args.rows, args.scaling)
     scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
     # the partial-inertial scheme is only meaningful for a gentle step (2.0 m | 1.6 m instead of 10 m | 1 m)
@@ -200,7 +243,9 @@ def main():
     runner.save()
     runner.barrier()
     t_warm = time.perf_counter()
-    while time.perf_counter() - t_warm < args.prewarm_s:
+    # every rank must run the same number of passes (each is 25 collective iterations): the decision is taken on the
+    # maximum over ranks of the elapsed time, which is one value everywhere
+    while runner.max_over_ranks(time.perf_counter() - t_warm) < args.prewarm_s:
         runner.step(25)
         runner.barrier()
 
@@ -234,7 +279,7 @@ def main():
         runner.domain.upload(manning=man)                  # a 128 MiB host copy: the clocks settle again afterwards
         del man
         t_warm = time.perf_counter()
-        while time.perf_counter() - t_warm < args.prewarm_s:
+        while runner.max_over_ranks(time.perf_counter() - t_warm) < args.prewarm_s:
             runner.step(25)
             runner.barrier()
         runner.restore()
@@ -248,6 +293,7 @@ def main():
         km_ms, km_n = runner.domain.kernel_timing_read()
         manning_leg = (el_m, km_ms, km_n)
 
+    strip_info = runner.domain.strip_info() if world > 1 and getattr(runner, "loop", "") == "cxx" else None
     if rank == 0:
         cells = cols * rows
         value = cells * args.steps / elapsed / 1e6
@@ -264,7 +310,7 @@ def main():
                                    f"{cols}x{rows}{'' if levels[0] == 10.0 else ' (levels %g|%g m)' % levels}, "
                                    f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
-                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + (f", per-iteration loop: {getattr(runner, 'loop', 'batch call')}" if world > 1 else "") + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
+                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + (f", per-iteration loop: {getattr(runner, 'loop', 'batch call')}" if world > 1 else "") + (f", collective library {strip_info['library']} reporting {strip_info['comm_ranks']} ranks, halo overlap {'on' if strip_info['halo_overlap'] else 'off'}" if strip_info else "") + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
                                                                 else " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"),
                        "timed_steps": [args.warmup + args.evolve_steps, args.warmup + args.evolve_steps + args.steps],
                        "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},

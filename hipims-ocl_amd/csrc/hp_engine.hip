@@ -36,6 +36,8 @@ struct Rccl {
 	decltype(&ncclRecv)          Recv = nullptr;
 	decltype(&ncclAllReduce)     AllReduce = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	decltype(&ncclCommCount)     CommCount = nullptr;        // optional (reporting only)
+	std::string path;                                        // what the dynamic loader resolved the library to
 } g_rccl;
 
 std::atomic<hp_log_sink_t> g_log_sink{nullptr};
@@ -104,6 +106,7 @@ struct hp_domain {
 	// halo overlap (strip decomposition): the row segments next to the ghost rows run on their own stream so the
 	// neighbours' halo transfer can start while the interior segments are still being computed
 	bool             halo_overlap = false;
+	bool             halo_overlap_set = false;        // the host chose explicitly (hp_set_halo_overlap): comm_init keeps it
 	hipStream_t      stream_halo = nullptr;
 	hipEvent_t       ev_fork = nullptr, ev_halo = nullptr;
 	bool             fork_is_advance = false;         // ev_fork was recorded BY the last advance_time launch
@@ -752,10 +755,8 @@ int hp_state_save(hp_domain_t* d)
 	if (d->in_step) return fail(HP_ERR_STATE, "hp_state_save between hp_step_begin and hp_step_end");
 	const size_t bytes = d->cells * 4 * d->esize;
 	const size_t sc_bytes = d->desc.precision == 8 ? sizeof(Scalars<double>) : sizeof(Scalars<float>);
-	if (!d->saved_state) {
-		HIP_TRY(hipMalloc(&d->saved_state, bytes));
-		HIP_TRY(hipMalloc(&d->saved_scalars, sc_bytes + 4 * d->esize));
-	}
+	if (!d->saved_state) HIP_TRY(hipMalloc(&d->saved_state, bytes));
+	if (!d->saved_scalars) HIP_TRY(hipMalloc(&d->saved_scalars, sc_bytes + 4 * d->esize));
 	HIP_TRY(hipMemcpyAsync(d->saved_state, d->state[d->use_alt], bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->saved_scalars, d->scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync((char*)d->saved_scalars + sc_bytes, d->cfl_slot, 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
@@ -781,8 +782,9 @@ int hp_state_restore(hp_domain_t* d)
 	HIP_TRY(hipMemcpyAsync(d->scalars, d->saved_scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
 	d->use_alt = d->saved_use_alt;
-	d->need_full_reduce = d->saved_full_reduce;
-	d->edge_dirty = d->saved_edge_dirty;
+	// a bed or state upload between save and restore has left its own marks: they stay
+	d->need_full_reduce = d->need_full_reduce || d->saved_full_reduce;
+	d->edge_dirty = d->edge_dirty || d->saved_edge_dirty;
 	d->fork_is_advance = false;
 	return HP_OK;
 }
@@ -1074,6 +1076,7 @@ int hp_set_halo_overlap(hp_domain_t* d, int on)
 	if (!d) return fail(HP_ERR_INVALID, "null domain");
 	if (d->in_step) return fail(HP_ERR_STATE, "hp_set_halo_overlap inside an iteration");
 	d->halo_overlap = on != 0;
+	d->halo_overlap_set = true;
 	return HP_OK;
 }
 
@@ -1145,20 +1148,47 @@ extern "C" {
 int hp_comm_load(const char* library_path)
 {
 	if (g_rccl.handle) return HP_OK;
-	const char* candidates[] = {library_path, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+	// an explicit path is the only candidate (the caller names the copy its process already uses; silently picking
+	// another one could bind a second HIP runtime); NULL = the system's
+	const bool given = library_path && *library_path;
+	const char* candidates[] = {given ? library_path : "librccl.so", given ? nullptr : "librccl.so.1",
+	                            given ? nullptr : "/opt/rocm/lib/librccl.so"};
 	void* h = nullptr;
+	std::string why = "not found";
 	for (const char* c : candidates) {
 		if (!c || !*c) continue;
 		h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
 		if (h) break;
+		const char* e = dlerror();           // returns the message ONCE and clears it
+		if (e) why = e;
 	}
-	if (!h) return fail(HP_ERR_UNSUPPORTED, std::string("cannot load the RCCL library: ") + (dlerror() ? dlerror() : "not found"));
+	if (!h) return fail(HP_ERR_UNSUPPORTED, "cannot load the RCCL library: " + why);
 	Rccl r;
 	r.handle = h;
 #define SYM(name) r.name = (decltype(r.name))dlsym(h, "nccl" #name); if (!r.name) { dlclose(h); return fail(HP_ERR_UNSUPPORTED, "RCCL library lacks nccl" #name); }
 	SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(GroupStart) SYM(GroupEnd) SYM(Send) SYM(Recv) SYM(AllReduce) SYM(GetErrorString)
 #undef SYM
+	r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
+	Dl_info where;
+	if (dladdr((void*)r.AllReduce, &where) && where.dli_fname) r.path = where.dli_fname;
 	g_rccl = r;
+	return HP_OK;
+}
+
+int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out)
+{
+	if (!out) return fail(HP_ERR_INVALID, "out == NULL");
+	std::memset(out, 0, sizeof *out);
+	std::snprintf(out->library, sizeof out->library, "%s", g_rccl.path.c_str());
+	out->comm_ranks = -1;
+	if (!d) return HP_OK;                                                // library path only
+	out->comm_rank = d->comm_rank;
+	out->halo_overlap = d->halo_overlap ? 1 : 0;
+	if (d->comm && g_rccl.CommCount) {
+		int n = -1;
+		RCCL_TRY(g_rccl.CommCount(d->comm, &n));
+		out->comm_ranks = n;                                             // what the LIBRARY says, not what the caller passed
+	}
 	return HP_OK;
 }
 
@@ -1190,7 +1220,7 @@ int hp_strip_comm_init(hp_domain_t* d, const void* id, int rank, int world)
 	RCCL_TRY(g_rccl.CommInitRank(&d->comm, world, uid, rank));
 	d->comm_rank = rank; d->comm_world = world;
 	if (!d->ev_xchg) HIP_TRY(hipEventCreateWithFlags(&d->ev_xchg, hipEventDisableTiming));
-	d->halo_overlap = world > 1;
+	if (!d->halo_overlap_set) d->halo_overlap = world > 1;             // default only: an explicit choice stands
 	return HP_OK;
 }
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
     "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_set_halo_overlap",
     "hp_stream_halo", "hp_comm_load", "hp_comm_unique_id", "hp_strip_comm_init", "hp_strip_step_batch", "hp_strip_update_timestep",
-    "hp_strip_comm_destroy", "hp_timer_start",
+    "hp_strip_comm_destroy", "hp_strip_info", "hp_timer_start",
     "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read",
 ]
 
@@ -73,6 +73,11 @@ class DomainDesc(C.Structure):
                 ("dt_fixed", C.c_double), ("dt_initial", C.c_double), ("t_end", C.c_double),
                 ("quirks", C.c_uint32), ("math_mode", C.c_int32), ("kernel", C.c_int32),
                 ("global_rows", C.c_int64), ("row_offset", C.c_int64)]
+
+
+class StripInfo(C.Structure):
+    _fields_ = [("library", C.c_char * 256), ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32),
+                ("halo_overlap", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ScalarsOut(C.Structure):
@@ -143,6 +148,7 @@ def load_library(path: str | None = None):
     lib.hp_strip_step_batch.argtypes = [C.c_void_p, C.c_uint32]
     lib.hp_strip_update_timestep.argtypes = [C.c_void_p]
     lib.hp_strip_comm_destroy.argtypes = [C.c_void_p]
+    lib.hp_strip_info.argtypes = [C.c_void_p, C.POINTER(StripInfo)]
     lib.hp_timer_start.argtypes = [C.c_void_p]
     lib.hp_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.hp_kernel_timing.argtypes = [C.c_void_p, C.c_int]
@@ -355,6 +361,12 @@ class Domain:
 
     def strip_update_timestep(self):
         _check(self.lib, self.lib.hp_strip_update_timestep(self.h), "hp_strip_update_timestep")
+
+    def strip_info(self):
+        info = StripInfo()
+        _check(self.lib, self.lib.hp_strip_info(self.h, C.byref(info)), "hp_strip_info")
+        return dict(library=info.library.decode(errors="replace"), comm_ranks=info.comm_ranks, comm_rank=info.comm_rank,
+                    halo_overlap=bool(info.halo_overlap))
 
     def strip_comm_destroy(self):
         _check(self.lib, self.lib.hp_strip_comm_destroy(self.h), "hp_strip_comm_destroy")

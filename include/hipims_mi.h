@@ -246,12 +246,24 @@ int hp_stream_halo(hp_domain_t* d, void** hip_stream);
  *      torch/lib/librccl.so), or NULL for the system's.  The unique id is created on rank 0 and handed to the other
  *      ranks by the host's own means (MPI_Bcast in HiPIMS, a torch broadcast in this repository's tests). ---- */
 #define HP_COMM_ID_BYTES 128
-int hp_comm_load(const char* rccl_library_path);
+int hp_comm_load(const char* rccl_library_path);   /* a path is tried alone; NULL tries librccl.so, librccl.so.1, /opt/rocm/lib/librccl.so */
 int hp_comm_unique_id(void* id_out /* HP_COMM_ID_BYTES */);
-int hp_strip_comm_init(hp_domain_t* d, const void* id, int rank, int world);   /* collective: every rank calls it; turns the halo overlap on */
+int hp_strip_comm_init(hp_domain_t* d, const void* id, int rank, int world);   /* collective: every rank calls it; turns the halo overlap on unless hp_set_halo_overlap chose */
 int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations);               /* hp_step_batch for a strip */
 int hp_strip_update_timestep(hp_domain_t* d);                                 /* hp_update_timestep for a strip (collective) */
 int hp_strip_comm_destroy(hp_domain_t* d);
+/* What the strip loop is really running on (reporting: bench.py puts it into its JSON line).  `library` is the file the
+ * dynamic loader resolved the collective library to, `comm_ranks` the rank count that library reports for the domain's
+ * communicator (ncclCommCount; -1 without a communicator).  d == NULL: library path only.  No reference counterpart
+ * (CMPIManager logs its node count, MPI/CMPIManager.cpp:63-80). */
+typedef struct {
+	char    library[256];
+	int32_t comm_ranks;
+	int32_t comm_rank;
+	int32_t halo_overlap;        /* 1: halo rows on their own stream, the transfer overlaps the interior launch */
+	int32_t reserved;
+} hp_strip_info_t;
+int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out);
 
 /* ---- measurement hooks (no reference counterpart; COCLDevice has no profiling queue, COCLDevice.cpp:283-288) ----
  * Bracket a region of the domain's stream with HIP events and return the elapsed milliseconds. */

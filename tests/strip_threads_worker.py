@@ -53,6 +53,8 @@ def rank_main(r):
         dom.upload(st[lo:hi], bed[lo:hi], man[lo:hi]); attach(dom)
         dom.set_halo_overlap(bool(overlap))
         dom.strip_comm_init(uid, r, world)
+        info = dom.strip_info()                           # an explicit choice survives comm_init
+        assert info["halo_overlap"] == bool(overlap) and info["comm_rank"] == r, info
         dom.set_target_time(1e9)
         start.wait()
         dom.strip_update_timestep()                       # tst_Reduce + all-reduce + tst_UpdateTimestep, as after any upload

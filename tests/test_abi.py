@@ -73,3 +73,43 @@ def test_log_sink_receives_failures_with_the_reference_error_level():
     assert len(seen) == 1 and seen[0][0] == 2 and "size mismatch" in seen[0][1]
     assert lib.hp_domain_create(C.byref(d), C.byref(h)) == -1          # sink removed: no further callbacks
     assert len(seen) == 1
+
+
+def test_comm_load_failure_is_an_error_code_not_a_crash():
+    # dlerror() was called twice (the second call returns NULL) and the message was built from NULL.
+    # Run in a child process: a regression here is a segfault, which must fail this test, not end the session.
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import hipims_mi as hp; lib = hp.load_library();"
+            "rc = lib.hp_comm_load(b'/nonexistent/dir/librccl.so'); msg = lib.hp_last_error().decode();"
+            "print(rc, msg); sys.exit(0 if rc == -4 and 'cannot load the RCCL library' in msg and 'nonexistent' in msg else 1)"
+            % os.path.join(ROOT, "hipims-ocl_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HIPIMS_MI_NO_TORCH="1"))
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_strip_info_without_a_domain_reports_no_communicator():
+    lib = hipims_mi.load_library()
+    info = hipims_mi.StripInfo()
+    assert lib.hp_strip_info(None, C.byref(info)) == 0 and info.comm_ranks == -1
+    assert lib.hp_strip_info(None, None) == -1
+
+
+def test_bench_never_runs_a_smaller_job_than_asked_for():
+    """`python bench.py --gpus 8` without a launcher's environment used to run N = 1 and print
+    "n_gpus": 1.  It now starts the ranks itself -- and where the GPUs are not there it must refuse."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are present: the self-launch would really run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HIPIMS_MI_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout and "refusing" in r.stderr
+    # a launcher's environment that disagrees with --gpus is an error too, before anything touches a GPU
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout and "WORLD_SIZE=1" in r.stderr

@@ -213,12 +213,18 @@ def test_multi_process_rehearsal_on_one_gpu(scheme, world, tmp_path):
 
 
 def test_bench_multi_rank_branch_rehearsal():
-    """bench.py's N > 1 branch end to end (strip inputs, barrier, max-over-ranks timing, rank-0 JSON line) with two
-    processes sharing the GPU over the rehearsal transport; the numbers are meaningless, the line must be well formed."""
+    """bench.py's N > 1 branch end to end THROUGH ITS OWN LAUNCHER (`python bench.py --gpus 2`, no torchrun around it:
+    it starts the two rank processes itself), default time-based pre-warm included (its pass count must be the same on
+    both ranks), strip inputs, barrier, max-over-ranks timing, rank-0 JSON line; two processes share the GPU over the
+    rehearsal transport; the numbers are meaningless, the line must be well formed."""
     import json
+    import subprocess
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = _torchrun(2, [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--cols", "512",
-                      "--rows", "1024", "--repeats", "1", "--prewarm-s", "0"], env_extra={"HIPIMS_MI_BACKEND": "gloo"})
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
+                        "--cols", "512", "--rows", "1024", "--repeats", "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(env, HIPIMS_MI_BACKEND="gloo"))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                     # rank 0 only
@@ -226,6 +232,19 @@ def test_bench_multi_rank_branch_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and d["value"] > 0
     assert "REHEARSAL" in d["config"]["parallelism"] and "cpu_baseline" not in d
     assert d["config"]["successful_iterations"] == 35 and d["roofline"]["cells_per_launch"] == 512 * (512 + 1)
+
+
+def test_bench_line_names_the_collective_library_on_the_cxx_loop():
+    """One real RCCL rank through bench.py's N > 1 code path is not reachable (N = 1 takes the batch call), so the
+    reporting hook is checked where it lives: the C++ strip loop with a 1-rank communicator says which library it
+    loaded and how many ranks THAT LIBRARY counts."""
+    r = strips.StripRunner(64, 64, rank=0, world=1, loop="cxx")
+    try:
+        info = r.domain.strip_info()
+    finally:
+        r.close()
+    assert info["library"].endswith(".so") or ".so." in info["library"]
+    assert "rccl" in info["library"] and info["comm_ranks"] == 1 and info["comm_rank"] == 0
 
 
 @pytest.mark.parametrize("world,scheme,precision,overlap,rain", [

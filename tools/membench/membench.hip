@@ -26,6 +26,68 @@ __global__ __launch_bounds__(256) void k_linear(const d2* __restrict__ src, cons
 	}
 }
 
+// Round 3: k_linear above issues ONE 16-B load per loop trip (plus a conditional second one), so a
+// wave never has more than a few hundred bytes in flight and the "copy ceiling" it measured was its own latency bound.
+// k_copy_u is the guide's float4 copy done properly: UNROLL independent 16-B loads per lane issued back to back, then
+// UNROLL stores, grid-stride over the buffer.  `bed_too` adds the 8 B/cell bed read (one 16-B load per two cells).
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_copy_u(const d2* __restrict__ src, const d2* __restrict__ bed2, d2* __restrict__ dst,
+                                                size_t n2, int bed_too)
+{
+	const size_t chunk = (size_t)256 * UNROLL;                        // 16-B elements per block trip
+	double acc = 0;
+	for (size_t base = (size_t)blockIdx.x * chunk; base < n2; base += (size_t)gridDim.x * chunk) {
+		d2 v[UNROLL];
+		#pragma unroll
+		for (int k = 0; k < UNROLL; ++k) {
+			const size_t i = base + (size_t)k * 256 + threadIdx.x;
+			v[k] = i < n2 ? __builtin_nontemporal_load(&src[i]) : d2{0, 0};
+		}
+		if (bed_too) {
+			// bed is a quarter of the state's bytes: one 16-B load for every four state elements
+			#pragma unroll
+			for (int k = 0; k < UNROLL; k += 4) {
+				const size_t i = (base + (size_t)k * 256) / 4 + threadIdx.x;
+				if (i < n2 / 4) { const d2 b = bed2[i]; acc += b.x + b.y; }
+			}
+		}
+		#pragma unroll
+		for (int k = 0; k < UNROLL; ++k) {
+			const size_t i = base + (size_t)k * 256 + threadIdx.x;
+			if (k == 0) v[k].x += acc * 1e-300;
+			if (i < n2) dst[i] = v[k];
+		}
+	}
+}
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_copy_u_plain(const d2* __restrict__ src, const d2* __restrict__ bed2, d2* __restrict__ dst,
+                                                      size_t n2, int bed_too)
+{
+	const size_t chunk = (size_t)256 * UNROLL;
+	double acc = 0;
+	for (size_t base = (size_t)blockIdx.x * chunk; base < n2; base += (size_t)gridDim.x * chunk) {
+		d2 v[UNROLL];
+		#pragma unroll
+		for (int k = 0; k < UNROLL; ++k) {
+			const size_t i = base + (size_t)k * 256 + threadIdx.x;
+			v[k] = i < n2 ? src[i] : d2{0, 0};
+		}
+		if (bed_too) {
+			#pragma unroll
+			for (int k = 0; k < UNROLL; k += 4) {
+				const size_t i = (base + (size_t)k * 256) / 4 + threadIdx.x;
+				if (i < n2 / 4) { const d2 b = bed2[i]; acc += b.x + b.y; }
+			}
+		}
+		#pragma unroll
+		for (int k = 0; k < UNROLL; ++k) {
+			const size_t i = base + (size_t)k * 256 + threadIdx.x;
+			if (k == 0) v[k].x += acc * 1e-300;
+			if (i < n2) dst[i] = v[k];
+		}
+	}
+}
+
 template <int DEPTH, bool CONTIG>
 __global__ __launch_bounds__(256) void k_march(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst,
                                                int cols, int rows, int rseg, int groups, int ntiles)
@@ -63,7 +125,7 @@ __global__ __launch_bounds__(256) void k_march(const d2* __restrict__ src, const
 
 int main(int argc, char** argv)
 {
-	const int cols = 4096, rows = 4096;
+	const int cols = 4096, rows = argc > 1 ? atoi(argv[1]) : 4096;
 	const size_t cells = (size_t)cols * rows;
 	d2 *src, *dst; double* bed;
 	CK(hipMalloc(&src, cells * 32)); CK(hipMalloc(&dst, cells * 32)); CK(hipMalloc(&bed, cells * 8));
@@ -82,6 +144,40 @@ int main(int argc, char** argv)
 	for (int blocks : {2048, 4096, 8192, 16384})
 		timeit(("linear float4-shaped copy, blocks=" + std::to_string(blocks)).c_str(),
 		       [&] { hipLaunchKernelGGL(k_linear, dim3(blocks), dim3(256), 0, 0, src, bed, dst, cells); });
+	// the guide's shape: many independent 16-B loads in flight per lane.  72 B/cell with the bed, 64 B/cell without.
+	for (int bed_too : {1, 0}) {
+		const double b = (double)cells * (bed_too ? 72 : 64);
+		auto timeit2 = [&](const char* name, auto launch) {
+			for (int i = 0; i < 5; ++i) launch();
+			CK(hipEventRecord(e0));
+			const int n = 50;
+			for (int i = 0; i < n; ++i) launch();
+			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+			float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= n;
+			printf("%-60s %.4f ms  %.2f TB/s\n", name, ms, b / ms / 1e9);
+		};
+		for (int blocks : {1024, 2048, 4096, 8192, 65536}) {
+			char nm[160];
+			snprintf(nm, sizeof nm, "unrolled x4 copy (nt loads)%s, blocks=%d", bed_too ? " + bed" : "", blocks);
+			timeit2(nm, [&] { hipLaunchKernelGGL((k_copy_u<4>), dim3(blocks), dim3(256), 0, 0, src, (const d2*)bed, dst, cells * 2, bed_too); });
+			snprintf(nm, sizeof nm, "unrolled x8 copy (nt loads)%s, blocks=%d", bed_too ? " + bed" : "", blocks);
+			timeit2(nm, [&] { hipLaunchKernelGGL((k_copy_u<8>), dim3(blocks), dim3(256), 0, 0, src, (const d2*)bed, dst, cells * 2, bed_too); });
+			snprintf(nm, sizeof nm, "unrolled x4 copy (plain loads)%s, blocks=%d", bed_too ? " + bed" : "", blocks);
+			timeit2(nm, [&] { hipLaunchKernelGGL((k_copy_u_plain<4>), dim3(blocks), dim3(256), 0, 0, src, (const d2*)bed, dst, cells * 2, bed_too); });
+			snprintf(nm, sizeof nm, "unrolled x8 copy (plain loads)%s, blocks=%d", bed_too ? " + bed" : "", blocks);
+			timeit2(nm, [&] { hipLaunchKernelGGL((k_copy_u_plain<8>), dim3(blocks), dim3(256), 0, 0, src, (const d2*)bed, dst, cells * 2, bed_too); });
+		}
+	}
+	{
+		// hipMemcpyAsync device-to-device of the state alone, for reference (64 B/cell)
+		const double b = (double)cells * 64;
+		for (int i = 0; i < 3; ++i) CK(hipMemcpyAsync(dst, src, cells * 32, hipMemcpyDeviceToDevice, 0));
+		CK(hipEventRecord(e0));
+		for (int i = 0; i < 20; ++i) CK(hipMemcpyAsync(dst, src, cells * 32, hipMemcpyDeviceToDevice, 0));
+		CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+		printf("%-60s %.4f ms  %.2f TB/s\n", "hipMemcpyAsync D2D (state only)", ms, b / ms / 1e9);
+	}
 	for (int rseg : {16, 32, 64}) {
 		const int groups = cols / 64 / 4, nsegs = (rows + rseg - 1) / rseg, ntiles = groups * nsegs;
 		const unsigned blocks = (ntiles + 7) / 8 * 8;
