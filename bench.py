@@ -176,8 +176,9 @@ def main():
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--math", choices=["fast", "strict"], default="fast")
     ap.add_argument("--kernel", choices=["auto", "basic"], default="auto")
-    ap.add_argument("--workload", choices=["s-dam", "s-rain"], default="s-dam",
-                    help="s-dam: BASELINE configs[1..3]; s-rain: configs[4] (initially dry terrain + gridded rainfall, dx = 2 m)")
+    ap.add_argument("--workload", choices=["s-dam", "s-rain", "s-rough"], default="s-dam",
+                    help="s-dam: BASELINE configs[1..3]; s-rain: configs[4] (initially dry terrain + gridded rainfall, dx = 2 m); "
+                         "s-rough: SURVEY 8(d)'s wet/dry rough terrain at full size (every tile on the general path; N = 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = 16.8 Mcell per GPU along the configs' ladder (default); strong = 4096^2 cut into N strips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -228,6 +229,11 @@ def main():
         runner.upload(st, bed, man)
         runner.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"],
                                   rain["off_y"], rain["interval"])
+    elif args.workload == "s-rough":
+        if world != 1:
+            raise SystemExit("--workload s-rough is a single-GPU diagnostic")
+        st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
+        runner.upload(st, bed, man)
     else:
         st, bed, man = (syn.s_dam(cols, runner.local_rows_total, dtype=real, levels=levels) if world == 1
                         else runner.make_s_dam(real, levels=levels))
@@ -306,7 +312,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "repeats_ms_per_step": [r[0] / args.steps * 1e3 for r in runs],
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{'S-RAIN gridded-rainfall on dry terrain' if args.workload == 's-rain' else 'S-DAM flat-DEM dam-break'} "
+            "config": {"workload": f"{ {'s-rain': 'S-RAIN gridded-rainfall on dry terrain', 's-rough': 'S-ROUGH wet/dry rough terrain', 's-dam': 'S-DAM flat-DEM dam-break'}[args.workload] } "
                                    f"{cols}x{rows}{'' if levels[0] == 10.0 else ' (levels %g|%g m)' % levels}, "
                                    f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
@@ -319,7 +325,7 @@ def main():
                          "kernel": runner.flux_kernel_name, "avg_launch_ms": k_ms, "launches_sampled": k_n,
                          "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": cells_per_launch},
         }
-        if args.workload in ("s-dam", "s-rain"):
+        if args.workload in ("s-dam", "s-rain", "s-rough"):
             # both synthetic workloads have ONE Manning value, which the engine passes as a scalar: the bytes this
             # launch really has to move are 72 (fp64) / 36 (fp32) per cell; SURVEY 8(d)'s contract figure stays above
             wb = bpc * 0.9

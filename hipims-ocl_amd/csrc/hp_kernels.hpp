@@ -276,12 +276,15 @@ struct TileMap {
 	int  band_rows;              // rows per band
 	int  rseg, nbig;             // tall segments per band
 	int  rseg_tail, ntail;       // short segments per band (after the tall ones)
+	int  reverse;                // walk each band's tiles in the opposite order (alternate iterations: see hp_engine.hip)
 };
 
 // rows [y0, y1) and the column strip of this wave; false if the block / wave has nothing to do (wave-uniform)
 __device__ __forceinline__ bool tile_rows(const TileMap& tm, const int wave, long& strip, long& y0, long& y1)
 {
-	const unsigned band = blockIdx.x % (unsigned)tm.nbands, i = blockIdx.x / (unsigned)tm.nbands;
+	const unsigned band = blockIdx.x % (unsigned)tm.nbands;
+	unsigned i = blockIdx.x / (unsigned)tm.nbands;
+	if (tm.reverse) i = (unsigned)(tm.groups * (tm.nbig + tm.ntail)) - 1u - i;
 	const unsigned nbig_tiles = (unsigned)(tm.groups * tm.nbig);
 	const long band_y0 = tm.y_begin + (long)band * tm.band_stride;
 	const long band_y1 = (band_y0 + tm.band_rows < tm.y_end) ? (band_y0 + tm.band_rows) : tm.y_end;
@@ -336,12 +339,18 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
 	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
 
-	auto load_row = [&](const long y) {
+	// `live` = false: a prefetch slot that no row step will read (the row beyond the tile's north halo row).  The lanes
+	// then present an out-of-range offset: the range check answers with zeros and NO memory request is made -- the slot
+	// keeps its place in the wave's vmcnt sequence without fetching a row from HBM (round 2 fetched 21 rows per 18-row
+	// tile; 20 are needed).
+	auto load_row = [&](const long y, const bool live = true) {
 		RowRegs<T> r;
 		const unsigned k = (unsigned)(y - (y0 - 1));                               // wave-uniform -> SGPR offsets
-		r.c = buf_load_state(srd_src, voff_state, k * row_state, T());
-		r.zb = buf_load_scalar(srd_bed, voff_scalar, k * row_scalar, T());
-		r.n = p.manning_uniform ? p.manning_value : buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
+		unsigned vs_ = live ? voff_state : HP_OOB, vc_ = live ? voff_scalar : HP_OOB;
+		asm volatile("" : "+v"(vs_), "+v"(vc_));                                   // a select, never a branch around the loads
+		r.c = buf_load_state(srd_src, vs_, k * row_state, T());
+		r.zb = buf_load_scalar(srd_bed, vc_, k * row_scalar, T());
+		r.n = p.manning_uniform ? p.manning_value : buf_load_scalar(srd_man, vc_, k * row_scalar, T());
 		return r;
 	};
 
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 
 	// one row: `rc` is updated, `rn` is its northern neighbour (already landed), `pre` receives the prefetch of row y+2
 	auto row_step = [&](const long y, const RowRegs<T>& rn, RowRegs<T>& pre) {
-		pre = load_row((y + 2 < p.rows) ? (y + 2) : (p.rows - 1));                 // prefetch (clamped)
+		pre = load_row((y + 2 <= y1) ? (y + 2) : y1, y + 2 <= y1);                 // prefetch; nothing beyond the north halo row y1
 		State4<T> out = rc.c;
 		bool write = out_x;
 		Side<T> sN = sC;
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			const RowRegs<T>& rn = rP;
 			const bool dryC = (rc.c.z - rc.zb) < vs, dryN = (rn.c.z - rn.zb) < vs;
 			if (!__all(dryC && dryN && dryS)) break;
-			rQ = load_row((y + 2 < p.rows) ? (y + 2) : (p.rows - 1));
+			rQ = load_row((y + 2 <= y1) ? (y + 2) : y1, y + 2 <= y1);
 			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
 			const bool write = out_x && disabled;                                      // nulls are carried, dry cells untouched (Q3)
 			if (out_x && !disabled) stale_rows |= 1ull << (unsigned)(y - y0);
@@ -562,13 +571,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
 	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
 
-	auto load_row = [&](const long y) {
+	auto load_row = [&](const long y, const bool live = true) {                 // `live`: see K1
 		RowRegs<T> r;
 		const unsigned k = (unsigned)(y - (y0 - 2));
-		r.c = buf_load_state(srd_src, voff_state, k * row_state, T());
-		r.zb = buf_load_scalar(srd_bed, voff_scalar, k * row_scalar, T());
+		unsigned vs_ = live ? voff_state : HP_OOB, vc_ = live ? voff_scalar : HP_OOB;
+		asm volatile("" : "+v"(vs_), "+v"(vc_));
+		r.c = buf_load_state(srd_src, vs_, k * row_state, T());
+		r.zb = buf_load_scalar(srd_bed, vc_, k * row_scalar, T());
 		if (UNIFORM_N) r.n = p.manning_value;               // one value everywhere (found at upload): stays a scalar
-		else           r.n = buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
+		else           r.n = buf_load_scalar(srd_man, vc_, k * row_scalar, T());
 		return r;
 	};
 	auto predict = [&](const RowRegs<T>& south, const RowRegs<T>& mid, const RowRegs<T>& north, bool& dry_e, bool& dry_w,
@@ -621,7 +632,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	// `pre` receives the prefetch of row y+3; the row in flight is never copied (see K1).  On return `rn` is the row to
 	// correct next and `rc`'s registers hold ITS northern neighbour (back from LDS): the caller swaps the two names.
 	auto row_step = [&](const long y, RowRegs<T>& rc, RowRegs<T>& rn, const RowRegs<T>& rnn, RowRegs<T>& pre) {
-		pre = load_row((y + 3 < p.rows) ? (y + 3) : (p.rows - 1));                 // prefetch (clamped)
+		// prefetch; the predictor of row y1 is the last consumer and reads up to row y1 + 1 (<= rows - 1)
+		pre = load_row((y + 3 <= y1 + 1) ? (y + 3) : (y1 + 1), y + 3 <= y1 + 1);
 		State4<T> out = rc.c;
 		const T zb_c = rc.zb;
 		bool skip_cfl = false;
@@ -808,12 +820,14 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
 	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
 
-	auto load_row = [&](const long y) {
+	auto load_row = [&](const long y, const bool live = true) {                 // `live`: see K1
 		RowRegs<T> r;
 		const unsigned k = (unsigned)(y - (y0 - 1));
-		r.c = buf_load_state(srd_src, voff_state, k * row_state, T());
-		r.zb = buf_load_scalar(srd_bed, voff_scalar, k * row_scalar, T());
-		r.n = uniform_n ? p.manning_value : buf_load_scalar(srd_man, voff_scalar, k * row_scalar, T());
+		unsigned vs_ = live ? voff_state : HP_OOB, vc_ = live ? voff_scalar : HP_OOB;
+		asm volatile("" : "+v"(vs_), "+v"(vc_));
+		r.c = buf_load_state(srd_src, vs_, k * row_state, T());
+		r.zb = buf_load_scalar(srd_bed, vc_, k * row_scalar, T());
+		r.n = uniform_n ? p.manning_value : buf_load_scalar(srd_man, vc_, k * row_scalar, T());
 		return r;
 	};
 	auto flux = [&](const T n, const T q_prev, const T z_up, const T b_up, const T z_down, const T b_down) {
@@ -830,7 +844,7 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 	}
 
 	auto row_step = [&](const long y, const RowRegs<T>& rn, RowRegs<T>& pre) {
-		pre = load_row((y + 2 < p.rows) ? (y + 2) : (p.rows - 1));
+		pre = load_row((y + 2 <= y1) ? (y + 2) : y1, y + 2 <= y1);
 		State4<T> out = rc.c;
 		bool write = out_x;
 
@@ -1134,7 +1148,7 @@ __global__ __launch_bounds__(64) void bdy_cell(const Params<T> p, const Scalars<
 		c.z = fmax_(zb, ts[1]);
 	} else if (fabs_(ts[2]) > p.vs || fabs_(ts[3]) > p.vs || b.discharge_def == 3) {   // :67-98
 		T depth = (fabs_(ts[2]) * dt) / p.dx + (fabs_(ts[3]) * dt) / p.dx;
-		T crit = fmax_(pow_(pow_(ts[2], T(2.0)) / g, T(T(1.0) / T(3.0))), pow_(pow_(ts[3], T(2.0)) / g, T(T(1.0) / T(3.0))));
+		T crit = fmax_(pow13_((ts[2] * ts[2]) / g), pow13_((ts[3] * ts[3]) / g));      // :81
 		if (b.discharge_def == 3) {                                                // volume: no direction, no scaling
 			depth = (fabs_(ts[2]) * dt) / (p.dx * p.dx);
 			crit = T(0);

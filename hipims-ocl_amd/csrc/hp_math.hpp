@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define HP_CR_FN __host__ __device__ __forceinline__
+#include "hp_crmath.h"          // the cube root STRICT shares with the oracle and the reference build (see there)
+
 namespace hp {
 
 enum : int { AXIS_X = 0, AXIS_Y = 1 };
@@ -42,10 +45,13 @@ __device__ __forceinline__ double fma_(double a, double b, double c) { return __
 __device__ __forceinline__ float  fma_(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double sqrt_(double x) { return __builtin_sqrt(x); }
 __device__ __forceinline__ float  sqrt_(float x)  { return __builtin_sqrtf(x); }
-__device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
-__device__ __forceinline__ float  pow_(float x, float y)   { return powf(x, y); }
-__device__ __forceinline__ double cbrt_(double x) { return cbrt(x); }
-__device__ __forceinline__ float  cbrt_(float x)  { return cbrtf(x); }
+// STRICT's pow: the reference asks for three exponents only (1/3, 10/3, 2); the first two come from hp_crmath.h --
+// correctly rounded cube root from IEEE basic operations, bit-identical on host and device -- so that a STRICT run
+// equals the oracle WITH friction on (round 2 used the device library's pow: last-bit differences from glibc's)
+__device__ __forceinline__ double pow13_(double x)  { return hp_cr_cbrt(x); }
+__device__ __forceinline__ float  pow13_(float x)   { return hp_cr_cbrtf(x); }
+__device__ __forceinline__ double pow103_(double x) { return hp_cr_pow103(x); }
+__device__ __forceinline__ float  pow103_(float x)  { return hp_cr_pow103f(x); }
 __device__ __forceinline__ double fabs_(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float  fabs_(float x)  { return __builtin_fabsf(x); }
 __device__ __forceinline__ double fmax_(double a, double b) { return __builtin_fmax(a, b); }
@@ -424,7 +430,7 @@ __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, co
 	const T h = z - zb;
 	if (h < vs || q < vs) return;
 	if (STRICT) {
-		const T cf  = (g * n * n) / pow_(h, T(T(1.0) / T(3.0)));
+		const T cf  = (g * n * n) / pow13_(h);                       // CLFriction.clc:43
 		const T sfx = (-cf / (h * h)) * qx * q;
 		const T sfy = (-cf / (h * h)) * qy * q;
 		const T dx  = T(1.0) + dt * (cf / (h * h)) * (2 * (qx * qx) + (qy * qy)) / q;
@@ -677,7 +683,7 @@ __device__ __forceinline__ T inertial_flux(const T n, const T dt, const T q_prev
 	if (STRICT) {
 		const T slope = (z_down - z_up) / dx;                                             // :343
 		q = (q_prev - (g * d * dt * slope)) /                                             // :346-348
-		    (T(1.0) + g * d * dt * n * n * fabs_(q_prev) / pow_(d, T(T(10.0) / T(3.0))));
+		    (T(1.0) + g * d * dt * n * n * fabs_(q_prev) / pow103_(d));
 		const T c = sqrt_(g * d);
 		if (q > T(0) && ((fabs_(q) / d) / c) > T(0.8)) q = d * c * T(0.8);                // :351-356
 		if (q < T(0) && ((fabs_(q) / d) / c) > T(0.8)) q = T(0) - d * c * T(0.8);

@@ -13,9 +13,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* pow() is the one operation of the path whose result is implementation defined (an OpenCL device's pow is good to
+ * 16 ulp); the reference only ever asks for x^(1/3), x^(10/3) and x^2.  The oracle, the reference build's shim and the
+ * STRICT HIP kernels all take the first two from this header (correctly rounded cube root, IEEE basic operations only:
+ * same bits on every platform), and x^2 as x*x. */
+#include "../hipims-ocl_amd/csrc/hp_crmath.h"
+
 #ifdef ORC_FP32
 #define R_SQRT  sqrtf
-#define R_POW   powf
+#define R_POW13(x)  hp_cr_cbrtf(x)
+#define R_POW103(x) hp_cr_pow103f(x)
 #define R_FABS  fabsf
 #define R_FMAX  fmaxf
 #define R_FMIN  fminf
@@ -23,7 +30,8 @@
 #define R_FMOD  fmodf
 #else
 #define R_SQRT  sqrt
-#define R_POW   pow
+#define R_POW13(x)  hp_cr_cbrt(x)
+#define R_POW103(x) hp_cr_pow103(x)
 #define R_FABS  fabs
 #define R_FMAX  fmax
 #define R_FMIN  fmin
@@ -225,7 +233,7 @@ void orc_friction(const orc_params* p, const real s[4], real bed, real n, real d
 	real dDepth = s[0] - bed;
 	if (dDepth < VS || dQ < VS) return;                               /* :40 */
 
-	real dCf  = (GRAVITY * n * n) / (R_POW(dDepth, (real)(RC(1.0) / RC(3.0))));     /* :43 */
+	real dCf  = (GRAVITY * n * n) / (R_POW13(dDepth));     /* :43 */
 	real dSfx = (-dCf / (dDepth * dDepth)) * s[2] * dQ;                              /* :44-45 */
 	real dSfy = (-dCf / (dDepth * dDepth)) * s[3] * dQ;
 	real dDx  = RC(1.0) + dt * (dCf / (dDepth * dDepth)) * (2 * (s[2] * s[2]) + (s[3] * s[3])) / dQ;   /* :46-47 */
@@ -523,7 +531,7 @@ real orc_inertial_flux(const orc_params* p, real dManningCoef, real dTimestep, r
 
 	dDischarge = (dPreviousDischarge - (GRAVITY * dDepth * dTimestep * dSlope)) /                     /* :346-348 */
 	             (RC(1.0) + GRAVITY * dDepth * dTimestep * dManningCoef * dManningCoef * R_FABS(dPreviousDischarge) /
-	              R_POW(dDepth, (real)(RC(10.0) / RC(3.0))));
+	              R_POW103(dDepth));
 
 	if (dDischarge > RC(0.0) &&                                                                       /* :351-356 */
 	    ((R_FABS(dDischarge) / dDepth) / R_SQRT(GRAVITY * dDepth)) > FROUDE_LIMIT)
@@ -918,8 +926,8 @@ void orc_bdy_cell(const orc_params* p, const orc_scalars* s, int depth_def, int 
 		} else {                                                                  /* :67-98 */
 			if (R_FABS(ts[2]) > VS || R_FABS(ts[3]) > VS || discharge_def == ORC_DISCHARGE_IS_VOLUME) {
 				real dDepth = (R_FABS(ts[2]) * dLocalTimestep) / DY + (R_FABS(ts[3]) * dLocalTimestep) / DX;
-				real dCriticalDepth = R_FMAX(R_POW(R_POW(ts[2], RC(2.0)) / GRAVITY, (real)(RC(1.0) / RC(3.0))),
-				                             R_POW(R_POW(ts[3], RC(2.0)) / GRAVITY, (real)(RC(1.0) / RC(3.0))));
+				real dCriticalDepth = R_FMAX(R_POW13((ts[2] * ts[2]) / GRAVITY),
+				                             R_POW13((ts[3] * ts[3]) / GRAVITY));
 				if (discharge_def == ORC_DISCHARGE_IS_VOLUME) {
 					dDepth = (R_FABS(ts[2]) * dLocalTimestep) / (DX * DY);
 					dCriticalDepth = RC(0.0);
