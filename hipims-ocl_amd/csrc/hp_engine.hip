@@ -91,7 +91,6 @@ struct hp_domain {
 	int              inertial_rseg = 32;              // ... of inertial_march
 	int              tall_rseg = 18;                  // K1/K6 tile height where an XCD band has >= 256 rows (16 if a knob is set)
 	int              tail_rseg = 8, tail_pct = 0;     // optional short tiles for the last tail_pct % of each XCD band (measured: no gain)
-	int              serpentine = 0;                  // odd iterations walk each XCD band's tiles in reverse (HP_SERPENTINE)
 	void*            host_scalars = nullptr;          // pinned mirror
 	int              use_alt = 0;                     // bUseAlternateKernel
 	bool             in_step = false;
@@ -236,10 +235,9 @@ struct RowRange { long lo, hi; };
 // TileMap of one launch (see hp_kernels.hpp): 8 XCD bands over [lo, hi), tall tiles first and optionally short tiles
 // for the last `tail_pct` percent of each band; or, for the halo part, the two blocks of `halo` rows as two bands.
 inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rseg, int rseg_tail, int tail_pct,
-                          TileMap& tm, unsigned& blocks, int rseg_tall = 16, int reverse = 0)
+                          TileMap& tm, unsigned& blocks, int rseg_tall = 16)
 {
 	static const long halo_env = std::getenv("HP_HALO_ROWS") ? std::atol(std::getenv("HP_HALO_ROWS")) : 0;
-	tm.reverse = reverse;
 	const long halo = halo_env >= g ? halo_env : (rseg > g ? rseg : g);
 	const bool can_split = hi - lo > 2 * halo;
 	tm.nstrips = nstrips;
@@ -287,7 +285,7 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
-	if (!make_tile_map(2, p.rows - 2, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks, 16, d->serpentine & d->use_alt))
+	if (!make_tile_map(2, p.rows - 2, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks))
 		return HP_OK;
 	if (d->manning_uniform)
 		hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, true, T>), dim3(blocks), dim3(256), 0, stream, p,
@@ -307,7 +305,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
-	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg, d->serpentine & d->use_alt))
+	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg))
 		return HP_OK;
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
@@ -322,7 +320,7 @@ int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, i
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
-	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg, d->serpentine & d->use_alt))
+	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg))
 		return HP_OK;
 	hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
@@ -621,7 +619,6 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 64) { d->march_rseg = v; d->tall_rseg = 16; }   // a forced 16 stays 16
 	}
-	if (const char* e = std::getenv("HP_SERPENTINE")) d->serpentine = std::atoi(e) != 0;
 	if (const char* e = std::getenv("HP_TAIL_RSEG")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) d->tail_rseg = v; }
 	if (const char* e = std::getenv("HP_TAIL_PCT"))  { const int v = std::atoi(e); if (v >= 0 && v <= 100) d->tail_pct = v; }
 	if (const char* e = std::getenv("HP_INERTIAL_RSEG")) {

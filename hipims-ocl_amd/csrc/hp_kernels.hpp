@@ -276,15 +276,12 @@ struct TileMap {
 	int  band_rows;              // rows per band
 	int  rseg, nbig;             // tall segments per band
 	int  rseg_tail, ntail;       // short segments per band (after the tall ones)
-	int  reverse;                // walk each band's tiles in the opposite order (alternate iterations: see hp_engine.hip)
 };
 
 // rows [y0, y1) and the column strip of this wave; false if the block / wave has nothing to do (wave-uniform)
 __device__ __forceinline__ bool tile_rows(const TileMap& tm, const int wave, long& strip, long& y0, long& y1)
 {
-	const unsigned band = blockIdx.x % (unsigned)tm.nbands;
-	unsigned i = blockIdx.x / (unsigned)tm.nbands;
-	if (tm.reverse) i = (unsigned)(tm.groups * (tm.nbig + tm.ntail)) - 1u - i;
+	const unsigned band = blockIdx.x % (unsigned)tm.nbands, i = blockIdx.x / (unsigned)tm.nbands;
 	const unsigned nbig_tiles = (unsigned)(tm.groups * tm.nbig);
 	const long band_y0 = tm.y_begin + (long)band * tm.band_stride;
 	const long band_y1 = (band_y0 + tm.band_rows < tm.y_end) ? (band_y0 + tm.band_rows) : tm.y_end;

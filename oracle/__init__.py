@@ -379,9 +379,12 @@ class RefSim(_SimBase):
     """
     WORKERS = 64          # TIMESTEP_WORKERS; any value gives the same max
 
-    def __init__(self, *a, mad=False, **k):
+    def __init__(self, *a, mad=False, libm_pow=False, **k):
         super().__init__(*a, **k)
         stem = {GODUNOV: "god_", MUSCL: "mch_", INERTIAL: "ine_"}[self.scheme] + self.precision + ("_mad" if mad else "")
+        if libm_pow:                                 # pow() from the host libm instead of hp_crmath.h (fp64 Godunov only)
+            assert stem == "god_f64", "libm-pow reference build: Godunov fp64 strict only"
+            stem += "_libm"
         if not self.friction:                        # FRICTION_ENABLED undefined: Godunov / MUSCL fp64 builds exist
             assert stem in ("god_f64", "mch_f64") and self.dynamic_dt, "no-friction reference build: fp64 Godunov/MUSCL"
             stem += "_nofric"

@@ -52,6 +52,10 @@ double sqrt(double x)              { return __builtin_sqrt(x); }
 // for bit.  Any other exponent would be a use this build does not know about: it stops.
 double pow(double x, double y)
 {
+#ifdef REF_LIBM_POW
+	return __builtin_pow(x, y);       // a DIFFERENT conforming pow (this host's libm): the *_libm builds measure how far two
+	                                  // platforms' runs of the reference itself drift apart through this one built-in
+#endif
 	if (y == 1.0 / 3.0)  return hp_cr_cbrt(x);
 	if (y == 10.0 / 3.0) return hp_cr_pow103(x);
 	if (y == 2.0)        return x * x;

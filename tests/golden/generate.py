@@ -261,10 +261,11 @@ def cell_boundary(precision, tag):
     save(f"f11_cell_boundary_{tag}", **out)
 
 
-def newcastle(precision, tag, mad=False):
+def newcastle(precision, tag, mad=False, libm_pow=False):
     """F10: config C1 -- the reference's own example (342x195 @ 2 m DEM from its data file, rain 70 mm/h + drainage
     12 mm/h, closed edges), Godunov fp64, first 900 iterations on the reference's kernels.  The -cl-mad-enable build
-    (what the reference ships) stores only the final levels and time: it brackets the reference's own spread."""
+    (what the reference ships) and the build whose pow() is the host libm's (another conforming OpenCL platform) store
+    only the final levels and time: together they bracket the reference's own platform-dependent spread."""
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hipims_mi import frontend
@@ -272,13 +273,13 @@ def newcastle(precision, tag, mad=False):
     with tempfile.TemporaryDirectory() as tmp:
         cfg = frontend.parse_configuration(make_newcastle(tmp))
         st, bed, man, res = frontend.build_domain(cfg)
-    sim = oracle.RefSim(342, 195, precision=precision, dx=res, end_time=cfg.duration, mad=mad)
+    sim = oracle.RefSim(342, 195, precision=precision, dx=res, end_time=cfg.duration, mad=mad, libm_pow=libm_pow)
     sim.upload(st, bed, man)
     frontend.attach_boundaries(cfg, sim, 342)
     sim.set_target(1e9)
     dt = sim.run(900)
     final = sim.download()
-    if mad:
+    if mad or libm_pow:
         save(f"f10_newcastle_{tag}", z=final[..., 0], t=np.array(sim.scalars()["t"]))
         return
     depth = np.maximum(0, final[..., 0] - bed)
@@ -429,7 +430,8 @@ JOBS = [
     ("f8", lambda: [time_control(p, p) for p in ("f64", "f32")]),
     ("f9", lambda: [rain(p, p) for p in ("f64", "f32")]),
     ("f11", lambda: [cell_boundary(p, p) for p in ("f64", "f32")]),
-    ("f10", lambda: [newcastle("f64", "f64"), newcastle("f64", "f64_mad", mad=True)]),
+    ("f10", lambda: [newcastle("f64", "f64"), newcastle("f64", "f64_mad", mad=True),
+                    newcastle("f64", "f64_libm", libm_pow=True)]),
     ("f13", fixed_timestep),
     ("f14", no_friction),
     ("f15", disabled_cells),

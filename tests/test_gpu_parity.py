@@ -1,7 +1,7 @@
 """Parity of the HIP engine (through the C ABI) with the oracle and the golden fixtures.  GPU only.
 
 Tolerances (fp64, north_star): depth RMSE < 1e-9 m, max |depth diff| < 1e-7 m, dt relative < 1e-12.
-STRICT arithmetic is additionally required to be bit-identical wherever pow() is not involved.
+STRICT arithmetic is additionally required to be bit-identical (with friction too: tests/test_gpu_strict_friction.py).
 fp32: depth RMSE < 1e-4 m.
 """
 import os
@@ -162,37 +162,44 @@ def test_uniform_rain_and_gridded_rain_fixture(kernel):
 @pytest.mark.parametrize("mode", MODES)
 def test_newcastle_example_rain_drainage(mode, tmp_path):
     """Config C1: the reference's example model (its own 342x195 @ 2 m DEM file, rain 70 mm/h + drainage 12 mm/h,
-    closed edges) read through the front end, 900 iterations, against the fixture from the reference's kernels.
+    closed edges) read through the front end, 900 iterations, against the fixtures from the reference's kernels.
 
-    Steep urban terrain under a millimetre-thin rain film is the one case here where rounding is amplified: wet/dry
-    decisions at VERY_SMALL flip a step earlier or later.  The reference's own two builds -- strict and as shipped
-    with -cl-mad-enable (COCLProgram.cpp:73) -- already differ by depth RMSE 6.4e-9 m / max 7.0e-7 m / 6e-10 relative
-    in elapsed time after these 900 iterations (both fixtures are committed: f10_newcastle_f64{,_mad}.npz).  The
-    engine is therefore held to 3x that bracket instead of the 1e-9 m that the other cases meet."""
+    STRICT reproduces the reference kernels' run itself (RMSE 0: tests/test_gpu_strict_friction.py holds every bit).
+    FAST cannot: steep urban terrain under a millimetre-thin rain film amplifies rounding -- wet/dry decisions at
+    VERY_SMALL flip a step earlier or later -- and the reference's OWN builds differ from one another here.  Three of
+    them are committed as fixtures: strict (f10_newcastle_f64), as shipped with -cl-mad-enable (COCLProgram.cpp:73;
+    _mad) and strict on a platform with a different conforming pow() (_libm).  Their largest pairwise spread after these
+    900 iterations is depth RMSE 4.1e-9 m, max 4.5e-7 m, 1.5e-8 relative in elapsed time; FAST is held to TWICE that
+    ensemble spread in each measure (achieved: 5.8e-9 m, 5.2e-7 m, 1.3e-8; profiles/r03*_parity_numbers.jsonl)."""
+    from itertools import combinations
     from hipims_mi import frontend
     from model_dir import make_newcastle
-    g, gm = load_golden("f10_newcastle_f64"), load_golden("f10_newcastle_f64_mad")
+    refs = [load_golden("f10_newcastle_f64"), load_golden("f10_newcastle_f64_mad"), load_golden("f10_newcastle_f64_libm")]
+    g = refs[0]
     cfg = frontend.parse_configuration(make_newcastle(tmp_path))
     st, bed, man, res = frontend.build_domain(cfg)
-    dr = np.maximum(0, g["z"] - bed)
-    dm = np.maximum(0, gm["z"] - bed)
-    bracket_rmse, bracket_max = np.sqrt(np.mean((dr - dm) ** 2)), np.abs(dr - dm).max()
-    bracket_t = abs(float(g["t"]) - float(gm["t"])) / float(g["t"])
-    assert 1e-9 < bracket_rmse < 1e-8                    # the reference's own spread, as recorded above
+    depth = lambda z: np.maximum(0, z - bed)
+    dr = depth(g["z"])
+    pairs = list(combinations(refs, 2))
+    bracket_rmse = max(np.sqrt(np.mean((depth(a["z"]) - depth(b["z"])) ** 2)) for a, b in pairs)
+    bracket_max = max(np.abs(depth(a["z"]) - depth(b["z"])).max() for a, b in pairs)
+    bracket_t = max(abs(float(a["t"]) - float(b["t"])) for a, b in pairs) / float(g["t"])
+    assert 1e-9 < bracket_rmse < 1e-8 and bracket_t < 1e-7     # the reference's own spread, as recorded above
 
     dom = hp.Domain(342, 195, dx=res, t_end=cfg.duration, math_mode=mode)
     dom.upload(st, bed, man)
     frontend.attach_boundaries(cfg, dom, 342)
     dom.set_target_time(1e9)
     dom.step_batch(900)
-    dg = np.maximum(0, dom.download()[..., 0] - bed)
-    record("c1_newcastle_900", mode="strict" if mode == hp.MATH_STRICT else "fast",
-           rmse=float(np.sqrt(np.mean((dg - dr) ** 2))), max=float(np.abs(dg - dr).max()),
-           dt_rel=abs(dom.read_scalars()["time"] - float(g["t"])) / float(g["t"]),
+    dg = depth(dom.download()[..., 0])
+    rmse, mx = float(np.sqrt(np.mean((dg - dr) ** 2))), float(np.abs(dg - dr).max())
+    dt_rel = abs(dom.read_scalars()["time"] - float(g["t"])) / float(g["t"])
+    record("c1_newcastle_900", mode="strict" if mode == hp.MATH_STRICT else "fast", rmse=rmse, max=mx, dt_rel=dt_rel,
            bracket_rmse=float(bracket_rmse), bracket_max=float(bracket_max), bracket_t=float(bracket_t))
-    assert np.sqrt(np.mean((dg - dr) ** 2)) < 3 * bracket_rmse and np.abs(dg - dr).max() < 3 * bracket_max
-    # elapsed time: the CFL-limiting cell is a single thin-film cell, so dt inherits the flips more directly: 10x bracket
-    assert abs(dom.read_scalars()["time"] - float(g["t"])) < 10 * bracket_t * float(g["t"])
+    if mode == hp.MATH_STRICT:
+        assert rmse == 0.0 and dt_rel == 0.0                   # north_star: depth RMSE < 1e-9 m vs the reference run
+    else:
+        assert rmse < 2 * bracket_rmse and mx < 2 * bracket_max and dt_rel < 2 * bracket_t
 
 
 def test_front_end_runs_the_example_on_the_gpu(tmp_path):
