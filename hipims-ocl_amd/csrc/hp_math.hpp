@@ -271,55 +271,79 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 	// none of the dry-side forms, zeroed velocities or stopping conditions can apply (they all test h <= VERY_SMALL),
 	// and when in addition every lane is in the subcritical "middle" region of the HLLC fan only the HLL middle state
 	// is needed.  Same formulas, same results -- the selects between alternatives nobody takes are simply not executed.
-	if (!STRICT && __all(hL > vs && hR > vs)) {
-		FaceCore<T> k;
-		k.etaL = etaL; k.etaR = etaR; k.zbm = zbm;
-		k.unL = (AXIS == AXIS_X ? L.u0 : L.v0); k.unR = (AXIS == AXIS_X ? R.u0 : R.v0);
-		k.utL = (AXIS == AXIS_X ? L.v0 : L.u0); k.utR = (AXIS == AXIS_X ? R.v0 : R.u0);
-		k.qnL = (AXIS == AXIS_X ? qxL : qyL); k.qnR = (AXIS == AXIS_X ? qxR : qyR);
-		k.qtL = (AXIS == AXIS_X ? qyL : qxL); k.qtR = (AXIS == AXIS_X ? qyR : qxR);
-		const T aL = sqrt_fast(g * hL), aR = sqrt_fast(g * hR);
-		const T tmp = (aL + aR) / 2 + (k.unL - k.unR) / 4;
-		const T u_star = (k.unL + k.unR) / 2 + aL - aR;
-		const T a_star = fabs_(tmp);
-		const T sL = fmin_(k.unL - aL, u_star - a_star), sR = fmax_(k.unR + aR, u_star + a_star);
-		k.sL = sL; k.sR = sR; k.sLsR = sL * sR;
-		const T sm_num = sL * hR * (k.unR - sR) - sR * hL * (k.unL - sL);
-		const T sm_den = hR * (k.unR - sR) - hL * (k.unL - sL);
-		const bool sm_nonneg = (sm_den < T(0)) ? (sm_num <= T(0)) : ((sm_num / sm_den) >= T(0));
-		k.inv_ds = rcp_fast(sR - sL);
-		if (__all(sL < T(0) && sR >= T(0))) {
-			auto finish_mid = [&](const T s, const bool own_left) {
-				const T half_g = T(0.5) * g;
-				const T a = etaL - s, b = etaR - s, zb = zbm - s;
-				const T fnL = fma_(k.unL, k.qnL, half_g * (a * (a - 2 * zb)));
-				const T fnR = fma_(k.unR, k.qnR, half_g * (b * (b - 2 * zb)));
-				const T f1m = fma_(k.sLsR, (b - a), fma_(sR, k.qnL, -(sL * k.qnR))) * k.inv_ds;
-				const T f2m = fma_(k.sLsR, (k.qnR - k.qnL), fma_(sR, fnL, -(sL * fnR))) * k.inv_ds;
-				const T ft = f1m * (sm_nonneg ? k.utL : k.utR);
-				FaceFlux<T> o;
-				o.f0 = f1m;
-				o.fx = (AXIS == AXIS_X ? f2m : ft);
-				o.fy = (AXIS == AXIS_X ? ft : f2m);
-				o.eta_nb = own_left ? b : a;
-				o.zb_nb = zb;
-				o.stop = false;
-				return o;
-			};
-			oL = finish_mid(shL, true);
-			oR = oL;
-			if (shL != shR) oR = finish_mid(shR, false);
-			oR.eta_nb = etaL - shR;
-		} else {
-			k.bLeft = sL >= T(0);
-			k.bMid1 = sL < T(0) && sR >= T(0) && sm_nonneg;
-			const bool bMid2 = sL < T(0) && sR >= T(0) && !k.bMid1;
-			k.bRight = !k.bLeft && !k.bMid1 && !bMid2;
-			oL = finish_wet<AXIS, STRICT>(k, shL, true, false);
-			oR = oL;
-			if (shL != shR) oR = refinish_wet<AXIS>(k, oL, shR, false, false);
-			oR.eta_nb = etaL - shR;
+	if (!STRICT) {
+		// ---- FAST flavour (round 3 formulation) ----
+		// (1) The vertical shift enters a finished face only through the pressure-like terms g/2 (eta^2 - 2 zb eta) of the
+		//     normal-momentum flux, and identically on both sides: with a = eta - s and zb = zbm - s,
+		//         a (a - 2 zb) = eta (eta - 2 zbm) - s (s - 2 zbm),
+		//     so F_n(s) = F_n(0) - C(s), C(s) = g/2 s (s - 2 zbm), in all three regions of the fan (in the middle one
+		//     the HLL average of two fluxes that both carry -C is the average minus C).  The face is therefore finished ONCE
+		//     without shift; each of the two cells subtracts its own C (4 operations; C(0) = 0 exactly) instead of the
+		//     second finish round 2 paid for (16 operations + selects).
+		// (2) s_M is only needed for its sign (which side's tangential velocity the middle state carries, :206-224), and
+		//     s_M = -(s_R - s_L) F_1 / den with den < 0 whenever a side is wet: sign(s_M) = sign of the HLL mass flux F_1,
+		//     which is computed anyway.  (Round 2 evaluated s_M's numerator and denominator: 12 operations.)
+		// (3) A wavefront that is not wet on both sides of every face runs STRAIGHT-LINE code: dry-side wave speeds
+		//     (:129-140), region (:174-198) and the dry-dry flux (:45-61) are per-lane selects over ONE instruction stream
+		//     (round 2: divergent branches, each under its own exec mask, ~190 VALU per face; now ~140).  A wet-wet
+		//     lane executes exactly the operations of the all-wet path, so a face has the same bits whichever wavefront
+		//     (tile, strip) solves it.
+		const T half_g = T(0.5) * g;
+		const bool all_wet = __all(hL > vs && hR > vs);
+		const bool dryL = hL < vs, dryR = hR < vs;
+		T unL = (AXIS == AXIS_X ? L.u0 : L.v0), unR = (AXIS == AXIS_X ? R.u0 : R.v0);     // dVel (:87-98)
+		T utL = (AXIS == AXIS_X ? L.v0 : L.u0), utR = (AXIS == AXIS_X ? R.v0 : R.u0);
+		if (!all_wet) {                                                                   // zero velocity on a dry side
+			unL = dryL ? T(0) : unL; utL = dryL ? T(0) : utL;
+			unR = dryR ? T(0) : unR; utR = dryR ? T(0) : utR;
 		}
+		const T qnL = (AXIS == AXIS_X ? qxL : qyL), qnR = (AXIS == AXIS_X ? qxR : qyR);   // dDis (:99-102)
+		const T qtL = (AXIS == AXIS_X ? qyL : qxL), qtR = (AXIS == AXIS_X ? qyR : qxR);
+		const T aL = sqrt_fast(g * hL), aR = sqrt_fast(g * hR);                           // dA (:103-106)
+		const T tmp = (aL + aR) / 2 + (unL - unR) / 4;                                    // :123-126
+		const T u_star = (unL + unR) / 2 + aL - aR;
+		const T a_star = fabs_(tmp);
+		T sL = fmin_(unL - aL, u_star - a_star), sR = fmax_(unR + aR, u_star + a_star);   // :129-140
+		if (!all_wet) {
+			sL = dryL ? (unR - 2 * aR) : sL;
+			sR = dryR ? (unL + 2 * aL) : sR;
+		}
+		const T sLsR = sL * sR;
+		const T inv_ds = rcp_fast(sR - sL);
+		// unshifted normal-momentum fluxes of the two sides (left bed on both sides, Q4) and the HLL middle state (:200-203)
+		const T fnL = fma_(unL, qnL, half_g * (etaL * (etaL - 2 * zbm)));
+		const T fnR = fma_(unR, qnR, half_g * (etaR * (etaR - 2 * zbm)));
+		const T f1m = fma_(sLsR, (etaR - etaL), fma_(sR, qnL, -(sL * qnR))) * inv_ds;
+		const T f2m = fma_(sLsR, (qnR - qnL), fma_(sR, fnL, -(sL * fnR))) * inv_ds;
+		const T ftm = f1m * ((f1m >= T(0)) ? utL : utR);                                  // (2)
+		T f0 = f1m, fn = f2m, ft = ftm;
+		if (!__all(sL < T(0) && sR >= T(0))) {                                            // not subcritical everywhere
+			const bool bLeft = sL >= T(0), mid = sL < T(0) && sR >= T(0), bRight = !bLeft && !mid;   // NaN speeds -> "right"
+			f0 = bLeft ? qnL : (bRight ? qnR : f1m);
+			fn = bLeft ? fnL : (bRight ? fnR : f2m);
+			ft = bLeft ? (unL * qtL) : (bRight ? (unR * qtR) : ftm);
+		}
+		T fnForL = fn, fnForR = fn;
+		if (!all_wet) {
+			// (1): each cell subtracts its own C(s); a wet-wet face has no shift (a level below the common bed means a dry side)
+			fnForL = fn - half_g * (shL * (shL - 2 * zbm));
+			fnForR = fn - half_g * (shR * (shR - 2 * zbm));
+			const bool both_dry = dryL && dryR;
+			if (__any(both_dry)) {                                                        // :45-61, the statements of finish_dry
+				const T a1 = etaL - shL, b1 = etaR - shL, z1 = zbm - shL;
+				const T a2 = etaL - shR, b2 = etaR - shR, z2 = zbm - shR;
+				const T p1 = half_g * (((a1 + b1) / 2) * ((a1 + b1) / 2) - z1 * (a1 + b1));
+				const T p2 = half_g * (((a2 + b2) / 2) * ((a2 + b2) / 2) - z2 * (a2 + b2));
+				f0 = both_dry ? T(0) : f0;
+				ft = both_dry ? T(0) : ft;
+				fnForL = both_dry ? p1 : fnForL;
+				fnForR = both_dry ? p2 : fnForR;
+			}
+		}
+		oL.f0 = f0; oL.fx = (AXIS == AXIS_X ? fnForL : ft); oL.fy = (AXIS == AXIS_X ? ft : fnForL);
+		oL.eta_nb = etaR - shL; oL.zb_nb = zbm - shL; oL.stop = stopL;
+		oR.f0 = f0; oR.fx = (AXIS == AXIS_X ? fnForR : ft); oR.fy = (AXIS == AXIS_X ? ft : fnForR);
+		oR.eta_nb = etaL - shR; oR.zb_nb = zbm - shR; oR.stop = stopR;
 	} else if (hL < vs && hR < vs) {
 		oL = finish_dry<AXIS>(etaL, etaR, zbm, shL, true, stopL);
 		oR = finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
