@@ -298,7 +298,6 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 			unR = dryR ? T(0) : unR; utR = dryR ? T(0) : utR;
 		}
 		const T qnL = (AXIS == AXIS_X ? qxL : qyL), qnR = (AXIS == AXIS_X ? qxR : qyR);   // dDis (:99-102)
-		const T qtL = (AXIS == AXIS_X ? qyL : qxL), qtR = (AXIS == AXIS_X ? qyR : qxR);
 		const T aL = sqrt_fast(g * hL), aR = sqrt_fast(g * hR);                           // dA (:103-106)
 		const T tmp = (aL + aR) / 2 + (unL - unR) / 4;                                    // :123-126
 		const T u_star = (unL + unR) / 2 + aL - aR;
@@ -321,6 +320,7 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 			const bool bLeft = sL >= T(0), mid = sL < T(0) && sR >= T(0), bRight = !bLeft && !mid;   // NaN speeds -> "right"
 			f0 = bLeft ? qnL : (bRight ? qnR : f1m);
 			fn = bLeft ? fnL : (bRight ? fnR : f2m);
+			const T qtL = (AXIS == AXIS_X ? qyL : qxL), qtR = (AXIS == AXIS_X ? qyR : qxR);   // only the supercritical regions use them
 			ft = bLeft ? (unL * qtL) : (bRight ? (unR * qtR) : ftm);
 		}
 		T fnForL = fn, fnForR = fn;
@@ -449,38 +449,48 @@ __device__ __forceinline__ FaceFlux<T> face_dry_for_right(const Side<T>& L, cons
 template <bool STRICT, typename T>
 __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, const T n, const T dt, const T vs)
 {
+	static_assert(STRICT, "the FAST flavour goes through friction_fast (below)");
 	const T g = gravity<T>();
-	const T q = STRICT ? sqrt_(qx * qx + qy * qy) : sqrt_fast(fma_(qx, qx, qy * qy));
+	const T q = sqrt_(qx * qx + qy * qy);
 	const T h = z - zb;
 	if (h < vs || q < vs) return;
-	if (STRICT) {
-		const T cf  = (g * n * n) / pow13_(h);                       // CLFriction.clc:43
-		const T sfx = (-cf / (h * h)) * qx * q;
-		const T sfy = (-cf / (h * h)) * qy * q;
-		const T dx  = T(1.0) + dt * (cf / (h * h)) * (2 * (qx * qx) + (qy * qy)) / q;
-		const T dy  = T(1.0) + dt * (cf / (h * h)) * ((qx * qx) + 2 * (qy * qy)) / q;
-		T fx = sfx / dx, fy = sfy / dy;
-		if (qx >= T(0)) { if (fx < -qx / dt) fx = -qx / dt; } else { if (fx > -qx / dt) fx = -qx / dt; }
-		if (qy >= T(0)) { if (fy < -qy / dt) fy = -qy / dt; } else { if (fy > -qy / dt) fy = -qy / dt; }
-		qx = qx + dt * fx;
-		qy = qy + dt * fy;
-	} else {
-		// A = dt g n^2 h^(-7/3);  dt Fx = -A Q^2 qx / (Q + A (2 qx^2 + qy^2))   [Q = |q|], no division by Q
-		const T rc = rcbrt_fast(h);                          // h^(-1/3)
-		const T rc2 = rc * rc, rc4 = rc2 * rc2;
-		const T A = (dt * g) * (n * n) * (rc4 * rc2 * rc);   // h^(-7/3)
-		const T qx2 = qx * qx, qy2 = qy * qy;
-		const T num = -A * (qx2 + qy2);
-		const T denx = fma_(A, fma_(T(2), qx2, qy2), q), deny = fma_(A, fma_(T(2), qy2, qx2), q);
-		const T rxy = rcp_fast(denx * deny);                 // 1/denx = rxy*deny, 1/deny = rxy*denx
-		T dqx = num * qx * (rxy * deny);
-		T dqy = num * qy * (rxy * denx);
-		// friction can stop the flow, not reverse it (:52-65): dt*Fx limited to -qx
-		if (qx >= T(0)) dqx = fmax_(dqx, -qx); else dqx = fmin_(dqx, -qx);
-		if (qy >= T(0)) dqy = fmax_(dqy, -qy); else dqy = fmin_(dqy, -qy);
-		qx += dqx;
-		qy += dqy;
-	}
+	const T cf  = (g * n * n) / pow13_(h);                           // CLFriction.clc:43
+	const T sfx = (-cf / (h * h)) * qx * q;
+	const T sfy = (-cf / (h * h)) * qy * q;
+	const T dx  = T(1.0) + dt * (cf / (h * h)) * (2 * (qx * qx) + (qy * qy)) / q;
+	const T dy  = T(1.0) + dt * (cf / (h * h)) * ((qx * qx) + 2 * (qy * qy)) / q;
+	T fx = sfx / dx, fy = sfy / dy;
+	if (qx >= T(0)) { if (fx < -qx / dt) fx = -qx / dt; } else { if (fx > -qx / dt) fx = -qx / dt; }
+	if (qy >= T(0)) { if (fy < -qy / dt) fy = -qy / dt; } else { if (fy > -qy / dt) fy = -qy / dt; }
+	qx = qx + dt * fx;
+	qy = qy + dt * fy;
+}
+
+// FAST flavour of the same term, straight-line.  With A = dt g n^2 h^(-7/3) and Q = |q| the reference's update is
+//   qx <- qx + max(dt Fx, -qx)  (qx >= 0; mirrored otherwise),  dt Fx = -qx A Q^2 / (Q + A (2 qx^2 + qy^2)),
+// i.e. qx <- qx (1 - min(fx, 1)) with fx = A Q^2 / (Q + A (2 qx^2 + qy^2)) >= 0: "friction can stop the flow, not reverse it"
+// (:52-65) is a clamp of fx at one -- no sign cases, no division by Q.  Cells the reference skips (h or Q below
+// VERY_SMALL, :36-37) take fx = 0, and a wavefront without an active cell skips the arithmetic (still water).
+template <typename T>
+__device__ __forceinline__ void friction_fast(T& qx, T& qy, const T z, const T zb, const T n, const T dt, const T vs)
+{
+	const T g = gravity<T>();
+	const T h = z - zb;
+	const T q = sqrt_fast(fma_(qx, qx, qy * qy));
+	const bool active = !(h < vs || q < vs);
+	if (!__any(active)) return;
+	const T rc = rcbrt_fast(h);                              // h^(-1/3)
+	const T rc2 = rc * rc, rc4 = rc2 * rc2;
+	const T A = ((dt * g) * (n * n)) * (rc4 * rc2 * rc);     // dt g n^2 h^(-7/3)
+	const T qx2 = qx * qx, qy2 = qy * qy;                    // (recomputed here: two multiplications against two live registers)
+	const T aq2 = A * (qx2 + qy2);
+	const T denx = fma_(A, fma_(T(2), qx2, qy2), q), deny = fma_(A, fma_(T(2), qy2, qx2), q);
+	const T rxy = rcp_fast(denx * deny);                     // 1/denx = rxy * deny, 1/deny = rxy * denx
+	T fx = fmin_(aq2 * (rxy * deny), T(1)), fy = fmin_(aq2 * (rxy * denx), T(1));
+	fx = active ? fx : T(0);
+	fy = active ? fy : T(0);
+	qx = fma_(-qx, fx, qx);
+	qy = fma_(-qy, fy, qy);
 }
 
 template <bool STRICT = true, typename T>
@@ -520,13 +530,20 @@ __device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, con
 	d2 = small_to_zero<STRICT>(d2, vs);
 	d3 = small_to_zero<STRICT>(d3, vs);
 
-	if (fN.stop || fE.stop || fS.stop || fW.stop) { c.qx = T(0); c.qy = T(0); }   // :351-355
-
-	c.z  = c.z  - dt * d0;                                           // :358-360
-	c.qx = c.qx - dt * d2;
-	c.qy = c.qy - dt * d3;
-
-	if (with_friction) friction<STRICT>(c.qx, c.qy, c.z, zb, n, dt, vs);          // :362-372
+	const bool stop = fN.stop || fE.stop || fS.stop || fW.stop;
+	if (STRICT) {
+		if (stop) { c.qx = T(0); c.qy = T(0); }                      // :351-355
+		c.z  = c.z  - dt * d0;                                       // :358-360
+		c.qx = c.qx - dt * d2;
+		c.qy = c.qy - dt * d3;
+		if (with_friction) friction<true>(c.qx, c.qy, c.z, zb, n, dt, vs);        // :362-372
+	} else {
+		if (__any(stop)) { c.qx = stop ? T(0) : c.qx; c.qy = stop ? T(0) : c.qy; }   // a stopping condition needs a dry side
+		c.z  = fma_(-dt, d0, c.z);
+		c.qx = fma_(-dt, d2, c.qx);
+		c.qy = fma_(-dt, d3, c.qy);
+		if (with_friction) friction_fast(c.qx, c.qy, c.z, zb, n, dt, vs);
+	}
 
 	if (CLAMP_FIRST) {                                               // mch_2nd_cacheNone order (MUSCL :791-796)
 		if (c.z - zb < vs) c.z = zb;
@@ -615,9 +632,12 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 	// changes nothing and the re-extrapolated faces are the cell state again: exactly, in both arithmetic flavours
 	// (+-0.5 * 0 + c = c; x - x = 0; 0 * anything finite = 0).  The rest of the predictor is skipped for the whole
 	// wavefront.  Flood models are mostly such water (and dry land) most of the time.
-	const bool flat = sx.z == T(0) && sx.h == T(0) && sx.qx == T(0) && sx.qy == T(0) &&
-	                  sy.z == T(0) && sy.h == T(0) && sy.qx == T(0) && sy.qy == T(0);
-	quiet_row = __all(first || flat);       // wave-uniform: every lane's four faces ARE its cell state
+	bool flat = sx.z == T(0) && sy.z == T(0);                                           // staged like `same`
+	quiet_row = false;
+	if (__all(first || flat)) {
+		flat = flat && sx.h == T(0) && sx.qx == T(0) && sx.qy == T(0) && sy.h == T(0) && sy.qx == T(0) && sy.qy == T(0);
+		quiet_row = __all(first || flat);   // wave-uniform: every lane's four faces ARE its cell state
+	}
 	if (quiet_row) return f;
 	if (first) return f;
 
