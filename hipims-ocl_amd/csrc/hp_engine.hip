@@ -24,6 +24,8 @@ namespace {
 
 thread_local std::string g_last_error;
 
+constexpr size_t CFL_SLOT_BYTES = 1024;        // hp_math.hpp: SLOT_* elements, each on its own 256-B line
+
 // RCCL entry points, resolved by hp_comm_load
 struct Rccl {
 	void* handle = nullptr;
@@ -79,7 +81,7 @@ struct hp_domain {
 	void*            bed = nullptr;
 	void*            manning = nullptr;
 	void*            scalars = nullptr;               // Scalars<T> on the device
-	void*            cfl_slot = nullptr;              // T[4]: running max | last used max | edge ring of [0] | of [1]
+	void*            cfl_slot = nullptr;              // CFL_SLOT_BYTES: running max | SLOT_SAVED last used max | SLOT_EDGE ring maxima of [0], [1]
 	bool             manning_uniform = false;         // found at upload: one value everywhere -> kernels skip the array
 	double           manning_value = 0.0;
 	bool             need_full_reduce = true;         // the remembered maximum is stale (upload / link import)
@@ -653,14 +655,14 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	HIP_TRY_C(hipMalloc(&d->bed, d->cells * d->esize));
 	HIP_TRY_C(hipMalloc(&d->manning, d->cells * d->esize));
 	HIP_TRY_C(hipMalloc(&d->scalars, 256));
-	HIP_TRY_C(hipMalloc(&d->cfl_slot, 1024));
+	HIP_TRY_C(hipMalloc(&d->cfl_slot, CFL_SLOT_BYTES));
 
 	HIP_TRY_C(hipHostMalloc(&d->host_scalars, 512, hipHostMallocDefault));
 	HIP_TRY_C(hipMemset(d->state[0], 0, d->cells * 4 * d->esize));
 	HIP_TRY_C(hipMemset(d->state[1], 0, d->cells * 4 * d->esize));
 	HIP_TRY_C(hipMemset(d->bed, 0, d->cells * d->esize));
 	HIP_TRY_C(hipMemset(d->manning, 0, d->cells * d->esize));
-	HIP_TRY_C(hipMemset(d->cfl_slot, 0, 1024));
+	HIP_TRY_C(hipMemset(d->cfl_slot, 0, CFL_SLOT_BYTES));
 	HIP_TRY_C(hipMemset(d->scalars, 0, 256));
 	HIP_TRY_C(hipEventCreate(&d->ev_start));
 	HIP_TRY_C(hipEventCreate(&d->ev_stop));
@@ -756,10 +758,12 @@ int hp_state_save(hp_domain_t* d)
 	const size_t bytes = d->cells * 4 * d->esize;
 	const size_t sc_bytes = d->desc.precision == 8 ? sizeof(Scalars<double>) : sizeof(Scalars<float>);
 	if (!d->saved_state) HIP_TRY(hipMalloc(&d->saved_state, bytes));
-	if (!d->saved_scalars) HIP_TRY(hipMalloc(&d->saved_scalars, sc_bytes + 4 * d->esize));
+	if (!d->saved_scalars) HIP_TRY(hipMalloc(&d->saved_scalars, sc_bytes + CFL_SLOT_BYTES));
 	HIP_TRY(hipMemcpyAsync(d->saved_state, d->state[d->use_alt], bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->saved_scalars, d->scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
-	HIP_TRY(hipMemcpyAsync((char*)d->saved_scalars + sc_bytes, d->cfl_slot, 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
+	// the WHOLE slot block: running maximum, last maximum used (SLOT_SAVED), ring maxima (SLOT_EDGE) -- round 2 kept the first
+	// four elements only, which since the slots moved 256 B apart no longer included the remembered maximum
+	HIP_TRY(hipMemcpyAsync((char*)d->saved_scalars + sc_bytes, d->cfl_slot, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
 	d->saved_full_reduce = d->need_full_reduce;
 	d->saved_edge_dirty = d->edge_dirty;
 	d->saved_use_alt = d->use_alt;
@@ -780,7 +784,7 @@ int hp_state_restore(hp_domain_t* d)
 	HIP_TRY(hipMemcpyAsync(d->state[0], d->saved_state, bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->state[1], d->saved_state, bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->scalars, d->saved_scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
-	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
 	d->use_alt = d->saved_use_alt;
 	// a bed or state upload between save and restore has left its own marks: they stay
 	d->need_full_reduce = d->need_full_reduce || d->saved_full_reduce;

@@ -270,11 +270,13 @@ def test_fp32_fast_soak_stays_finite_and_conservative(scheme):
 # ---- device-side checkpoint (hp_state_save / hp_state_restore): saveCurrentState + rollbackSimulation kept in HBM ----
 @pytest.mark.parametrize("scheme", [hp.SCHEME_GODUNOV, hp.SCHEME_MUSCL_HANCOCK, hp.SCHEME_INERTIAL])
 @pytest.mark.parametrize("saved_after", [6, 7])          # both ping-pong phases (quirk Q1 prices the primary buffer only)
-def test_state_restore_replays_bit_for_bit(scheme, saved_after):
+@pytest.mark.parametrize("rain", [True, False])           # without a boundary every other iteration re-uses the REMEMBERED maximum
+def test_state_restore_replays_bit_for_bit(scheme, saved_after, rain):
     st, bed, man = syn.s_rough(192, 96)
     d = hp.Domain(192, 96, scheme=scheme)
     d.upload(st, bed, man)
-    d.add_uniform(hp.UNIFORM_RAIN_INTENSITY, [[0.0, 30.0], [3600.0, 30.0]], 3600.0, 3600.0)
+    if rain:
+        d.add_uniform(hp.UNIFORM_RAIN_INTENSITY, [[0.0, 30.0], [3600.0, 30.0]], 3600.0, 3600.0)
     d.set_target_time(1e9)
     d.step_batch(saved_after)
     d.state_save()
