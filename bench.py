@@ -318,6 +318,8 @@ def main():
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
                        "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + (f", per-iteration loop: {getattr(runner, 'loop', 'batch call')}" if world > 1 else "") + (f", collective library {strip_info['library']} reporting {strip_info['comm_ranks']} ranks, halo overlap {'on' if strip_info['halo_overlap'] else 'off'}" if strip_info else "") + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
                                                                 else " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"),
+                       "area_boundaries": ("none" if args.workload != "s-rain" else
+                                           "fused into the flux kernel's store epilogue" if runner.domain.boundaries_fused() else "separate pass"),
                        "timed_steps": [args.warmup + args.evolve_steps, args.warmup + args.evolve_steps + args.steps],
                        "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -97,6 +97,10 @@ struct hp_domain {
 	int              use_alt = 0;                     // bUseAlternateKernel
 	bool             in_step = false;
 	std::vector<Boundary> bdy;
+	// area boundaries carried by the flux kernel's fused epilogue (K1, FUSED): device copy of their descriptors
+	void*            fused_list = nullptr;
+	bool             fusable = false;                 // Godunov, tuned kernel, 1..FUSED_BDY_MAX uniform / coarse gridded boundaries, no cell boundary
+	int              fuse_next = 0;                   // this iteration is followed by another one of the same batch
 	uint64_t         cells_calculated = 0, iterations = 0;
 	hipEvent_t       ev_start = nullptr, ev_stop = nullptr;
 	// flux-kernel timing samples
@@ -164,7 +168,7 @@ template <typename T> int apply_boundaries(hp_domain* d, void* target)
 	auto flush = [&]() {
 		if (list.count == 0) return;
 		hipLaunchKernelGGL(bdy_area<T>, grid, block, 0, d->stream, p, (const Scalars<T>*)d->scalars, list, (State4<T>*)target,
-		                   (const T*)d->bed, truncated);
+		                   (const T*)d->bed, truncated, d->fusable ? (const T*)d->cfl_slot + SLOT_BDY : (const T*)nullptr);
 		list.count = 0;
 	};
 	for (const Boundary& b : d->bdy) {
@@ -309,9 +313,17 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	unsigned blocks;
 	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg))
 		return HP_OK;
-	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
-	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
+	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
+	if (d->fusable)
+		hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, true, T>), dim3(blocks), dim3(256), 0, stream, p,
+		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm,
+		                   (const AreaBdyList<T>*)d->fused_list, d->fuse_next, truncated);
+	else
+		hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, false, T>), dim3(blocks), dim3(256), 0, stream, p,
+		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm,
+		                   (const AreaBdyList<T>*)nullptr, 0, truncated);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -487,6 +499,48 @@ template <typename T> int set_scalar_field(hp_domain* d, size_t offset, double v
 {
 	hipLaunchKernelGGL(store_scalar<T>, dim3(1), dim3(1), 0, d->stream, (T*)((char*)d->scalars + offset), (T)value);
 	HIP_TRY(hipGetLastError());
+	return HP_OK;
+}
+
+
+// Which area boundaries the flux kernel carries itself (K1 FUSED, hp_kernels.hpp): Godunov scheme, tuned kernel, nothing but
+// uniform / gridded boundaries (a cell boundary in between has its place in the order added), at most FUSED_BDY_MAX of
+// them, and rain grids coarse enough for a tile to meet at most two grid rows and a wavefront two grid columns.  Everything
+// else keeps the stand-alone pass.  HP_FUSE_BDY=0 switches the fusion off (A/B runs).
+template <typename T> int refresh_fusable_t(hp_domain* d)
+{
+	static const bool enabled = !(std::getenv("HP_FUSE_BDY") && std::atoi(std::getenv("HP_FUSE_BDY")) == 0);
+	d->fusable = false;
+	if (!enabled || d->desc.scheme != HP_SCHEME_GODUNOV || d->desc.kernel == HP_KERNEL_BASIC) return HP_OK;
+	if (d->bdy.empty() || d->bdy.size() > (size_t)FUSED_BDY_MAX) return HP_OK;
+	AreaBdyList<T> list;
+	list.count = 0;
+	for (const Boundary& b : d->bdy) {
+		if (b.kind == 2) return HP_OK;
+		AreaBdy<T>& a = list.b[list.count++];
+		a = AreaBdy<T>{};
+		if (b.kind == 0) {
+			a.kind = 0;
+			a.u = UniformBdy<T>{(const T*)b.data, (uint32_t)b.entries, b.definition, (T)b.interval, (T)b.length};
+		} else {
+			if (b.resolution < 64.0 * d->desc.dx) return HP_OK;
+			a.kind = 1;
+			a.g = GriddedBdy<T>{(const T*)b.data, b.entries, b.grows, b.gcols, b.definition,
+			                    (T)b.resolution, (T)b.off_x, (T)b.off_y, (T)b.interval};
+		}
+	}
+	if (!d->fused_list) HIP_TRY(hipMalloc(&d->fused_list, sizeof(AreaBdyList<double>)));
+	HIP_TRY(hipMemcpy(d->fused_list, &list, sizeof list, hipMemcpyHostToDevice));
+	d->fusable = true;
+	return HP_OK;
+}
+
+int refresh_fusable(hp_domain* d)
+{
+	int rc = d->desc.precision == 8 ? refresh_fusable_t<double>(d) : refresh_fusable_t<float>(d);
+	if (rc != HP_OK) return rc;
+	// nothing of a next iteration is in any buffer at this point (a batch's last iteration never fuses)
+	HIP_TRY(hipMemsetAsync((char*)d->cfl_slot + (size_t)SLOT_BDY * d->esize, 0, d->esize, d->stream));
 	return HP_OK;
 }
 
@@ -690,7 +744,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
 	hipFree(d->scalars); hipFree(d->cfl_slot);
-	hipFree(d->saved_state); hipFree(d->saved_scalars);
+	hipFree(d->saved_state); hipFree(d->saved_scalars); hipFree(d->fused_list);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
 	if (d->ev_stop) hipEventDestroy(d->ev_stop);
@@ -719,6 +773,7 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 		d->use_alt = 0;                                                   // :1075
 		d->need_full_reduce = true;
 		d->edge_dirty = true;
+		HIP_TRY(hipMemsetAsync((char*)d->cfl_slot + (size_t)SLOT_BDY * d->esize, 0, d->esize, d->stream));
 		return HP_OK;
 	case HP_ARRAY_BED:
 		if (bytes != d->cells * d->esize) return fail(HP_ERR_INVALID, "bed size mismatch");
@@ -840,7 +895,7 @@ int hp_boundary_add_uniform(hp_domain_t* d, int definition, const void* series, 
 	HIP_TRY(hipMalloc(&b.data, bytes));
 	HIP_TRY(hipMemcpy(b.data, series, bytes, hipMemcpyHostToDevice));
 	d->bdy.push_back(b);
-	return HP_OK;
+	return refresh_fusable(d);
 }
 
 int hp_boundary_add_gridded(hp_domain_t* d, int definition, const void* grids, uint64_t entries,
@@ -868,7 +923,7 @@ int hp_boundary_add_gridded(hp_domain_t* d, int definition, const void* grids, u
 	HIP_TRY(hipMalloc(&b.data, bytes));
 	HIP_TRY(hipMemcpy(b.data, grids, bytes, hipMemcpyHostToDevice));
 	d->bdy.push_back(b);
-	return HP_OK;
+	return refresh_fusable(d);
 }
 
 int hp_boundary_add_cell(hp_domain_t* d, int depth_definition, int discharge_definition, const uint64_t* cells,
@@ -902,7 +957,7 @@ int hp_boundary_add_cell(hp_domain_t* d, int depth_definition, int discharge_def
 	HIP_TRY(hipMemcpy(b.data, series, bytes, hipMemcpyHostToDevice));
 	d->bdy.push_back(b);
 	d->bdy_on_ring = d->bdy_on_ring || on_ring;
-	return HP_OK;
+	return refresh_fusable(d);
 }
 
 int hp_boundary_clear(hp_domain_t* d)
@@ -913,6 +968,13 @@ int hp_boundary_clear(hp_domain_t* d)
 	for (auto& b : d->bdy) { hipFree(b.data); hipFree(b.cells); }
 	d->bdy.clear();
 	d->bdy_on_ring = false;
+	return refresh_fusable(d);
+}
+
+int hp_boundaries_fused(hp_domain_t* d, int* fused)
+{
+	if (!d || !fused) return fail(HP_ERR_INVALID, "null argument");
+	*fused = d->fusable ? 1 : 0;
 	return HP_OK;
 }
 
@@ -1007,9 +1069,13 @@ int hp_step_batch(hp_domain_t* d, uint32_t n_iterations)
 	if (rc != HP_OK) return rc;
 	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
 	for (uint32_t i = 0; i < n_iterations; ++i) {
+		// (K1 FUSED) every iteration but the last carries its successor's rain / loss: between batches the buffers are
+		// what the reference's are -- a download never sees rain of an iteration that has not begun
+		d->fuse_next = i + 1 < n_iterations;
 		if ((rc = dispatch_begin(d)) != HP_OK) return rc;
 		if ((rc = dispatch_end(d)) != HP_OK) return rc;
 	}
+	d->fuse_next = 0;
 	return HP_OK;
 }
 
@@ -1250,6 +1316,7 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
 	d->fork_is_advance = fork_ready;
 	for (uint32_t i = 0; i < n_iterations; ++i) {
+		d->fuse_next = i + 1 < n_iterations;          // as hp_step_batch: the rows sent to the neighbours carry the rain too
 		if ((rc = dispatch_begin(d)) != HP_OK) return rc;
 		if ((rc = strip_exchange(d, d->adv_fresh != 0)) != HP_OK) return rc;
 		if ((rc = dispatch_end(d)) != HP_OK) return rc;
@@ -1258,6 +1325,7 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 		// and let hp_step_begin record its own fork event whenever a transfer was queued on the domain's stream
 		if (!d->halo_overlap) d->fork_is_advance = false;
 	}
+	d->fuse_next = 0;
 	return HP_OK;
 }
 

@@ -302,12 +302,60 @@ __device__ __forceinline__ bool tile_rows(const TileMap& tm, const int wave, lon
 	return y0 < band_y1 && strip < tm.nstrips;
 }
 
-template <bool STRICT, int CFL_MODE, typename T>
+// ---- area boundaries (bdy_Uniform / bdy_Gridded, Boundaries/CLBoundaries.clc:130-246): descriptors shared by the stand-alone
+//      pass (bdy_area, further down) and by the flux kernel's fused epilogue ----
+template <typename T> struct UniformBdy { const T* series; uint32_t entries; int definition; T interval, length; };
+template <typename T> struct GriddedBdy {
+	const T* grids; uint64_t entries, grows, gcols; int definition; T resolution, off_x, off_y, interval;
+};
+
+template <typename T>
+__device__ __forceinline__ bool bdy_in_range(const Params<T>& p, const long x, const long gy, const bool truncated)
+{
+	if (x >= p.cols - 1 || gy >= p.global_rows - 1 || x <= 0 || gy <= 0) return false;
+	// NDRange = floor(n/8)*8 per axis (CBoundaryUniform.cpp:294-295, CBoundaryGridded.cpp:298-299; Q9)
+	if (truncated && (x >= (p.cols / 8) * 8 || gy >= (p.global_rows / 8) * 8)) return false;
+	return true;
+}
+
+constexpr int AREA_BDY_MAX = 8;
+template <typename T> struct AreaBdy {
+	int kind;                      // 0 uniform, 1 gridded
+	UniformBdy<T> u;
+	GriddedBdy<T> g;
+};
+template <typename T> struct AreaBdyList { int count; AreaBdy<T> b[AREA_BDY_MAX]; };
+
+
+// What the fused epilogue of K1 carries per area boundary: the level increment of the tile's lower / upper rain-grid row
+// (a uniform boundary has one value for both), the first row of the upper one, and how it is applied.
+constexpr int FUSED_BDY_MAX = 3;
+constexpr int SLOT_BDY = 96;            // cfl_slot[SLOT_BDY] != 0: the next iteration's area boundaries are already in its source buffer
+template <typename T> struct FusedBdy {
+	T    inc_lo, inc_hi;                // per lane: metres added per application (uniform loss: metres removed)
+	int  y_switch;                      // local row from which inc_hi applies
+	int  mode;                          // -1 inactive, 0 add (uniform rain), 1 loss (floor at the bed), 2 add with the gridded kernel's extra null test
+};
+
+// FUSED (round 3): the instantiation a domain with fusable area boundaries runs.  The reference applies rain / loss IN PLACE
+// to an iteration's source buffer before its flux kernel (CSchemeGodunov.cpp:1637-1643).  Iteration n+1's source buffer
+// is what iteration n writes, and everything the boundary kernels of iteration n+1 read -- t, t_hydro and the sign of
+// dt -- follows from scalars that are known when the flux kernel of iteration n starts (tst_Advance_Normal:
+// t += dt, t_hydro accumulates or restarts, CLDynamicTimestep.clc:42-66), EXCEPT the new dt, of which the uniform
+// kernel only asks whether it is positive (CLBoundaries.clc:165-166).  So this kernel adds iteration n+1's increments to
+// the state it is about to store: same operations per cell as the stand-alone pass, no second trip through HBM.  Cells it
+// does not store (all-dry neighbourhoods, quirk Q3) get theirs read-modify-write in the cold pass after the row loop.
+// The host asks for it (`fuse_next`) on every iteration of a batch but the last -- what a download sees between batches
+// is the reference's buffer, without the next iteration's rain -- and the kernel declines when dt's sign is not certain
+// (within VERY_SMALL of the sync point, at the end time): the word at cfl_slot[SLOT_BDY] tells the stand-alone pass of
+// the next iteration whether there is anything left for it to do.
+template <bool STRICT, int CFL_MODE, bool FUSED, typename T>
 __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
-                                                     const TileMap tm)
+                                                     const TileMap tm, const AreaBdyList<T>* __restrict__ fused_list,
+                                                     const int fuse_next, const int truncated)
 {
 	// the wave index is made a scalar explicitly: everything derived from it (tile rows, buffer descriptors, row
 	// offsets) then lives in SGPRs and the buffer accesses need no waterfall loop
@@ -324,6 +372,100 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	const bool with_friction = p.friction != 0;
 	T vmax = T(0);
 	unsigned long long stale_rows = 0;   // bit i: row y0+i of this lane was left untouched (all-dry, Q3); rseg <= 64
+
+	// ---- fused area boundaries of the NEXT iteration (see above) ----
+	FusedBdy<T> fb[FUSED_BDY_MAX];
+	bool fuse = false, fuse_flag = false;                                          // wave-uniform
+	bool fuse_x = false;                                                           // this lane's column is inside the boundary kernels' range
+	if (FUSED) {
+		#pragma unroll
+		for (int k = 0; k < FUSED_BDY_MAX; ++k) { fb[k].inc_lo = fb[k].inc_hi = T(0); fb[k].y_switch = 0; fb[k].mode = -1; }
+		if (fuse_next) {
+			// t and t_hydro as tst_Advance_Normal will leave them (CLDynamicTimestep.clc:42-66, the statements of advance_body)
+			const T dt_n = fmax_(T(0), dt);
+			const T t1 = sc->t + dt_n;
+			const T th0 = sc->t_hydro;
+			const T th1 = (th0 > T(1.0)) ? dt_n : (th0 + dt_n);
+			// dt of the next iteration is positive whatever the new maximum is, unless the sync point or the end time
+			// intervene (:112-137); only the uniform kernel asks (CLBoundaries.clc:165-166)
+			const bool dt_positive = (sc->t_sync - t1 > p.vs) && (t1 < p.t_end) && (p.dynamic_dt || p.dt_fixed > T(0));
+			const int nb = fused_list->count;
+			bool has_uniform = false;
+			#pragma unroll
+			for (int k = 0; k < FUSED_BDY_MAX; ++k) has_uniform = has_uniform || (k < nb && fused_list->b[k].kind == 0);
+			fuse_flag = !has_uniform || dt_positive;
+			fuse = fuse_flag && th1 >= T(1.0);                                         // the hydrological gate (:165, :224)
+			if (fuse) {
+				const long tile_rows_n = y1 - y0;
+				fuse_x = x >= 1 && x <= p.cols - 2 && (!truncated || x < (p.cols / 8) * 8);     // bdy_in_range, column part
+				#pragma unroll
+				for (int k = 0; k < FUSED_BDY_MAX; ++k) {                                 // (static indices: fb[] lives in registers)
+					if (k >= nb) continue;
+					const AreaBdy<T>& b = fused_list->b[k];
+					if (b.kind == 0) {
+						if (t1 >= b.u.length) continue;                                       // :168
+						unsigned long ts = (unsigned long)floor_(t1 / b.u.interval);          // :172-173
+						if (ts >= b.u.entries) ts = b.u.entries - 1;
+						const T amount = b.u.series[2 * ts + 1] / T(3600000.0) * th1;
+						fb[k].inc_lo = fb[k].inc_hi = amount;
+						fb[k].y_switch = (int)y0;
+						fb[k].mode = b.u.definition == 1 ? 1 : (b.u.definition == 0 ? 0 : -1);
+					} else {
+						if (b.g.definition != 0 && b.g.definition != 2) continue;           // accumulated depths: nothing is applied (:238-242)
+						unsigned long ts = (unsigned long)floor_(t1 / b.g.interval);          // :228
+						if (ts >= b.g.entries) ts = b.g.entries - 1;
+						// this lane's rain-grid column, and the rain-grid row of tile row y0 + lane (one evaluation per
+						// lane covers the tile's rows: the host only fuses grids whose cells are at least 64 model cells
+						// wide and high, so a tile meets at most two grid rows and a wavefront at most two grid columns)
+						T colf = floor_((((T)xc * p.dx) - b.g.off_x) / b.g.resolution);          // :231
+						if (colf < T(0)) colf = T(0);
+						const long gy_l = y0 + lane + p.row_offset;
+						const T rowf = floor_((((T)gy_l * p.dx) - b.g.off_y) / b.g.resolution);  // :232
+						const unsigned long col = (unsigned long)colf;
+						const unsigned long c0 = (unsigned long)__builtin_amdgcn_readfirstlane((int)col);
+						const unsigned long c1 = (c0 + 1 < b.g.gcols) ? c0 + 1 : c0;
+						const long row_l = (long)rowf;
+						const long r_lo = (long)__builtin_amdgcn_readfirstlane((int)row_l);
+						const unsigned long long in_lo = __ballot(lane < tile_rows_n && row_l == r_lo);
+						const long n_lo = (long)__popcll(in_lo);
+						const long r_hi = (n_lo < tile_rows_n) ? r_lo + 1 : r_lo;
+						const unsigned long base = (b.g.grows * b.g.gcols) * ts;
+						const unsigned long rl = (unsigned long)(r_lo < 0 ? 0 : r_lo), rh = (unsigned long)(r_hi < 0 ? 0 : ((unsigned long)r_hi < b.g.grows ? r_hi : (long)b.g.grows - 1));
+						const T g00 = b.g.grids[base + b.g.gcols * rl + c0], g01 = b.g.grids[base + b.g.gcols * rl + c1];
+						const T g10 = b.g.grids[base + b.g.gcols * rh + c0], g11 = b.g.grids[base + b.g.gcols * rh + c1];
+						const T rate_lo = (col == c0) ? g00 : g01, rate_hi = (col == c0) ? g10 : g11;
+						if (b.g.definition == 0) {                                            // :238-239
+							fb[k].inc_lo = rate_lo / T(3600000.0) * th1;
+							fb[k].inc_hi = rate_hi / T(3600000.0) * th1;
+						} else {                                                              // :241-242
+							fb[k].inc_lo = rate_lo / (p.dx * p.dx) * th1;
+							fb[k].inc_hi = rate_hi / (p.dx * p.dx) * th1;
+						}
+						fb[k].y_switch = (int)(y0 + n_lo);
+						fb[k].mode = 2;
+					}
+				}
+			}
+		}
+	}
+	// one cell's share of the next iteration's boundaries, in the order added: the statements of bdy_area
+	auto apply_fused = [&](State4<T> c, const T zb, const long y) {
+		const long gy = y + p.row_offset;
+		const bool row_ok = gy >= 1 && gy <= p.global_rows - 2 && (!truncated || gy < (p.global_rows / 8) * 8);
+		if (!row_ok) return c;                                                    // wave-uniform
+		const bool cell_ok = fuse_x && !(c.zmax <= T(-9999.0));                   // :168-169, :220-221 (first half)
+		#pragma unroll
+		for (int k = 0; k < FUSED_BDY_MAX; ++k) {
+			if (fb[k].mode < 0) continue;                                         // wave-uniform
+			const T inc = ((int)y >= fb[k].y_switch) ? fb[k].inc_hi : fb[k].inc_lo;
+			T z2;
+			if (fb[k].mode == 1) z2 = fmax_(zb, c.z - inc);                       // :179-180
+			else                 z2 = c.z + inc;                                  // :176-177, :238-242
+			const bool ok = cell_ok && !(fb[k].mode == 2 && c.z == T(-9999.0));   // :220-221 (second half; re-tested as the level changes)
+			c.z = ok ? z2 : c.z;
+		}
+		return c;
+	};
 
 	// the wave's window of the four arrays, addressed from its first cell (row y0-1, column of lane 0)
 	const size_t cell0 = (size_t)(y0 - 1) * p.cols + (size_t)(strip * MARCH_COLS);
@@ -420,7 +562,11 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		// out-of-range offset, which the buffer range check drops, instead of branching around the store.  That
 		// keeps the wave's vmcnt bookkeeping static so the wait for the prefetched row never has to drain the
 		// stores behind it.
-		buf_store_state(out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+		// (FUSED) what is stored already carries the next iteration's rain / loss; the CFL epilogue prices the state WITHOUT
+		// it, as the reference's reduction runs before the next iteration's boundary kernels
+		State4<T> stored = out;
+		if (FUSED && fuse) stored = apply_fused(out, rc.zb, y);
+		buf_store_state(stored, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
 		if (CFL_MODE == 1) {
 			if (write) {
 				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
@@ -455,6 +601,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			if (out_x && !disabled) stale_rows |= 1ull << (unsigned)(y - y0);
 			const Side<T> sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
 			fS = face_dry_for_right<AXIS_Y, STRICT>(sC, sN, vs);
+			// (FUSED: the only cells this loop stores are nulls, which no boundary kernel touches)
 			buf_store_state(rc.c, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
 			if (CFL_MODE == 1) {
 				if (write) {
@@ -478,14 +625,19 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	}
 	if (y < y1) row_step(y, rP, rQ);
 
-	if (CFL_MODE == 1 && __any(stale_rows != 0)) {
-		// cells the reference leaves untouched still hold their two-steps-old value in dst, and tst_Reduce prices it
+	if ((CFL_MODE == 1 || (FUSED && fuse)) && __any(stale_rows != 0)) {
+		// cells the reference leaves untouched still hold their two-steps-old value in dst, and tst_Reduce prices it;
+		// (FUSED) the next iteration's boundary kernels would change exactly that value in place: read-modify-write
 		for (long y = y0; y < y1; ++y) {
 			if ((stale_rows >> (unsigned)(y - y0)) & 1ull) {
 				const size_t id = (size_t)y * p.cols + xc;
 				const State4<T> c = dst[id];
-				const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
-				if (s > vmax) vmax = s;
+				const T zb = bed[id];
+				if (CFL_MODE == 1) {
+					const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, zb, p.qs);
+					if (s > vmax) vmax = s;
+				}
+				if (FUSED && fuse) dst[id] = apply_fused(c, zb, y);
 			}
 		}
 	}
@@ -496,6 +648,9 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		vmax = wave_max(vmax);
 		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
+	// (FUSED) tell the next iteration's stand-alone boundary pass whether anything is left for it to do.  Every wavefront
+	// reaches the same decision from the same scalars; one of them writes it down.
+	if (FUSED && blockIdx.x == 0 && wave == 0 && lane == 0) cfl_slot[SLOT_BDY] = fuse_flag ? T(1) : T(0);
 	}   // tile / strip guard
 }
 
@@ -974,20 +1129,6 @@ __global__ __launch_bounds__(256) void cfl_reduce(const Params<T> p, const State
 //     bdy_Uniform (Boundaries/CLBoundaries.clc:130-184), bdy_Gridded (:186-246).
 //     Rows are addressed globally so ghost rows of a strip receive the same rain as their owner gives them.
 // -------------------------------------------------------------------------------------------------
-template <typename T> struct UniformBdy { const T* series; uint32_t entries; int definition; T interval, length; };
-template <typename T> struct GriddedBdy {
-	const T* grids; uint64_t entries, grows, gcols; int definition; T resolution, off_x, off_y, interval;
-};
-
-template <typename T>
-__device__ __forceinline__ bool bdy_in_range(const Params<T>& p, const long x, const long gy, const bool truncated)
-{
-	if (x >= p.cols - 1 || gy >= p.global_rows - 1 || x <= 0 || gy <= 0) return false;
-	// NDRange = floor(n/8)*8 per axis (CBoundaryUniform.cpp:294-295, CBoundaryGridded.cpp:298-299; Q9)
-	if (truncated && (x >= (p.cols / 8) * 8 || gy >= (p.global_rows / 8) * 8)) return false;
-	return true;
-}
-
 // Both kernels run on a small grid-stride grid: the hydrological gate (t_hydro >= 1 s, a device scalar the host
 // cannot see without a sync) is closed on most iterations, and a launch whose every wave exits after reading three
 // scalars must cost microseconds, not a 16 M-thread dispatch.
@@ -1045,18 +1186,12 @@ __global__ __launch_bounds__(256) void bdy_gridded(const Params<T> p, const Scal
 // applied to it in the order added (each exactly as bdy_uniform / bdy_gridded would, gate and all), and written once.
 // Per cell this is the same sequence of operations as the separate launches, so results are bit-identical; what goes
 // away is one launch and one 64 B/cell pass per boundary (the reference's example model has two: rain and drainage).
-constexpr int AREA_BDY_MAX = 8;
-template <typename T> struct AreaBdy {
-	int kind;                      // 0 uniform, 1 gridded
-	UniformBdy<T> u;
-	GriddedBdy<T> g;
-};
-template <typename T> struct AreaBdyList { int count; AreaBdy<T> b[AREA_BDY_MAX]; };
-
 template <typename T>
 __global__ __launch_bounds__(256) void bdy_area(const Params<T> p, const Scalars<T>* __restrict__ sc, const AreaBdyList<T> list,
-                                                State4<T>* __restrict__ state, const T* __restrict__ bed, const bool truncated)
+                                                State4<T>* __restrict__ state, const T* __restrict__ bed, const bool truncated,
+                                                const T* __restrict__ applied)
 {
+	if (applied && *applied != T(0)) return;       // the previous iteration's flux kernel has applied them already (K1, FUSED)
 	const T t = sc->t, dt_real = sc->dt, dt = sc->t_hydro;
 	if (dt < T(1.0)) return;                                                      // CLBoundaries.clc:165, :224 (uniform over the grid)
 	// per boundary: is it active this iteration, and (uniform) how much does it add / remove

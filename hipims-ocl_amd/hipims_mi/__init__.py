@@ -30,7 +30,7 @@ PTR_STATE_NEXT_SRC, PTR_STATE_OTHER, PTR_BED, PTR_MANNING, PTR_CFL_MAX, PTR_SCAL
 EXPORTS = [
     "hp_abi_version", "hp_device_count", "hp_device_info", "hp_last_error", "hp_set_log_sink", "hp_domain_desc_default",
     "hp_domain_create", "hp_domain_destroy", "hp_domain_upload", "hp_domain_download", "hp_domain_upload_rows", "hp_state_save", "hp_state_restore",
-    "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_add_cell", "hp_boundary_clear", "hp_set_target_time", "hp_set_time",
+    "hp_boundary_add_uniform", "hp_boundary_add_gridded", "hp_boundary_add_cell", "hp_boundary_clear", "hp_boundaries_fused", "hp_set_target_time", "hp_set_time",
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
     "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_set_halo_overlap",
     "hp_stream_halo", "hp_comm_load", "hp_comm_unique_id", "hp_strip_comm_init", "hp_strip_step_batch", "hp_strip_update_timestep",
@@ -126,6 +126,7 @@ def load_library(path: str | None = None):
     lib.hp_boundary_add_cell.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                          C.c_double, C.c_double]
     lib.hp_boundary_clear.argtypes = [C.c_void_p]
+    lib.hp_boundaries_fused.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.hp_set_target_time.argtypes = [C.c_void_p, C.c_double]
     lib.hp_force_timestep.argtypes = [C.c_void_p, C.c_double]
     lib.hp_set_time.argtypes = [C.c_void_p, C.c_double]
@@ -318,6 +319,12 @@ class Domain:
         _check(self.lib, self.lib.hp_boundary_add_cell(self.h, depth_def, discharge_def, rel.ctypes.data_as(C.c_void_p),
                                                        rel.size, ser.ctypes.data_as(C.c_void_p), ser.shape[0], interval,
                                                        length), "hp_boundary_add_cell")
+
+    def boundaries_fused(self):
+        """True when rain / loss ride in the flux kernel's store epilogue instead of a pass of their own."""
+        f = C.c_int(0)
+        _check(self.lib, self.lib.hp_boundaries_fused(self.h, C.byref(f)), "hp_boundaries_fused")
+        return bool(f.value)
 
     # ---- time control / stepping ----
     def set_target_time(self, t):

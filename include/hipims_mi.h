@@ -174,6 +174,12 @@ enum { HP_DISCHARGE_IGNORE = 0, HP_DISCHARGE_IS_DISCHARGE = 1, HP_DISCHARGE_IS_V
 int hp_boundary_add_cell(hp_domain_t* d, int depth_definition, int discharge_definition, const uint64_t* cells,
                          uint64_t count, const void* series, uint64_t entries, double interval, double length);
 int hp_boundary_clear(hp_domain_t* d);
+/* Are the domain's area boundaries carried by the flux kernel itself (rain / loss of iteration n+1 added to the state
+ * iteration n stores, no separate pass over the grid)?  True for the Godunov scheme with up to three uniform / gridded
+ * boundaries, no cell boundary among them, and rain grids of at least 64 model cells per grid cell; everything else runs
+ * the boundary kernels as separate launches like the reference (CSchemeGodunov.cpp:1637-1643).  Results are identical
+ * either way; bench.py reports it. */
+int hp_boundaries_fused(hp_domain_t* d, int* fused);
 
 /* ---- time control ---- */
 int hp_set_target_time(hp_domain_t* d, double t);     /* CScheme::setTargetTime -> "Target time (sync)" buffer (:1166-1176) */
