@@ -656,20 +656,40 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	// tile that still gives every CU some blocks (tools/small_grid_probe.py: 4096^2 and 2048^2 want 16, 1024^2 8,
 	// 512^2 4, the 342 x 195 example 2).
 	{
-		auto pick = [&](long updated_rows, long updated_cols, int tile_cols, int tallest, int shortest) {
+		int cus = 256;
+		hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, desc->device);
+		static const bool refine = !(std::getenv("HP_RSEG_REFINE") && std::atoi(std::getenv("HP_RSEG_REFINE")) == 0);
+		auto pick = [&](long updated_rows, long updated_cols, int tile_cols, int tallest, int shortest, int blocks_per_cu) {
 			const long groups = ((updated_cols + tile_cols - 1) / tile_cols + 3) / 4;
 			int rseg = tallest;
 			while (rseg > shortest && groups * ((updated_rows + rseg - 1) / rseg) < 350) rseg /= 2;
+			// Round 3: a launch whose blocks all fit the chip at once (a row strip of a strong-scaling run: 4096 x 514 is 544
+			// tiles of 16 rows on 768 block slots) lasts as long as ONE tile does, so the shortest tile that still fits in one
+			// round wins: 13-row tiles put that strip into 680 blocks (56 -> 51 us per iteration).  Fine-tune within
+			// (rseg/2, rseg] where the halving above left a middle-sized tile; launches of more than one round are left alone
+			// (tools/r03k.sh: 2048^2, 4096 x 1026 and 8192 x 514 lose 0-9 % with shorter tiles).
+			if (refine && rseg >= 8) {
+				const long band_rows = (updated_rows + 7) / 8, slots = (long)cus * blocks_per_cu;
+				auto cost = [&](int r) {
+					const long blocks = groups * 8 * ((band_rows + r - 1) / r);
+					return ((blocks + slots - 1) / slots) * (long)(2 * r + 7);        // rounds x (rows + 3.5), doubled to stay integral
+				};
+				if (groups * 8 * ((band_rows + rseg - 1) / rseg) <= slots) {        // measured (profiles/r03k): no gain beyond one round
+					int best = rseg;
+					for (int r = rseg - 1; r > rseg / 2; --r) if (cost(r) < cost(best)) best = r;
+					rseg = best;
+				}
+			}
 			return rseg;
 		};
 		// fp32 rows are cheap enough for a tile's three-row fill and extra south face to show: 32-row tiles measured
 		// 13 % (S-DAM) to 47 % (S-RAIN 8192^2) ahead of 16; fp64 is flat or slightly worse beyond 18
-		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? 32 : 16, 2);
+		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? 32 : 16, 2, desc->precision == 4 ? 5 : 3);
 		d->inertial_rseg = d->march_rseg;
 		// K2 after the inert-row cut (round 2): a tile of still water or dry land costs a fifth of a tile on the flood front,
 		// so fp64 wants more, shorter tiles for the dispatcher to balance (16-20 rows: 0.319 ms against 0.355 at 32 on the
 		// 4096^2 dam break, 0.355 against 0.395 on the developed flood, +2-5 % at 8192^2 and 16384 x 1028); fp32 stays at 32
-		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? 32 : 16, 4);
+		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? 32 : 16, 4, desc->precision == 4 ? 4 : 3);
 	}
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);

@@ -3,7 +3,7 @@
 Same options as the reference executable (src/main.cpp:464-567): -c/--config-file, -l/--log-file, -s/--quiet-mode,
 -n/--disable-screen (accepted, there is no curses screen here), -m/--mpi-mode (one process per GPU is the strip runner's
 job: rejected), -x/--code-dir (accepted and ignored: the kernels are compiled into libhipims_mi.so).  Extras:
---output-format .npy|.asc, --batch N (fixed batch size instead of the autotuner).  There is no CPU fallback: without
+--output-format xml|.img|.npy|.asc, --batch N (fixed batch size instead of the autotuner).  There is no CPU fallback: without
 the HIP library and a GPU this exits with the engine's error.
 """
 import argparse
@@ -18,7 +18,8 @@ def main(argv=None):
     ap.add_argument("-n", "--disable-screen", action="store_true", help="(accepted; no curses screen here)")
     ap.add_argument("-m", "--mpi-mode", action="store_true", help="(not supported: use the strip runner)")
     ap.add_argument("-x", "--code-dir", default=None, help="(accepted and ignored)")
-    ap.add_argument("--output-format", default=".asc", choices=[".npy", ".asc"])
+    ap.add_argument("--output-format", default="xml", choices=["xml", ".img", ".npy", ".asc"],
+                    help="xml (default): the driver each <dataTarget format=...> names (HFA -> .img, others -> .asc)")
     ap.add_argument("--batch", type=int, default=0, help="fixed batch size (default: autotuned, as the reference)")
     args = ap.parse_args(argv)
     if args.mpi_mode:

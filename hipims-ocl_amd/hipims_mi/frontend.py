@@ -14,7 +14,7 @@ What is mirrored (paths relative to the reference's src/):
   * main loop                   CModel.cpp:723-770, :870-891 (sync at every output time), CSchemeGodunov::runSimulation
   * output derivations          Datasets/CRasterDataset.cpp:185-267 (depth, velocity, fsl, maxdepth, maxfsl, froude;
                                 threshold 1e-8, NODATA -9999)
-Rasters: HFA .img through hipims_mi.hfa (read), ESRI ASCII .asc and NumPy .npy (read and write).
+Rasters: HFA .img through hipims_mi.hfa, ESRI ASCII .asc and NumPy .npy (read and write).
 <domainEdge treatment="closed"> is honoured (bed = 9999.9 on that edge, CDomainCartesian.cpp:773-799); the reference
 never parses the element (quirk Q9), so its own behaviour there is undefined.
 """
@@ -71,6 +71,8 @@ def write_raster(path, south_up, resolution, origin=(0.0, 0.0)):
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     if ext == ".npy":
         np.save(path, south_up)
+    elif ext == ".img":                        # format="HFA" in the reference's XML (CDomainCartesian.cpp:300, CRasterDataset.cpp:101-183)
+        hfa.write_raster(path, south_up, resolution, origin)
     elif ext == ".asc":
         with open(path, "w") as f:
             f.write(f"ncols {south_up.shape[1]}\nnrows {south_up.shape[0]}\nxllcorner {origin[0]}\nyllcorner {origin[1]}\n"
@@ -150,8 +152,10 @@ def parse_configuration(xml_path):
     for ds in data.findall("dataSource"):
         cfg.sources.append(((ds.get("type") or "").lower(), [v.strip().lower() for v in (ds.get("value") or "").split(",")],
                             ds.get("source")))
+    cfg.target_formats = []                  # GDAL driver names of the <dataTarget format=...> attributes (CDomainCartesian.cpp:300)
     for dt in data.findall("dataTarget"):
         cfg.targets.append(((dt.get("value") or "").lower(), dt.get("target")))
+        cfg.target_formats.append((dt.get("format") or "").upper())
     sch = dom.find("scheme")
     name = (sch.get("name") or "godunov").lower()
     # CScheme::createFromConfig (CScheme.cpp:140-176): "muscl-hancock" | "godunov" | "inertial"

@@ -1,4 +1,4 @@
-"""Minimal reader for Erdas Imagine HFA (.img) single-band rasters -- enough for HiPIMS model directories.
+"""Minimal reader and writer for Erdas Imagine HFA (.img) single-band rasters -- enough for HiPIMS model directories.
 
 The reference reads rasters through GDAL (src/Datasets/CRasterDataset.cpp:101-183); GDAL is not available here, and
 the only raster format the reference's example ships is an RLE-compressed float32 HFA file.  This reader walks the
@@ -156,3 +156,121 @@ def read_raster(path):
     """Raster as the reference holds it: row 0 = south (CRasterDataset.cpp:411), float64."""
     arr, info = read_hfa(path)
     return np.ascontiguousarray(arr[::-1]).astype(np.float64), info
+
+
+# ------------------------------------------------------------------------------------------------ writer
+# The reference writes its outputs through GDAL with the driver the XML names -- format="HFA" in its example model
+# (src/Datasets/CRasterDataset.cpp:101-183: one band, GDT_Float64, geotransform = top-left corner, rows top to bottom).
+# The writer below produces the same thing without GDAL: an Ehfa tree with one Eimg_Layer of f64 pixels in uncompressed
+# 64 x 64 blocks (GDAL's HFA block size), its RasterDMS block table, the Ehfa_Layer record naming the block type, and an
+# Eprj_MapInfo with the pixel-centre coordinates.  The MIF dictionary lists exactly the types used, in the published
+# syntax of the format.  Not written: statistics, pyramids, projection and the no-data node (the value stays -9999 in
+# the data, as in the reference's rasters).
+_DICTIONARY = (
+    "{1:lversion,1:LfreeList,1:LrootEntryPtr,1:sentryHeaderLength,1:LdictionaryPtr,}Ehfa_File,"
+    "{1:Lnext,1:Lprev,1:Lparent,1:Lchild,1:Ldata,1:ldataSize,64:cname,32:ctype,1:tmodTime,}Ehfa_Entry,"
+    "{16:clabel,1:LheaderPtr,}Ehfa_HeaderTag,"
+    "{1:LfreeList,1:lfreeSize,}Ehfa_FreeListNode,"
+    "{1:lsize,1:Lptr,}Ehfa_Data,"
+    "{1:lwidth,1:lheight,1:e3:thematic,athematic,fft of real-valued data,layerType,"
+    "1:e13:u1,u2,u4,u8,s8,u16,s16,u32,s32,f32,f64,c64,c128,pixelType,1:lblockWidth,1:lblockHeight,}Eimg_Layer,"
+    "{1:e2:raster,vector,type,1:LdictionaryPtr,}Ehfa_Layer,"
+    "{1:sfileCode,1:Loffset,1:lsize,1:e2:false,true,logvalid,"
+    "1:e2:no compression,ESRI GRID compression,compressionType,}Edms_VirtualBlockInfo,"
+    "{1:lmin,1:lmax,}Edms_FreeIDList,"
+    "{1:lnumvirtualblocks,1:lnumobjectsperblock,1:lnextobjectnum,"
+    "1:e2:no compression,RLC compression,compressionType,"
+    "0:poEdms_VirtualBlockInfo,blockinfo,0:poEdms_FreeIDList,freelist,1:tmodTime,}Edms_State,"
+    "{0:pcstring,}Emif_String,"
+    "{1:dx,1:dy,}Eprj_Coordinate,"
+    "{1:dwidth,1:dheight,}Eprj_Size,"
+    "{0:pcproName,1:*oEprj_Coordinate,upperLeftCenter,1:*oEprj_Coordinate,lowerRightCenter,"
+    "1:*oEprj_Size,pixelSize,0:pcunits,}Eprj_MapInfo,"
+    "."
+)
+
+
+def write_hfa(path, north_up, upper_left_corner=(0.0, 0.0), pixel_size=1.0, units="meters", block=64):
+    """Write `north_up` (array[rows, cols], row 0 = north) as a one-band f64 HFA raster; `upper_left_corner` is the outer
+    corner of the top-left pixel (a GDAL geotransform's origin), as the reference sets it."""
+    a = np.ascontiguousarray(north_up, dtype=np.float64)
+    rows, cols = a.shape
+    bw = bh = int(block)
+    bx, by = (cols + bw - 1) // bw, (rows + bh - 1) // bh
+    nblocks, block_bytes = bx * by, bw * bh * 8
+    padded = np.full((by * bh, bx * bw), -9999.0)
+    padded[:rows, :cols] = a
+
+    buf = bytearray(b"EHFA_HEADER_TAG\0" + struct.pack("<I", 20))
+    buf += b"\0" * 18                                        # Ehfa_File, filled in at the end
+
+    def reserve(n):
+        off = len(buf)
+        buf.extend(b"\0" * n)
+        return off
+
+    def entry(name, typ):
+        return dict(off=reserve(128), name=name, type=typ, data=0, size=0, next=0, prev=0, parent=0, child=0)
+
+    root, layer = entry("root", "root"), entry("Layer_1", "Eimg_Layer")
+    dms, elayer, mapinfo = entry("RasterDMS", "Edms_State"), entry("Ehfa_Layer", "Ehfa_Layer"), entry("Map_Info", "Eprj_MapInfo")
+    root["child"] = layer["off"]
+    layer["parent"] = root["off"]; layer["child"] = dms["off"]
+    chain = [dms, elayer, mapinfo]
+    for i, e in enumerate(chain):
+        e["parent"] = layer["off"]
+        e["prev"] = chain[i - 1]["off"] if i else 0
+        e["next"] = chain[i + 1]["off"] if i + 1 < len(chain) else 0
+
+    # the pixel blocks, then the node data that points at them
+    blocks_off = reserve(nblocks * block_bytes)
+    for i in range(nblocks):
+        r, c = divmod(i, bx)
+        buf[blocks_off + i * block_bytes: blocks_off + (i + 1) * block_bytes] = \
+            np.ascontiguousarray(padded[r * bh:(r + 1) * bh, c * bw:(c + 1) * bw]).tobytes()
+
+    layer["data"] = reserve(20); layer["size"] = 20
+    struct.pack_into("<iihhii", buf, layer["data"], cols, rows, 1, 10, bw, bh)       # athematic, f64
+
+    dms["size"] = 14 + 8 + 14 * nblocks + 8 + 4
+    dms["data"] = reserve(dms["size"])
+    struct.pack_into("<iiih", buf, dms["data"], nblocks, bw * bh, nblocks * bw * bh, 0)
+    struct.pack_into("<II", buf, dms["data"] + 14, nblocks, dms["data"] + 22)
+    for i in range(nblocks):
+        struct.pack_into("<hIihh", buf, dms["data"] + 22 + 14 * i, 0, blocks_off + i * block_bytes, block_bytes, 1, 0)
+    struct.pack_into("<III", buf, dms["data"] + 22 + 14 * nblocks, 0, 0, 0)            # empty free list, modTime
+
+    layer_dict = ("{%d:ddata,}RasterDMS,." % (bw * bh)).encode() + b"\0"            # the type of one block: bw*bh doubles
+    layer_dict_off = reserve(len(layer_dict))
+    buf[layer_dict_off:layer_dict_off + len(layer_dict)] = layer_dict
+    elayer["data"] = reserve(6); elayer["size"] = 6
+    struct.pack_into("<hI", buf, elayer["data"], 0, layer_dict_off)
+
+    pro, un = b"Unknown\0", units.encode() + b"\0"
+    mapinfo["size"] = 8 + len(pro) + 3 * 24 + 8 + len(un)
+    d = mapinfo["data"] = reserve(mapinfo["size"])
+    struct.pack_into("<II", buf, d, len(pro), d + 8)
+    buf[d + 8:d + 8 + len(pro)] = pro
+    d2 = d + 8 + len(pro)
+    ulx, uly = upper_left_corner[0] + 0.5 * pixel_size, upper_left_corner[1] - 0.5 * pixel_size
+    struct.pack_into("<IIdd", buf, d2, 1, d2 + 8, ulx, uly)
+    struct.pack_into("<IIdd", buf, d2 + 24, 1, d2 + 32, ulx + (cols - 1) * pixel_size, uly - (rows - 1) * pixel_size)
+    struct.pack_into("<IIdd", buf, d2 + 48, 1, d2 + 56, pixel_size, pixel_size)
+    struct.pack_into("<II", buf, d2 + 72, len(un), d2 + 80)
+    buf[d2 + 80:d2 + 80 + len(un)] = un
+
+    dict_off = reserve(len(_DICTIONARY) + 1)
+    buf[dict_off:dict_off + len(_DICTIONARY)] = _DICTIONARY.encode()
+    for e in (root, layer, dms, elayer, mapinfo):
+        struct.pack_into("<IIIIIi", buf, e["off"], e["next"], e["prev"], e["parent"], e["child"], e["data"], e["size"])
+        buf[e["off"] + 24:e["off"] + 24 + len(e["name"])] = e["name"].encode()
+        buf[e["off"] + 88:e["off"] + 88 + len(e["type"])] = e["type"].encode()
+    struct.pack_into("<iIIhI", buf, 20, 1, 0, root["off"], 128, dict_off)
+    with open(path, "wb") as f:
+        f.write(bytes(buf))
+
+
+def write_raster(path, south_up, resolution, origin=(0.0, 0.0)):
+    """The reference's convention (CRasterDataset.cpp:166-172): `origin` is the bottom-left corner of the domain."""
+    a = np.asarray(south_up, dtype=np.float64)
+    write_hfa(path, a[::-1], (origin[0], origin[1] + resolution * a.shape[0]), resolution)

@@ -199,11 +199,15 @@ class Model:
             return False
         final = self.sim.download()
         out = {}
-        for what, pattern in self.cfg.targets:
+        for k, (what, pattern) in enumerate(self.cfg.targets):
             arr = frontend.derive_output(what, final, self.bed, self.res)
             out[what] = arr
             if pattern and self.cfg.target_dir and self.output_format:
-                fname = os.path.splitext(pattern.replace("%t", str(int(round(self.current_time)))))[0] + self.output_format
+                ext = self.output_format
+                if ext == "xml":             # what the model file asks for: format="HFA" -> Imagine .img, anything else ESRI ASCII
+                    fmt = (getattr(self.cfg, "target_formats", None) or [""] * (k + 1))[k]
+                    ext = ".img" if fmt == "HFA" else ".asc"
+                fname = os.path.splitext(pattern.replace("%t", str(int(round(self.current_time)))))[0] + ext
                 frontend.write_raster(os.path.join(self.cfg.target_dir, fname), arr, self.res)
         self.outputs.append((self.current_time, out))
         self.last_output_time = self.current_time

@@ -465,13 +465,12 @@ def test_cli_runs_the_example(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Simulation complete: 2 output times" in r.stdout and "SIMULATION PROGRESS" in open(log).read()
     files = sorted(os.listdir(os.path.join(str(tmp_path), "output")))
-    assert "depth_30.asc" in files and "depth_60.asc" in files
-    # same rasters as the library call with the same fixed batch
+    assert "depth_30.img" in files and "depth_60.img" in files     # the example asks for format="HFA": Imagine rasters, as GDAL would write
+    # same rasters as the library call with the same fixed batch -- f64 pixels, so bit for bit
     from hipims_mi import frontend
     res = frontend.run_model(make_newcastle(tmp_path / "b", duration=60, frequency=30), batch=50, output_format=None)
-    asc = np.loadtxt(os.path.join(str(tmp_path), "output", "depth_60.asc"), skiprows=6)[::-1]
-    ref = res[-1][1]["depth"]
-    assert np.allclose(asc, ref, rtol=1e-9, atol=1e-12)
+    img, info = frontend.read_raster(os.path.join(str(tmp_path), "output", "depth_60.img"))
+    assert np.array_equal(img, res[-1][1]["depth"]) and info["pixel_size"] == (2.0, 2.0)
 
 
 @pytest.mark.parametrize("mode", MODES)
