@@ -23,11 +23,11 @@ XML = """<?xml version="1.0"?>
           <dataSource type="constant" value="depth" source="0.0" />
           <dataSource type="constant" value="manningCoefficient" source="0.030" />
           <dataSource type="raster" value="structure,dem" source="NewcastleCentreDEM_2m.img" />
-          <dataTarget type="raster" value="depth" target="depth_%t.img" />
-          <dataTarget type="raster" value="velocityX" target="velX_%t.img" />
-          <dataTarget type="raster" value="velocityY" target="velY_%t.img" />
-          <dataTarget type="raster" value="fsl" target="fsl_%t.img" />
-          <dataTarget type="raster" value="maxdepth" target="maxdepth_%t.img" />
+          <dataTarget type="raster" value="depth" format="HFA" target="depth_%t.img" />
+          <dataTarget type="raster" value="velocityX" format="HFA" target="velX_%t.img" />
+          <dataTarget type="raster" value="velocityY" format="HFA" target="velY_%t.img" />
+          <dataTarget type="raster" value="fsl" format="HFA" target="fsl_%t.img" />
+          <dataTarget type="raster" value="maxdepth" format="HFA" target="maxdepth_%t.img" />
         </data>
         <scheme name="{scheme}">
           <parameter name="courantNumber" value="0.50" />
