@@ -66,7 +66,8 @@ void CSchemeMI::setStrip(int rank, int world, const void* commId, long globalRow
 {
 	bStrip = true; iStripRank = rank; iStripWorld = world; lGlobalRows = globalRows; lRowOffset = rowOffset;
 	std::memcpy(cCommId, commId, HP_COMM_ID_BYTES);
-	bAutomaticQueue = false;                                          // batch sizes must agree across the ranks
+	// batch sizes must agree across the ranks: the automatic queue of a strip uses the reference's several-domains
+	// formula (runSimulation below), which is made of simulated quantities only
 }
 
 // prepare1OExecDimensions / Constants / Code / Memory / Kernels / Boundaries collapse into one descriptor
@@ -141,9 +142,15 @@ void CSchemeMI::runSimulation(double dTarget, double dRealTime)
 	if (dCurrentTime > dTarget + 1E-5) return;                        // :1389-1407 (warning in the reference)
 
 	// batch size: aim for about a second of work, no silly jumps, never beyond the rollback limit (:1420-1448)
-	if (bAutomaticQueue && !bStrip && dRealTime > 1E-5 && ucSyncMethod != syncMethod::kSyncTimestep) {
+	if (bAutomaticQueue && dRealTime > 1E-5 && ucSyncMethod != syncMethod::kSyncTimestep) {
 		const double dBatchDuration = dRealTime - dBatchStartedTime;
 		const unsigned int uiOld = uiQueueAdditionSize;
+		if (bStrip) {
+			// getDomainCount() > 1 (:1428-1429): the iterations left to the target at the batch's mean timestep, plus one.
+			// Time, target, timestep sum and iteration count are the same numbers on every rank, so is the result.
+			if (uiBatchSuccessful > 0 && dBatchTimesteps > 0.0)
+				uiQueueAdditionSize = (unsigned int)((dTargetTime - dCurrentTime) / (dBatchTimesteps / (double)uiBatchSuccessful) + 1.0);
+		} else
 		uiQueueAdditionSize = std::max(1u, std::min(uiBatchRate * 3,
 			(unsigned int)std::ceil(1.0 / (dBatchDuration / (double)uiQueueAdditionSize))));
 		if (uiQueueAdditionSize > uiOld * 2 && uiQueueAdditionSize > 40)

@@ -124,3 +124,24 @@ def test_cpp_host_strip_mode_matches_the_single_domain(scheme_name, world):
         assert float(la[0]) == float(lb[0]) and int(la[1]) == int(lb[1])              # time, successful iterations
         assert abs(float(la[2]) - float(lb[3])) <= 1e-11 * float(lb[3])                 # volume (summation order differs)
         assert abs(float(la[3]) - float(lb[4])) <= 1e-12 * abs(float(lb[4]))            # checksum of Z
+
+
+def test_cpp_host_strip_mode_automatic_queue_is_rank_consistent():
+    """The automatic batch size of a strip is the reference's several-domains formula (CSchemeGodunov.cpp:1428-1429: the
+    iterations left to the target at the batch's mean timestep) -- simulated quantities only, so every rank queues the same
+    batches (a disagreement would hang the collectives: the run must simply finish) and the result does not depend on the
+    number of strips."""
+    exe = os.path.join(PKG, "lib", "run_strips")
+    fake = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", fake,
+                               os.path.join(os.path.dirname(fake), "fake_rccl.cpp")])
+    outs = []
+    for world in (2, 3):
+        r = subprocess.run([exe, fake, str(world), "320", "161", "1.5", "0.5", "godunov", "0"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([l.split() for l in r.stdout.strip().splitlines()])
+    assert len(outs[0]) == len(outs[1]) == 3
+    for la, lb in zip(*outs):
+        assert float(la[0]) == float(lb[0]) and int(la[1]) == int(lb[1]) and int(la[1]) > 0
+        assert abs(float(la[3]) - float(lb[3])) <= 1e-12 * abs(float(lb[3]))
