@@ -157,7 +157,8 @@ def test_s_rain_8192_fp32_full_size_properties():
     got = depth[inner].sum()
     record("s_rain_8192_fp32", iterations=its, t=sc["time"], volume_rel_err=abs(got - expected) / expected,
            mean_depth_mm=1e3 * got / (n - 2) ** 2)
-    assert abs(got - expected) / expected < 2e-2, (got, expected)
+    # fp32 accumulation of 0.4 mm films on a 10 m level costs 2.3e-3; one missed gate opening of the ~22 would be 4.5e-2
+    assert abs(got - expected) / expected < 5e-3, (got, expected)
     dom.close()
 
 
