@@ -109,6 +109,13 @@ struct hp_domain {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;   // pool, created by hp_kernel_timing
 	size_t           timing_used = 0;
 	long             own_lo = 0, own_hi = 0;          // rows this rank owns (CFL reduction range)
+	// ghost rows of a strip: `ghost_rows` stored per interior side (g or 2g, g = the scheme's stencil reach), of which
+	// `ghost_valid` currently hold their owners' values; an iteration consumes g of them, the exchange refills them all
+	long             ghost_rows = 0, ghost_valid = 0, saved_ghost_valid = 0;
+	bool             split_now = false;               // this iteration is followed by an exchange: halo part on its own stream
+	// what the ranks told each other at the start of the batch (hp_strip_step_batch): which of them price a new maximum on
+	// the iterations that the ping-pong phase alone would not make them price
+	bool             strip_any_bdy = false, strip_any_full = false;
 	// halo overlap (strip decomposition): the row segments next to the ghost rows run on their own stream so the
 	// neighbours' halo transfer can start while the interior segments are still being computed
 	bool             halo_overlap = false;
@@ -129,6 +136,9 @@ struct hp_domain {
 };
 
 namespace {
+
+// stencil reach of the scheme = ghost rows one iteration consumes
+inline long strip_ghosts(const hp_domain* d) { return d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK ? 2 : 1; }
 
 template <typename T> Params<T> make_params(const hp_domain* d)
 {
@@ -241,10 +251,12 @@ struct RowRange { long lo, hi; };
 // TileMap of one launch (see hp_kernels.hpp): 8 XCD bands over [lo, hi), tall tiles first and optionally short tiles
 // for the last `tail_pct` percent of each band; or, for the halo part, the two blocks of `halo` rows as two bands.
 inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rseg, int rseg_tail, int tail_pct,
-                          TileMap& tm, unsigned& blocks, int rseg_tall = 16)
+                          TileMap& tm, unsigned& blocks, int rseg_tall = 16, long need = 0, long price_lo = 0, long price_hi = 0x7fffffffL)
 {
 	static const long halo_env = std::getenv("HP_HALO_ROWS") ? std::atol(std::getenv("HP_HALO_ROWS")) : 0;
-	const long halo = halo_env >= g ? halo_env : (rseg > g ? rseg : g);
+	if (need < g) need = g;                                             // rows at each end that a strip neighbour is sent
+	const long halo = halo_env >= need ? halo_env : (rseg > need ? rseg : need);
+	tm.price_lo = (int)price_lo; tm.price_hi = (int)(price_hi < 0x7fffffffL ? price_hi : 0x7fffffffL);
 	const bool can_split = hi - lo > 2 * halo;
 	tm.nstrips = nstrips;
 	tm.groups = (nstrips + 3) / 4;
@@ -285,13 +297,28 @@ inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rs
 	return true;
 }
 
+// Rows one flux launch updates: everything between the never-written edge ring / the outermost ghost rows.  A strip with
+// two reaches of ghost rows (ghost_rows = 2g) also updates, on the iteration that follows an exchange, the g ghost rows
+// next to its owned rows -- redundantly with their owner, from the same values, to the same bits -- and on the next
+// iteration, which finds only those still valid, its owned rows alone.
+inline void launch_rows(const hp_domain* d, long g, long& lo, long& hi)
+{
+	const bool south = d->desc.row_offset > 0, north = d->desc.row_offset + d->desc.rows < d->desc.global_rows;
+	const long keep = d->ghost_rows - (d->ghost_valid - g);             // ghost rows at each interior side NOT updated now
+	lo = south ? keep : g;
+	hi = d->desc.rows - (north ? keep : g);
+}
+
 template <typename T, bool STRICT, int CFL_MODE>
 int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
 {
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
-	if (!make_tile_map(2, p.rows - 2, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks))
+	long lo, hi;
+	launch_rows(d, 2, lo, hi);
+	if (!make_tile_map(lo, hi, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks,
+	                   16, d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
 	if (d->manning_uniform)
 		hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, true, T>), dim3(blocks), dim3(256), 0, stream, p,
@@ -311,7 +338,10 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
-	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg))
+	long lo, hi;
+	launch_rows(d, 1, lo, hi);
+	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
+	                   d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
 	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
 	if (d->fusable)
@@ -334,7 +364,10 @@ int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, i
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
-	if (!make_tile_map(1, p.rows - 1, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg))
+	long lo, hi;
+	launch_rows(d, 1, lo, hi);
+	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
+	                   d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
 	hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
@@ -417,7 +450,7 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		e1 = d->timing_events[d->timing_used].second;
 		HIP_TRY(hipEventRecord(e0, d->stream));
 	}
-	if (d->halo_overlap) {
+	if (d->halo_overlap && d->split_now) {
 		// fork: everything queued so far (previous advance, boundaries, ring pricing) happens-before the halo
 		// segments; they run on their own stream, next to the interior segments on the domain's stream
 		// (when nothing was queued since the previous advance_time, that kernel's own completion event serves:
@@ -454,7 +487,7 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 template <typename T> int step_end_impl(hp_domain* d)
 {
 	const Params<T> p = make_params<T>(d);
-	if (d->halo_overlap) {
+	if (d->halo_overlap) {                    // (also after an unsplit iteration: the NEXT one may be split and fork from here)
 		hipExtLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, nullptr, d->ev_fork, 0, p,
 		                      (Scalars<T>*)d->scalars, (T*)d->cfl_slot, d->adv_fresh);
 		d->fork_is_advance = true;                                        // cleared by anything else queued on the stream
@@ -646,9 +679,17 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		delete d;
 		return fail(HP_ERR_INVALID, "strip does not fit the global grid");
 	}
-	const long g = (desc->scheme == HP_SCHEME_MUSCL_HANCOCK) ? 2 : 1;     // ghost rows per side
-	d->own_lo = (d->desc.row_offset > 0) ? g : 0;
-	d->own_hi = d->desc.rows - ((d->desc.row_offset + d->desc.rows < d->desc.global_rows) ? g : 0);
+	const long g = (desc->scheme == HP_SCHEME_MUSCL_HANCOCK) ? 2 : 1;     // stencil reach = ghost rows per exchange
+	d->ghost_rows = desc->ghost_rows > 0 ? desc->ghost_rows : g;
+	if (d->ghost_rows != g && d->ghost_rows != 2 * g) {
+		delete d;
+		return fail(HP_ERR_INVALID, "ghost_rows must be 0, the scheme's stencil reach or twice that");
+	}
+	d->ghost_valid = d->ghost_rows;
+	d->split_now = true;                                                  // (hp_step_begin: every iteration is followed by an exchange)
+	d->own_lo = (d->desc.row_offset > 0) ? d->ghost_rows : 0;
+	d->own_hi = d->desc.rows - ((d->desc.row_offset + d->desc.rows < d->desc.global_rows) ? d->ghost_rows : 0);
+	if (d->own_hi - d->own_lo < 1) { delete d; return fail(HP_ERR_INVALID, "strip has no owned rows"); }
 	d->cells = (size_t)desc->cols * (size_t)desc->rows;
 	d->esize = (size_t)desc->precision;
 	// Tile height: a wavefront marches its tile's rows one after the other, so a grid that yields few tiles is bound
@@ -793,6 +834,7 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 		d->use_alt = 0;                                                   // :1075
 		d->need_full_reduce = true;
 		d->edge_dirty = true;
+		d->ghost_valid = d->ghost_rows;                                   // the host uploads strips with all their ghost rows
 		HIP_TRY(hipMemsetAsync((char*)d->cfl_slot + (size_t)SLOT_BDY * d->esize, 0, d->esize, d->stream));
 		return HP_OK;
 	case HP_ARRAY_BED:
@@ -842,6 +884,7 @@ int hp_state_save(hp_domain_t* d)
 	d->saved_full_reduce = d->need_full_reduce;
 	d->saved_edge_dirty = d->edge_dirty;
 	d->saved_use_alt = d->use_alt;
+	d->saved_ghost_valid = d->ghost_valid;
 	d->saved_valid = true;
 	return HP_OK;
 }
@@ -861,6 +904,7 @@ int hp_state_restore(hp_domain_t* d)
 	HIP_TRY(hipMemcpyAsync(d->scalars, d->saved_scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
 	d->use_alt = d->saved_use_alt;
+	d->ghost_valid = d->saved_ghost_valid;
 	// a bed or state upload between save and restore has left its own marks: they stay
 	d->need_full_reduce = d->need_full_reduce || d->saved_full_reduce;
 	d->edge_dirty = d->edge_dirty || d->saved_edge_dirty;
@@ -1060,6 +1104,10 @@ int hp_step_begin(hp_domain_t* d)
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	if (d->in_step) return fail(HP_ERR_STATE, "hp_step_begin called twice");
+	if (d->ghost_rows != strip_ghosts(d))
+		return fail(HP_ERR_UNSUPPORTED, "the split step exchanges after every iteration: it needs ghost_rows = the stencil reach "
+		                                "(two reaches of ghost rows are hp_strip_step_batch's)");
+	d->split_now = true;
 	d->fork_is_advance = fork_ready;
 	if ((rc = dispatch_begin(d)) != HP_OK) return rc;
 	d->in_step = true;
@@ -1194,30 +1242,29 @@ int rccl_ready()
 			return fail(HP_ERR_HIP, std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error")); \
 	} while (0)
 
-// ghost rows per interior side
-inline long strip_ghosts(const hp_domain* d) { return d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK ? 2 : 1; }
 
-// Ghost-row exchange of the iteration in flight + the all-reduce of the wave-speed maximum, queued behind the flux
-// launches of hp_step_begin (CDomainLink::pullFromBuffer / pushToBuffer + MPI_Allreduce(MIN), CMPIManager.cpp:852-861).
-int strip_exchange(hp_domain* d, bool reduce)
+// Ghost-row exchange of the iteration in flight, queued behind the flux launches of hp_step_begin: the first / last
+// `ghost_rows` owned rows of the new state go to the strip neighbours' ghost rows (CDomainLink::pullFromBuffer /
+// pushToBuffer, CDomainLink.cpp:168-270; CMPIManager's block exchange, CMPIManager.cpp:555-709).
+int strip_halo_exchange(hp_domain* d)
 {
-	const long g = strip_ghosts(d), rows = d->desc.rows;
-	const size_t row_elems = (size_t)d->desc.cols * 4, count = (size_t)g * row_elems;
+	const long G = d->ghost_rows, rows = d->desc.rows;
+	const size_t row_elems = (size_t)d->desc.cols * 4, count = (size_t)G * row_elems;
 	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
 	char* state = (char*)d->state[d->use_alt ^ 1];                    // the buffer the iteration in flight writes
 	const size_t row_bytes = row_elems * d->esize;
 	const bool south = d->comm_rank > 0, north = d->comm_rank < d->comm_world - 1;
 	// the rows the neighbours need come from the halo part of the step: the transfer is ordered after that stream only
-	hipStream_t xs = d->halo_overlap ? d->stream_halo : d->stream;
+	hipStream_t xs = (d->halo_overlap && d->split_now) ? d->stream_halo : d->stream;
 	if (south || north) {
 		RCCL_TRY(g_rccl.GroupStart());
 		if (south) {
-			RCCL_TRY(g_rccl.Send(state + (size_t)g * row_bytes, count, type, d->comm_rank - 1, d->comm, xs));            // my first owned rows
+			RCCL_TRY(g_rccl.Send(state + (size_t)G * row_bytes, count, type, d->comm_rank - 1, d->comm, xs));            // my first owned rows
 			RCCL_TRY(g_rccl.Recv(state, count, type, d->comm_rank - 1, d->comm, xs));                                     // into my south ghost rows
 		}
 		if (north) {
-			RCCL_TRY(g_rccl.Send(state + (size_t)(rows - 2 * g) * row_bytes, count, type, d->comm_rank + 1, d->comm, xs));  // my last owned rows
-			RCCL_TRY(g_rccl.Recv(state + (size_t)(rows - g) * row_bytes, count, type, d->comm_rank + 1, d->comm, xs));       // into my north ghost rows
+			RCCL_TRY(g_rccl.Send(state + (size_t)(rows - 2 * G) * row_bytes, count, type, d->comm_rank + 1, d->comm, xs));  // my last owned rows
+			RCCL_TRY(g_rccl.Recv(state + (size_t)(rows - G) * row_bytes, count, type, d->comm_rank + 1, d->comm, xs));       // into my north ghost rows
 		}
 		RCCL_TRY(g_rccl.GroupEnd());
 		if (xs != d->stream) {
@@ -1225,10 +1272,72 @@ int strip_exchange(hp_domain* d, bool reduce)
 			HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_xchg, 0));      // hp_step_end (and the next iteration) need the rows
 		}
 	}
-	// the maximum is new only when the reduction priced a buffer that changed (hp_step_needs_reduction); the decision
-	// is the same on every rank (same iteration parity), so either all ranks enter the collective or none does
-	if (reduce && d->comm_world > 1)
-		RCCL_TRY(g_rccl.AllReduce(d->cfl_slot, d->cfl_slot, 1, type, ncclMax, d->comm, d->stream));
+	return HP_OK;
+}
+
+template <typename T> __global__ void copy_scalar(T* to, const T* from) { *to = *from; }
+
+// The wave-speed maximum over all strips (MPI_Allreduce(MIN dt), CMPIManager.cpp:852-861).  Whether an iteration carries a
+// NEW maximum is decided from what is the same on every rank -- the scheme, quirk Q1 and the ping-pong phase, and what the
+// ranks told each other at the start of the batch (does ANY of them have boundaries, or a stale maximum after an upload) --
+// so either every rank enters the collective or none does, even when the host has given a boundary to one strip only.  A
+// rank whose own buffer was not priced this iteration contributes the local maximum it remembers.
+int strip_allreduce_max(hp_domain* d, bool first_of_batch)
+{
+	if (!d->desc.dynamic_dt || d->comm_world <= 1) return HP_OK;
+	const bool q1 = (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0, muscl = d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK;
+	const bool basic = d->desc.kernel == HP_KERNEL_BASIC && d->desc.scheme == HP_SCHEME_GODUNOV;
+	const bool dst_is_primary = d->use_alt == 1;
+	const bool everyone = muscl || !q1 || dst_is_primary || basic || d->strip_any_bdy || (first_of_batch && d->strip_any_full);
+	if (!everyone) {
+		if (d->adv_fresh) return fail(HP_ERR_STATE, "a strip priced a new maximum on an iteration the other ranks do not reduce "
+		                                            "(boundaries or uploads changed inside a batch?)");
+		return HP_OK;
+	}
+	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
+	if (!d->adv_fresh) {                                               // nothing new here: the remembered local maximum stands in
+		if (d->desc.precision == 8) hipLaunchKernelGGL(copy_scalar<double>, dim3(1), dim3(1), 0, d->stream, (double*)d->cfl_slot, (const double*)d->cfl_slot + SLOT_LOCAL);
+		else                        hipLaunchKernelGGL(copy_scalar<float>, dim3(1), dim3(1), 0, d->stream, (float*)d->cfl_slot, (const float*)d->cfl_slot + SLOT_LOCAL);
+		HIP_TRY(hipGetLastError());
+	}
+	RCCL_TRY(g_rccl.AllReduce(d->cfl_slot, (char*)d->cfl_slot + (size_t)SLOT_GLOBAL * d->esize, 1, type, ncclMax, d->comm, d->stream));
+	d->adv_fresh = 3;                                                  // advance_time: take the maximum from SLOT_GLOBAL
+	return HP_OK;
+}
+
+// Start of a batch: the ranks compare notes (one 8-element all-reduce and a read-back).  Boundaries and uploads are host
+// calls, which nothing forces to be the same on every rank; the ping-pong phase and the ghost-row state must be.
+int strip_handshake(hp_domain* d)
+{
+	d->strip_any_bdy = !d->bdy.empty() && d->desc.scheme != HP_SCHEME_MUSCL_HANCOCK;
+	d->strip_any_full = d->need_full_reduce;
+	if (d->comm_world <= 1) return HP_OK;
+	const double mine[8] = {d->strip_any_bdy ? 1.0 : 0.0, d->strip_any_full ? 1.0 : 0.0, (double)d->use_alt, -(double)d->use_alt,
+	                        (double)d->ghost_valid, -(double)d->ghost_valid, (double)d->ghost_rows, -(double)d->ghost_rows};
+	double all[8];
+	char* slot = (char*)d->cfl_slot + (size_t)SLOT_HANDSHAKE * d->esize;
+	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
+	if (d->desc.precision == 8) {
+		HIP_TRY(hipMemcpyAsync(slot, mine, sizeof mine, hipMemcpyHostToDevice, d->stream));
+	} else {
+		float f[8]; for (int i = 0; i < 8; ++i) f[i] = (float)mine[i];
+		HIP_TRY(hipMemcpyAsync(slot, f, sizeof f, hipMemcpyHostToDevice, d->stream));
+		HIP_TRY(hipStreamSynchronize(d->stream));                       // `f` leaves scope
+	}
+	RCCL_TRY(g_rccl.AllReduce(slot, slot + 8 * d->esize, 8, type, ncclMax, d->comm, d->stream));
+	if (d->desc.precision == 8) {
+		HIP_TRY(hipMemcpyAsync(all, slot + 8 * d->esize, sizeof all, hipMemcpyDeviceToHost, d->stream));
+		HIP_TRY(hipStreamSynchronize(d->stream));
+	} else {
+		float f[8];
+		HIP_TRY(hipMemcpyAsync(f, slot + 8 * d->esize, sizeof f, hipMemcpyDeviceToHost, d->stream));
+		HIP_TRY(hipStreamSynchronize(d->stream));
+		for (int i = 0; i < 8; ++i) all[i] = f[i];
+	}
+	if (all[2] != -all[3]) return fail(HP_ERR_STATE, "the strips disagree on the ping-pong phase (different iteration counts?)");
+	if (all[4] != -all[5] || all[6] != -all[7]) return fail(HP_ERR_STATE, "the strips disagree on their ghost rows");
+	d->strip_any_bdy = all[0] > 0.0;
+	d->strip_any_full = all[1] > 0.0;
 	return HP_OK;
 }
 } // namespace
@@ -1274,6 +1383,7 @@ int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out)
 	if (!d) return HP_OK;                                                // library path only
 	out->comm_rank = d->comm_rank;
 	out->halo_overlap = d->halo_overlap ? 1 : 0;
+	out->ghost_rows = (int32_t)d->ghost_rows;
 	if (d->comm && g_rccl.CommCount) {
 		int n = -1;
 		RCCL_TRY(g_rccl.CommCount(d->comm, &n));
@@ -1334,11 +1444,26 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 	if (rc != HP_OK) return rc;
 	if (!d->comm) return fail(HP_ERR_STATE, "hp_strip_step_batch without hp_strip_comm_init");
 	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
-	d->fork_is_advance = fork_ready;
+	if (n_iterations == 0) return HP_OK;
+	const long g = strip_ghosts(d);
+	if ((rc = strip_handshake(d)) != HP_OK) return rc;
+	d->fork_is_advance = fork_ready && d->comm_world <= 1;            // (the handshake queued work behind the last advance_time)
 	for (uint32_t i = 0; i < n_iterations; ++i) {
 		d->fuse_next = i + 1 < n_iterations;          // as hp_step_batch: the rows sent to the neighbours carry the rain too
+		if (d->ghost_valid < g) return fail(HP_ERR_STATE, "ghost rows exhausted");
+		// an iteration consumes g layers of ghost rows; when fewer than g are left afterwards, the new state's rows are
+		// exchanged (ghost_rows = g: every iteration; 2g: every second one, and only those iterations are split into a
+		// halo and an interior launch)
+		const bool exchange = d->ghost_valid - g < g;
+		d->split_now = exchange;
 		if ((rc = dispatch_begin(d)) != HP_OK) return rc;
-		if ((rc = strip_exchange(d, d->adv_fresh != 0)) != HP_OK) return rc;
+		if (exchange) {
+			if ((rc = strip_halo_exchange(d)) != HP_OK) return rc;
+			d->ghost_valid = d->ghost_rows;
+		} else {
+			d->ghost_valid -= g;
+		}
+		if ((rc = strip_allreduce_max(d, i == 0)) != HP_OK) return rc;
 		if ((rc = dispatch_end(d)) != HP_OK) return rc;
 		// the exchange sits between advance_time and the next flux launch on the stream graph: its event, not
 		// advance_time's, is what the next halo launch may fork from only if nothing else was queued -- keep it simple
@@ -1346,6 +1471,7 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 		if (!d->halo_overlap) d->fork_is_advance = false;
 	}
 	d->fuse_next = 0;
+	d->split_now = true;
 	return HP_OK;
 }
 
@@ -1363,14 +1489,15 @@ int hp_strip_update_timestep(hp_domain_t* d)
 	} else {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
 	}
-	if (d->desc.dynamic_dt && d->comm_world > 1)
-		RCCL_TRY(g_rccl.AllReduce(d->cfl_slot, d->cfl_slot, 1, type, ncclMax, d->comm, d->stream));
+	const bool reduced = d->desc.dynamic_dt && d->comm_world > 1;
+	if (reduced)
+		RCCL_TRY(g_rccl.AllReduce(d->cfl_slot, (char*)d->cfl_slot + (size_t)SLOT_GLOBAL * d->esize, 1, type, ncclMax, d->comm, d->stream));
 	if (d->desc.precision == 8)
 		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
-		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, 1);
+		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, reduced ? 3 : 1);
 	else
 		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
-		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, 1);
+		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, reduced ? 3 : 1);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }

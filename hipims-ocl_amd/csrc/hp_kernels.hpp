@@ -68,9 +68,13 @@ __device__ __forceinline__ void advance_body(const Params<T>& p, Scalars<T>* sc,
 	const T DT_MIN = T(1E-10), DT_MAX = T(15.0), HYDRO = T(1.0);                 // CLDynamicTimestep.clh:24-29
 	// slot[0] is only ever touched by agent-scope atomics (performed at the memory side, so no XCD's L2 holds a
 	// stale copy); the remembered maximum lives one cache line further (SLOT_SAVED)
+	// fresh: bit 0 = this iteration priced a buffer anew (slot[0] holds this rank's maximum); bit 1 = the maximum over all
+	// strips stands in slot[SLOT_GLOBAL] (hp_strip_step_batch's all-reduce writes it there, next to the local one)
 	T vmax;
 	if (fresh) {
 		vmax = atomic_exchange_zero(slot);
+		slot[SLOT_LOCAL] = vmax;
+		if (fresh & 2) vmax = slot[SLOT_GLOBAL];
 		slot[SLOT_SAVED] = vmax;
 	} else {
 		vmax = slot[SLOT_SAVED];
@@ -190,14 +194,18 @@ __device__ __forceinline__ float buf_load_scalar(__amdgpu_buffer_rsrc_t r, const
 {
 	return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
-// Store-data hazard.  On gfx950 a 16-byte buffer store reads its data VGPRs over several cycles AFTER it has issued;
-// a VALU instruction that overwrites one of them in the very next slot corrupts what lanes 12-15 of every 16-lane row
-// store (seen in round 2 as depth instead of level in z, fp32, 4096^2 and up, when `h = z - zb` of the CFL epilogue
-// reused z's register directly behind the store: the compiler's hazard recogniser exempts stores whose soffset is an
-// SGPR, as ours is).  The data registers are therefore kept alive through two wait states behind the store.
-__device__ __forceinline__ void store_data_fence(const hp_u32x4& a)
+// Store hazard.  On gfx950 a 16-byte buffer store reads its VGPR operands -- the data AND the per-lane offset -- over
+// several cycles AFTER it has issued; a VALU instruction that overwrites one of them in the next slots changes what lanes
+// 12-15 of every 16-lane row store, or where.  Seen in round 2 as depth instead of level in z (fp32, 4096^2 and up: `h = z -
+// zb` of the CFL epilogue reused z's register directly behind the store) and in round 3 as cells that were not stored at
+// all (strips with rain, fp32: the compiler had moved a `v_mov` that recycled the OFFSET register between the store and the
+// fence that then only covered the data).  The compiler's hazard recogniser exempts stores whose soffset is an SGPR, as
+// ours is.  All operands of the store are therefore kept alive through the wait states behind it: nothing may overwrite
+// them before this fence, whatever else gets scheduled in between (four wait states: round 2's two were found by trial, and
+// the cost is two cycles per row).
+__device__ __forceinline__ void store_fence(const hp_u32x4& a, const unsigned voff, const unsigned soff)
 {
-	asm volatile("s_nop 1" : : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w) : "memory");
+	asm volatile("s_nop 3" : : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(voff), "s"(soff) : "memory");
 }
 
 // `voff` selects per lane between the cell's offset and HP_OOB (dropped by the range check); it is pinned in a VGPR so
@@ -213,8 +221,8 @@ __device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgp
 	b.z = (unsigned)__double2loint(s.qy); b.w = (unsigned)__double2hiint(s.qy);
 	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, 0);
 	__builtin_amdgcn_raw_buffer_store_b128(b, r, (int)voff + 16, (int)soff, 0);
-	store_data_fence(a);
-	store_data_fence(b);
+	store_fence(a, voff, soff);
+	store_fence(b, voff, soff);
 }
 __device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu_buffer_rsrc_t r, unsigned voff, const unsigned soff)
 {
@@ -222,7 +230,7 @@ __device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu
 	hp_u32x4 a;
 	a.x = __float_as_uint(s.z); a.y = __float_as_uint(s.zmax); a.z = __float_as_uint(s.qx); a.w = __float_as_uint(s.qy);
 	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, 0);
-	store_data_fence(a);
+	store_fence(a, voff, soff);
 }
 
 constexpr int MARCH_COLS = 62;          // updated columns per wavefront (lanes 1..62)
@@ -276,6 +284,9 @@ struct TileMap {
 	int  band_rows;              // rows per band
 	int  rseg, nbig;             // tall segments per band
 	int  rseg_tail, ntail;       // short segments per band (after the tall ones)
+	int  price_lo, price_hi;     // rows whose cells the fused CFL epilogue prices: the rows this rank OWNS (a strip with two
+	                             // reaches of ghost rows also updates rows it does not own, hp_engine.hip: strip loop); 32-bit so
+	                             // that the per-row test is two scalar compares
 };
 
 // rows [y0, y1) and the column strip of this wave; false if the block / wave has nothing to do (wave-uniform)
@@ -567,7 +578,9 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		State4<T> stored = out;
 		if (FUSED && fuse) stored = apply_fused(out, rc.zb, y);
 		buf_store_state(stored, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
-		if (CFL_MODE == 1) {
+		const bool priced = (int)y >= tm.price_lo && (int)y < tm.price_hi;       // wave-uniform
+		if (!priced) {
+		} else if (CFL_MODE == 1) {
 			if (write) {
 				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
 				if (s > vmax) vmax = s;
@@ -603,7 +616,8 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			fS = face_dry_for_right<AXIS_Y, STRICT>(sC, sN, vs);
 			// (FUSED: the only cells this loop stores are nulls, which no boundary kernel touches)
 			buf_store_state(rc.c, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
-			if (CFL_MODE == 1) {
+			if (!((int)y >= tm.price_lo && (int)y < tm.price_hi)) {
+			} else if (CFL_MODE == 1) {
 				if (write) {
 					const T s = cfl_speed<STRICT>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
 					if (s > vmax) vmax = s;
@@ -633,7 +647,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 				const size_t id = (size_t)y * p.cols + xc;
 				const State4<T> c = dst[id];
 				const T zb = bed[id];
-				if (CFL_MODE == 1) {
+				if (CFL_MODE == 1 && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 					const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, zb, p.qs);
 					if (s > vmax) vmax = s;
 				}
@@ -864,7 +878,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 				// (the same state, by its neighbourhood test) has already put that wave speed into vmax, pricing it again
 				// cannot change the maximum
 				skip_cfl = inertD || still_priced;
-				still_priced = inertS && (still_priced || __any(out_x && out.zmax > T(-9999.0)));
+				still_priced = inertS && (still_priced || ((int)y >= tm.price_lo && (int)y < tm.price_hi && __any(out_x && out.zmax > T(-9999.0))));
 			} else {
 			still_priced = false;
 			if (!fS_ok) {                                   // the row below was a still row: its state is this row's state
@@ -900,7 +914,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		}
 
 		buf_store_state(out, srd_dst, out_x ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);
-		if (CFL_MODE == 1 && !skip_cfl && out_x) {
+		if (CFL_MODE == 1 && !skip_cfl && out_x && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, zb_c, p.qs);
 			if (s > vmax) vmax = s;
 		}
@@ -1023,7 +1037,8 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 			out = upd;
 		}
 		buf_store_state(out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
-		if (CFL_MODE == 1) {
+		if (!((int)y >= tm.price_lo && (int)y < tm.price_hi)) {
+		} else if (CFL_MODE == 1) {
 			if (write) {
 				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs, simplified);
 				if (s > vmax) vmax = s;
@@ -1047,7 +1062,7 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 
 	if (CFL_MODE == 1 && __any(stale_rows != 0)) {
 		for (long yy = y0; yy < y1; ++yy) {
-			if ((stale_rows >> (unsigned)(yy - y0)) & 1ull) {
+			if (((stale_rows >> (unsigned)(yy - y0)) & 1ull) && (int)yy >= tm.price_lo && (int)yy < tm.price_hi) {
 				const size_t id = (size_t)yy * p.cols + xc;
 				const State4<T> c = dst[id];
 				const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs, simplified);

@@ -796,6 +796,9 @@ __device__ __forceinline__ void atomic_max_nonneg(float* slot, float v)
 
 // layout of the CFL slot block (elements of T): [0] running max | [SLOT_SAVED] last max used | [SLOT_EDGE..+1] ring maxima
 constexpr int SLOT_SAVED = 32, SLOT_EDGE = 64;          // separate 256-B apart so line [0] only ever sees atomics
+// strips: this rank's own last maximum (what it contributes when its buffer was not priced anew), the all-reduced maximum
+// (the collective writes it next to, not over, the local one), and the batch-start handshake's 2 x 8 elements
+constexpr int SLOT_LOCAL = 33, SLOT_GLOBAL = 34, SLOT_HANDSHAKE = 112;
 
 __device__ __forceinline__ double atomic_exchange_zero(double* slot)
 {

@@ -72,12 +72,12 @@ class DomainDesc(C.Structure):
                 ("dry_threshold", C.c_double), ("friction", C.c_int32), ("dynamic_dt", C.c_int32),
                 ("dt_fixed", C.c_double), ("dt_initial", C.c_double), ("t_end", C.c_double),
                 ("quirks", C.c_uint32), ("math_mode", C.c_int32), ("kernel", C.c_int32),
-                ("global_rows", C.c_int64), ("row_offset", C.c_int64)]
+                ("global_rows", C.c_int64), ("row_offset", C.c_int64), ("ghost_rows", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class StripInfo(C.Structure):
     _fields_ = [("library", C.c_char * 256), ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32),
-                ("halo_overlap", C.c_int32), ("reserved", C.c_int32)]
+                ("halo_overlap", C.c_int32), ("ghost_rows", C.c_int32)]
 
 
 class ScalarsOut(C.Structure):
@@ -225,7 +225,7 @@ class Domain:
     def __init__(self, cols, rows, dx=1.0, scheme=SCHEME_GODUNOV, precision="f64", dry_threshold=1e-10,
                  courant=0.5, t_end=1e30, dynamic_dt=True, dt_fixed=0.001, dt_initial=0.001, friction=True,
                  quirks=QUIRKS_REFERENCE, math_mode=MATH_FAST, kernel=KERNEL_AUTO, device=0,
-                 global_rows=0, row_offset=0):
+                 global_rows=0, row_offset=0, ghost_rows=0):
         self.lib = load_library()
         self.cols, self.rows = int(cols), int(rows)
         self.precision = precision
@@ -241,6 +241,7 @@ class Domain:
         desc.dt_fixed, desc.dt_initial, desc.t_end = dt_fixed, dt_initial, t_end
         desc.quirks, desc.math_mode, desc.kernel = quirks, math_mode, kernel
         desc.global_rows, desc.row_offset = global_rows, row_offset
+        desc.ghost_rows = ghost_rows
         self.desc = desc
         self.h = C.c_void_p()
         _check(self.lib, self.lib.hp_domain_create(C.byref(desc), C.byref(self.h)), "hp_domain_create")
@@ -373,7 +374,7 @@ class Domain:
         info = StripInfo()
         _check(self.lib, self.lib.hp_strip_info(self.h, C.byref(info)), "hp_strip_info")
         return dict(library=info.library.decode(errors="replace"), comm_ranks=info.comm_ranks, comm_rank=info.comm_rank,
-                    halo_overlap=bool(info.halo_overlap))
+                    halo_overlap=bool(info.halo_overlap), ghost_rows=info.ghost_rows)
 
     def strip_comm_destroy(self):
         _check(self.lib, self.lib.hp_strip_comm_destroy(self.h), "hp_strip_comm_destroy")

@@ -42,7 +42,8 @@ def ghost_rows(scheme) -> int:
 
 
 def partition(global_rows: int, world: int, g: int):
-    """Rows owned by each rank and the rows it stores: [(own_lo, own_hi, local_lo, local_hi)] (global indices)."""
+    """Rows owned by each rank and the rows it stores: [(own_lo, own_hi, local_lo, local_hi)] (global indices).
+    `g` = ghost rows stored per interior side (the stencil reach, or a multiple of it for several iterations per exchange)."""
     parts = []
     for k in range(world):
         own_lo, own_hi = (k * global_rows) // world, ((k + 1) * global_rows) // world
@@ -162,19 +163,24 @@ class StripRunner:
     CPU tests substitute an oracle-backed engine; the default builds the HIP engine."""
 
     def __init__(self, cols, rows, scheme=SCHEME_GODUNOV, precision="f64", rank=0, world=1, device=0,
-                 engine_factory=None, backend=None, init_process_group=True, overlap=None, loop=None, **kw):
+                 engine_factory=None, backend=None, init_process_group=True, overlap=None, loop=None, exchange_period=1, **kw):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.cols, self.rows, self.rank, self.world = cols, rows, rank, world
-        self.g = ghost_rows(scheme)
+        # ghost rows stored per interior side: one stencil reach, exchanged after every iteration -- or two, exchanged after
+        # every second one by the library's own strip loop (the strip recomputes a reach of its neighbour's rows in between)
+        if exchange_period not in (1, 2):
+            raise ValueError("exchange_period must be 1 or 2")
+        self.exchange_period = exchange_period
+        self.g = ghost_rows(scheme) * exchange_period
         self.scheme, self.precision = scheme, precision
         self.parts = partition(rows, world, self.g)
         self.own_lo, self.own_hi, self.local_lo, self.local_hi = self.parts[rank]
         self.local_rows_total = self.local_hi - self.local_lo
         if engine_factory is None:
             self.engine = HipEngine(cols, self.local_rows_total, rows, self.local_lo, scheme=scheme,
-                                    precision=precision, device=device, **kw)
+                                    precision=precision, device=device, ghost_rows=self.g if exchange_period > 1 else 0, **kw)
             backend = backend or "nccl"
         else:
             self.engine = engine_factory(cols, self.local_rows_total, rows, self.local_lo)
@@ -192,6 +198,8 @@ class StripRunner:
         if loop is None:
             loop = os.environ.get("HIPIMS_MI_STRIP_LOOP", "cxx" if (engine_factory is None and backend == "nccl") else "torch")
         self.loop = loop
+        if exchange_period > 1 and loop != "cxx":
+            raise ValueError("several iterations per exchange are the C++ strip loop's (loop='cxx')")
         if loop == "cxx":
             if engine_factory is not None or backend != "nccl":
                 raise ValueError("the C++ strip loop runs on the HIP engine over RCCL only")
@@ -204,6 +212,8 @@ class StripRunner:
                 if "HIPIMS_MI_STRIP_LOOP" in os.environ:
                     raise
                 import sys
+                if exchange_period > 1:
+                    raise
                 print(f"[hipims_mi] C++ strip loop unavailable ({e}); using the torch loop", file=sys.stderr, flush=True)
                 self.loop = loop = "torch"
         if loop == "cxx":

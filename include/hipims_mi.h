@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HP_ABI_VERSION 1
+#define HP_ABI_VERSION 2          /* 2: hp_domain_desc_t.ghost_rows */
 
 typedef enum {
 	HP_OK              =  0,
@@ -129,6 +129,13 @@ typedef struct {
 	 * A single-GPU domain has global_rows == rows and row_offset == 0. */
 	int64_t  global_rows;        /* rows of the whole logical grid */
 	int64_t  row_offset;         /* global row index of local row 0 */
+	/* Ghost rows stored per interior side of a strip: 0 = one stencil reach g (1 row Godunov / inertial, 2 MUSCL-Hancock) and a
+	 * ghost-row exchange after every iteration; 2g = two reaches and an exchange after every SECOND iteration (the strip
+	 * recomputes g of its neighbour's rows redundantly in between; hp_strip_step_batch only).  What is left of the reference's
+	 * wide overlap zones with several iterations between synchronisations (Domain/Links/CDomainLink.cpp:297-328,
+	 * Domain/CDomainBase.cpp:163-174), here without forecast and rollback: results stay bit-identical to the single domain. */
+	int32_t  ghost_rows;
+	int32_t  reserved0;
 } hp_domain_desc_t;
 
 void hp_domain_desc_default(hp_domain_desc_t* desc);   /* reference defaults, CScheme.cpp:46-55 */
@@ -267,7 +274,7 @@ typedef struct {
 	int32_t comm_ranks;
 	int32_t comm_rank;
 	int32_t halo_overlap;        /* 1: halo rows on their own stream, the transfer overlaps the interior launch */
-	int32_t reserved;
+	int32_t ghost_rows;          /* ghost rows per interior side: the stencil reach (exchange every iteration) or twice that (every second) */
 } hp_strip_info_t;
 int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out);
 

@@ -5,7 +5,7 @@
 // which iterations all-reduce) runs with 2-4 real ranks (tests/strip_threads_worker.py).
 //   ncclSend / ncclRecv inside a group: the receiver copies device-to-device on ITS stream after the sender's stream
 //   has reached the send (event), and the sender's stream then waits for the copy (event) -- the ordering RCCL gives.
-//   ncclAllReduce(MAX, 1 element): through the host, with a generation barrier over the ranks.
+//   ncclAllReduce(MAX, 1..8 elements, in or out of place): through the host, with a generation barrier over the ranks.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -24,7 +24,7 @@ struct Shared {
 	std::map<std::pair<int, int>, std::vector<Parcel>> box;      // (src, dst) -> parcels in flight, FIFO
 	int world = 0, arrived = 0;
 	unsigned long long generation = 0;
-	double acc = 0.0, result = 0.0;
+	double acc[8] = {0}, result[8] = {0};
 };
 struct Op { bool send; void* buf; size_t bytes; int peer; hipStream_t stream; };
 thread_local std::vector<Op> t_ops;
@@ -124,23 +124,23 @@ ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t type, int peer, nc
 ncclResult_t ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm,
                            hipStream_t stream)
 {
-	if (count != 1 || op != ncclMax) return ncclInvalidArgument;
-	double v = 0.0; float vf = 0.0f;
+	if (count < 1 || count > 8 || op != ncclMax) return ncclInvalidArgument;
+	double v[8] = {0}; float vf[8] = {0};
 	if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
-	if (type == ncclDouble) { if (hipMemcpy(&v, sendbuf, 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError; }
-	else { if (hipMemcpy(&vf, sendbuf, 4, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError; v = vf; }
+	if (type == ncclDouble) { if (hipMemcpy(v, sendbuf, 8 * count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError; }
+	else { if (hipMemcpy(vf, sendbuf, 4 * count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError; for (size_t i = 0; i < count; ++i) v[i] = vf[i]; }
 	Shared* sh = comm->sh;
-	double result;
+	double result[8];
 	{
 		std::unique_lock<std::mutex> l(sh->m);
 		const unsigned long long gen = sh->generation;
-		if (sh->arrived == 0 || v > sh->acc) sh->acc = v;
-		if (++sh->arrived == comm->world) { sh->result = sh->acc; sh->arrived = 0; ++sh->generation; sh->cv.notify_all(); }
+		for (size_t i = 0; i < count; ++i) if (sh->arrived == 0 || v[i] > sh->acc[i]) sh->acc[i] = v[i];
+		if (++sh->arrived == comm->world) { for (size_t i = 0; i < count; ++i) sh->result[i] = sh->acc[i]; sh->arrived = 0; ++sh->generation; sh->cv.notify_all(); }
 		else sh->cv.wait(l, [&] { return sh->generation != gen; });
-		result = sh->result;
+		for (size_t i = 0; i < count; ++i) result[i] = sh->result[i];
 	}
-	if (type == ncclDouble) { if (hipMemcpy(recvbuf, &result, 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError; }
-	else { vf = (float)result; if (hipMemcpy(recvbuf, &vf, 4, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError; }
+	if (type == ncclDouble) { if (hipMemcpy(recvbuf, result, 8 * count, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError; }
+	else { for (size_t i = 0; i < count; ++i) vf[i] = (float)result[i]; if (hipMemcpy(recvbuf, vf, 4 * count, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError; }
 	return ncclSuccess;
 }
 

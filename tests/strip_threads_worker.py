@@ -1,7 +1,8 @@
 """Worker of tests/test_gpu_strips.py::test_cxx_strip_loop_with_several_ranks: runs hp_strip_step_batch -- the library's own
 per-iteration strip loop -- with WORLD ranks that are threads of this process sharing the one GPU, over the in-process
 test double of the collective library (tests/fake_rccl), and compares the gathered strips with the single domain
-bit for bit.   usage: strip_threads_worker.py <world> <scheme 0|1|2> <f64|f32> <overlap 0|1> <rain 0|1>"""
+bit for bit.   usage: strip_threads_worker.py <world> <scheme 0|1|2> <f64|f32> <overlap 0|1> <rain 0|1> [exchange period 1|2]
+[boundary on rank k only: -1 = on all]"""
 import os
 import sys
 import threading
@@ -15,9 +16,11 @@ import hipims_mi as hp  # noqa: E402
 from hipims_mi import strips, synthetic as syn  # noqa: E402
 
 world, scheme, precision, overlap, rain_on = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+period = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+cell_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -2          # >= 0: a cell boundary that only THAT rank is told about
 cols, rows, steps = 300, 157, 90
 real = np.float64 if precision == "f64" else np.float32
-g = strips.ghost_rows(scheme)
+g = strips.ghost_rows(scheme) * period                             # ghost rows stored per interior side
 if rain_on:
     st, bed, man, rain = syn.s_rain_rows(cols, rows, 0, rows, dx=2.0, dtype=real)
     dx = 2.0
@@ -26,9 +29,19 @@ else:
     rain, dx = None, 1.0
 
 
-def attach(dom):
+parts = strips.partition(rows, world, g)
+cell_ids = None
+if cell_rank >= 0:                                                 # five cells in the middle of that rank's owned rows: imposed depth
+    lo_, hi_ = parts[cell_rank][0], parts[cell_rank][1]
+    cell_ids = np.array([((lo_ + hi_) // 2) * cols + x for x in range(100, 105)], np.uint64)
+    cell_series = np.array([[0.0, 0.8, 0.0, 0.0], [1000.0, 0.8, 0.0, 0.0], [2000.0, 0.8, 0.0, 0.0]])
+
+
+def attach(dom, rank=None):
     if rain is not None:
         dom.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"], rain["off_y"], rain["interval"])
+    if cell_ids is not None and (rank is None or rank == cell_rank):     # the other ranks are NOT told (participation)
+        dom.add_cell(hp.DEPTH_IS_DEPTH, hp.DISCHARGE_IGNORE, cell_ids, cell_series, 1000.0, 2000.0)
 
 
 single = hp.Domain(cols, rows, dx=dx, scheme=scheme, precision=precision)
@@ -41,7 +54,6 @@ single.close()
 lib = hp.load_library()
 hp._check(lib, lib.hp_comm_load(os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so").encode()), "hp_comm_load")
 uid = hp.comm_unique_id()
-parts = strips.partition(rows, world, g)
 got, scal, errors = [None] * world, [None] * world, []
 start = threading.Barrier(world)
 
@@ -49,12 +61,13 @@ start = threading.Barrier(world)
 def rank_main(r):
     try:
         own_lo, own_hi, lo, hi = parts[r]
-        dom = hp.Domain(cols, hi - lo, dx=dx, scheme=scheme, precision=precision, global_rows=rows, row_offset=lo)
-        dom.upload(st[lo:hi], bed[lo:hi], man[lo:hi]); attach(dom)
+        dom = hp.Domain(cols, hi - lo, dx=dx, scheme=scheme, precision=precision, global_rows=rows, row_offset=lo,
+                        ghost_rows=g if period > 1 else 0)
+        dom.upload(st[lo:hi], bed[lo:hi], man[lo:hi]); attach(dom, r)
         dom.set_halo_overlap(bool(overlap))
         dom.strip_comm_init(uid, r, world)
         info = dom.strip_info()                           # an explicit choice survives comm_init
-        assert info["halo_overlap"] == bool(overlap) and info["comm_rank"] == r, info
+        assert info["halo_overlap"] == bool(overlap) and info["comm_rank"] == r and info["ghost_rows"] == g, info
         dom.set_target_time(1e9)
         start.wait()
         dom.strip_update_timestep()                       # tst_Reduce + all-reduce + tst_UpdateTimestep, as after any upload
@@ -82,7 +95,11 @@ if errors or any(t.is_alive() for t in threads):
     print("FAILED", errors, [t.is_alive() for t in threads], flush=True); os._exit(2)
 out = np.concatenate(got, axis=0)
 same = np.array_equal(out.view(np.uint8), want.view(np.uint8))
+if not same:
+    bad = np.argwhere((out != want).any(axis=-1))
+    print("differing cells:", len(bad), "rows", sorted(set(bad[:, 0].tolist()))[:20], "cols", sorted(set(bad[:, 1].tolist()))[:12],
+          "strip edges", [pp[:2] for pp in parts], flush=True)
 times = {(s["time"], s["timestep"]) for s in scal}
-print("ranks", world, "scheme", scheme, precision, "overlap", overlap, "rain", rain_on, "bit-identical", same, "times", times,
+print("ranks", world, "scheme", scheme, precision, "overlap", overlap, "rain", rain_on, "period", period, "cell boundary on rank", cell_rank, "bit-identical", same, "times", times,
       "single", (want_sc["time"], want_sc["timestep"]), flush=True)
 os._exit(0 if same and times == {(want_sc["time"], want_sc["timestep"])} else 1)

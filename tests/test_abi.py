@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_defaults():
     lib = hipims_mi.load_library()
-    assert lib.hp_abi_version() == 1
+    assert lib.hp_abi_version() == 2
     d = hipims_mi.DomainDesc()
     lib.hp_domain_desc_default(C.byref(d))
     # reference defaults: CScheme.cpp:46-55, CSchemeGodunov.cpp:56

@@ -247,11 +247,16 @@ def test_bench_line_names_the_collective_library_on_the_cxx_loop():
     assert "rccl" in info["library"] and info["comm_ranks"] == 1 and info["comm_rank"] == 0
 
 
-@pytest.mark.parametrize("world,scheme,precision,overlap,rain", [
-    (2, hp.SCHEME_GODUNOV, "f64", 1, 0), (3, hp.SCHEME_GODUNOV, "f64", 0, 0), (4, hp.SCHEME_GODUNOV, "f32", 1, 1),
-    (2, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0), (2, hp.SCHEME_INERTIAL, "f64", 1, 0),
-    (3, hp.SCHEME_GODUNOV, "f64", 1, 1)])
-def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, rain):
+@pytest.mark.parametrize("world,scheme,precision,overlap,rain,period,cell_rank", [
+    (2, hp.SCHEME_GODUNOV, "f64", 1, 0, 1, -2), (3, hp.SCHEME_GODUNOV, "f64", 0, 0, 1, -2), (4, hp.SCHEME_GODUNOV, "f32", 1, 1, 1, -2),
+    (2, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 1, -2), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 1, -2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 1, -2),
+    (3, hp.SCHEME_GODUNOV, "f64", 1, 1, 1, -2),
+    # two reaches of ghost rows, one exchange per TWO iterations (round 3)
+    (2, hp.SCHEME_GODUNOV, "f64", 1, 0, 2, -2), (3, hp.SCHEME_GODUNOV, "f64", 0, 0, 2, -2), (4, hp.SCHEME_GODUNOV, "f32", 1, 1, 2, -2),
+    (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 2, -2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 2, -2), (3, hp.SCHEME_GODUNOV, "f64", 1, 1, 2, -2),
+    # a cell boundary that only the strip holding its cells is told about: the other ranks must still enter every collective
+    (3, hp.SCHEME_GODUNOV, "f64", 1, 0, 1, 1), (3, hp.SCHEME_GODUNOV, "f64", 1, 0, 2, 2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 2, 0)])
+def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, rain, period, cell_rank):
     """hp_strip_step_batch / hp_strip_update_timestep with 2-4 REAL ranks: the ranks are threads of one process sharing
     the GPU, the collective library is the in-process test double tests/fake_rccl (RCCL itself refuses two ranks on
     one device).  Everything on the engine's side of the nine ncclXxx entry points is the production code: which rows
@@ -264,6 +269,6 @@ def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, ra
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", lib,
                                os.path.join(os.path.dirname(lib), "fake_rccl.cpp")])
     res = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "strip_threads_worker.py"), str(world),
-                          str(scheme), precision, str(overlap), str(rain)], capture_output=True, text=True, timeout=600)
+                          str(scheme), precision, str(overlap), str(rain), str(period), str(cell_rank)], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "bit-identical True" in res.stdout

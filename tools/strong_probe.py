@@ -13,12 +13,13 @@ import hipims_mi as hp
 from hipims_mi import strips, synthetic as syn
 
 cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4096, 514)
+period = int(os.environ.get("PERIOD", "1"))          # 2: two reaches of ghost rows, halo / interior split on every second iteration only
 steps = 400
 with socket.socket() as s:
     s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 st, bed, man = syn.s_dam(cols, rows)
-r = strips.StripRunner(cols, rows, rank=0, world=1, loop="cxx")
+r = strips.StripRunner(cols, rows, rank=0, world=1, loop="cxx", exchange_period=period)
 r.upload_global(st, bed, man); r.set_target_time(1e9)
 
 def timed(fn, n):
@@ -26,7 +27,7 @@ def timed(fn, n):
     t0 = time.perf_counter(); fn(n); host = (time.perf_counter() - t0) / n * 1e6
     r.barrier(); return (time.perf_counter() - t0) / n * 1e6, host
 
-print("strip %d x %d (%.2f Mcell)" % (cols, rows, cols * rows / 1e6))
+print("strip %d x %d (%.2f Mcell), exchange every %d iteration(s)" % (cols, rows, cols * rows / 1e6, period))
 for name, fn, overlap in (("(a) hp_step_batch", lambda n: r.domain.step_batch(n), False),
                           ("(b) hp_strip_step_batch", lambda n: r.domain.strip_step_batch(n), False),
                           ("(c) hp_strip_step_batch, split launches", lambda n: r.domain.strip_step_batch(n), True)):
