@@ -167,61 +167,28 @@ template <typename T> struct FaceCore {
 	bool bLeft, bRight, bMid1;
 };
 
-template <int AXIS, bool STRICT, typename T>
+// Shift-dependent tail of a STRICT face solve for one of the two cells (the FAST flavour finishes a face once, see face_solve)
+template <int AXIS, typename T>
 __device__ __forceinline__ FaceFlux<T> finish_wet(const FaceCore<T>& k, const T s, const bool own_left, const bool stop)
 {
 	const T half_g = T(0.5) * gravity<T>();
 	const T a = k.etaL - s, b = k.etaR - s, zb = k.zbm - s;
 	// normal-momentum flux of each side in free-surface form, left bed on both sides (:146-157, Q4)
-	T fnL, fnR;
-	if (STRICT) {
-		fnL = k.unL * k.qnL + half_g * (a * a - 2 * zb * a);
-		fnR = k.unR * k.qnR + half_g * (b * b - 2 * zb * b);
-	} else {
-		fnL = fma_(k.unL, k.qnL, half_g * (a * (a - 2 * zb)));
-		fnR = fma_(k.unR, k.qnR, half_g * (b * (b - 2 * zb)));
-	}
+	const T fnL = k.unL * k.qnL + half_g * (a * a - 2 * zb * a);
+	const T fnR = k.unR * k.qnR + half_g * (b * b - 2 * zb * b);
 	T f0, fn, ft;
 	if (k.bLeft)       { f0 = k.qnL; fn = fnL; ft = k.unL * k.qtL; }
 	else if (k.bRight) { f0 = k.qnR; fn = fnR; ft = k.unR * k.qtR; }
 	else {
 		// HLL middle state (:200-224)
-		T f1m, f2m;
-		if (STRICT) {
-			f1m = (k.sR * k.qnL - k.sL * k.qnR + k.sLsR * (b - a)) / (k.sR - k.sL);
-			f2m = (k.sR * fnL - k.sL * fnR + k.sLsR * (k.qnR - k.qnL)) / (k.sR - k.sL);
-		} else {
-			f1m = fma_(k.sLsR, (b - a), fma_(k.sR, k.qnL, -(k.sL * k.qnR))) * k.inv_ds;
-			f2m = fma_(k.sLsR, (k.qnR - k.qnL), fma_(k.sR, fnL, -(k.sL * fnR))) * k.inv_ds;
-		}
+		const T f1m = (k.sR * k.qnL - k.sL * k.qnR + k.sLsR * (b - a)) / (k.sR - k.sL);
+		const T f2m = (k.sR * fnL - k.sL * fnR + k.sLsR * (k.qnR - k.qnL)) / (k.sR - k.sL);
 		f0 = f1m; fn = f2m; ft = f1m * (k.bMid1 ? k.utL : k.utR);
 	}
 	FaceFlux<T> o;
 	o.f0 = f0;
 	o.fx = (AXIS == AXIS_X ? fn : ft);
 	o.fy = (AXIS == AXIS_X ? ft : fn);
-	o.eta_nb = own_left ? b : a;
-	o.zb_nb = zb;
-	o.stop = stop;
-	return o;
-}
-
-// The same face finished for the OTHER cell (FAST flavour): of everything finish_wet produces only the
-// normal-momentum flux feels the shift -- through the pressure-like terms g/2 (eta^2 - 2 zb eta) -- besides the two
-// values handed to the bed-slope source.  Mass flux and tangential momentum are carried over from the first finish
-// ((b - a) is the same difference up to rounding); this is what thin films over rough terrain execute on most faces.
-template <int AXIS, typename T>
-__device__ __forceinline__ FaceFlux<T> refinish_wet(const FaceCore<T>& k, const FaceFlux<T>& first, const T s,
-                                                    const bool own_left, const bool stop)
-{
-	const T half_g = T(0.5) * gravity<T>();
-	const T a = k.etaL - s, b = k.etaR - s, zb = k.zbm - s;
-	const T fnL = fma_(k.unL, k.qnL, half_g * (a * (a - 2 * zb)));
-	const T fnR = fma_(k.unR, k.qnR, half_g * (b * (b - 2 * zb)));
-	const T f2m = fma_(k.sLsR, (k.qnR - k.qnL), fma_(k.sR, fnL, -(k.sL * fnR))) * k.inv_ds;
-	const T fn = k.bLeft ? fnL : (k.bRight ? fnR : f2m);
-	FaceFlux<T> o = first;
-	if (AXIS == AXIS_X) o.fx = fn; else o.fy = fn;
 	o.eta_nb = own_left ? b : a;
 	o.zb_nb = zb;
 	o.stop = stop;
@@ -267,10 +234,6 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 
 	// ---- HLLC ----
 	FaceFlux<T> oL, oR;
-	// Wave-uniform fast path (FAST flavour): when every lane of the wavefront has water on both sides of its face,
-	// none of the dry-side forms, zeroed velocities or stopping conditions can apply (they all test h <= VERY_SMALL),
-	// and when in addition every lane is in the subcritical "middle" region of the HLLC fan only the HLL middle state
-	// is needed.  Same formulas, same results -- the selects between alternatives nobody takes are simply not executed.
 	if (!STRICT) {
 		// ---- FAST flavour (round 3 formulation) ----
 		// (1) The vertical shift enters a finished face only through the pressure-like terms g/2 (eta^2 - 2 zb eta) of the
@@ -283,7 +246,11 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 		// (2) s_M is only needed for its sign (which side's tangential velocity the middle state carries, :206-224), and
 		//     s_M = -(s_R - s_L) F_1 / den with den < 0 whenever a side is wet: sign(s_M) = sign of the HLL mass flux F_1,
 		//     which is computed anyway.  (Round 2 evaluated s_M's numerator and denominator: 12 operations.)
-		// (3) A wavefront that is not wet on both sides of every face runs STRAIGHT-LINE code: dry-side wave speeds
+		// (3) Wave-uniform short cuts: when every lane of the wavefront has water on both sides of its face, none of the
+		//     dry-side forms, zeroed velocities, shifts or stopping conditions can apply (they all need h <= VERY_SMALL),
+		//     and when every lane is in the subcritical "middle" region of the fan only the HLL middle state is needed:
+		//     the selects between alternatives nobody takes are simply not executed.  Otherwise the wavefront runs
+		//     STRAIGHT-LINE code: dry-side wave speeds
 		//     (:129-140), region (:174-198) and the dry-dry flux (:45-61) are per-lane selects over ONE instruction stream
 		//     (round 2: divergent branches, each under its own exec mask, ~190 VALU per face; now ~140).  A wet-wet
 		//     lane executes exactly the operations of the all-wet path, so a face has the same bits whichever wavefront
@@ -345,71 +312,45 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 		oR.f0 = f0; oR.fx = (AXIS == AXIS_X ? fnForR : ft); oR.fy = (AXIS == AXIS_X ? ft : fnForR);
 		oR.eta_nb = etaL - shR; oR.zb_nb = zbm - shR; oR.stop = stopR;
 	} else if (hL < vs && hR < vs) {
+		// ---- STRICT flavour: the reference's statements in the reference's order ----
 		oL = finish_dry<AXIS>(etaL, etaR, zbm, shL, true, stopL);
 		oR = finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
 	} else {
-		// velocities (:87-92).  STRICT: recomputed from the reconstructed discharges as the reference does;
-		// FAST: h*u0/h == u0 up to rounding, so the four divisions are dropped.
-		T uL, vL, uR, vR;
-		if (STRICT) {
-			uL = (hL < vs ? T(0) : qxL / hL); vL = (hL < vs ? T(0) : qyL / hL);
-			uR = (hR < vs ? T(0) : qxR / hR); vR = (hR < vs ? T(0) : qyR / hR);
-		} else {
-			uL = (hL < vs ? T(0) : L.u0); vL = (hL < vs ? T(0) : L.v0);
-			uR = (hR < vs ? T(0) : R.u0); vR = (hR < vs ? T(0) : R.v0);
-		}
+		// velocities recomputed from the reconstructed discharges as the reference does (:87-92)
+		const T uL = (hL < vs ? T(0) : qxL / hL), vL = (hL < vs ? T(0) : qyL / hL);
+		const T uR = (hR < vs ? T(0) : qxR / hR), vR = (hR < vs ? T(0) : qyR / hR);
 		FaceCore<T> k;
 		k.etaL = etaL; k.etaR = etaR; k.zbm = zbm;
 		k.unL = (AXIS == AXIS_X ? uL : vL); k.unR = (AXIS == AXIS_X ? uR : vR);           // dVel   (:95-98)
 		k.utL = (AXIS == AXIS_X ? vL : uL); k.utR = (AXIS == AXIS_X ? vR : uR);           // tangential velocity
 		k.qnL = (AXIS == AXIS_X ? qxL : qyL); k.qnR = (AXIS == AXIS_X ? qxR : qyR);       // dDis   (:99-102)
 		k.qtL = (AXIS == AXIS_X ? qyL : qxL); k.qtR = (AXIS == AXIS_X ? qyR : qxR);
-		const T aL = STRICT ? sqrt_(g * hL) : sqrt_fast(g * hL);                          // dA     (:103-106)
-		const T aR = STRICT ? sqrt_(g * hR) : sqrt_fast(g * hR);
+		const T aL = sqrt_(g * hL), aR = sqrt_(g * hR);                                   // dA     (:103-106)
 
 		// two-rarefaction star state and wave speeds (:123-142)
 		const T a_avg = (aL + aR) / 2;
 		const T tmp = a_avg + (k.unL - k.unR) / 4;
 		const T u_star = (k.unL + k.unR) / 2 + aL - aR;
-		T a_star;
-		if (STRICT) a_star = sqrt_(g * ((tmp * tmp) / g));
-		else        a_star = fabs_(tmp);                         // sqrt(g * tmp^2 / g)
+		const T a_star = sqrt_(g * ((tmp * tmp) / g));
 		T sL, sR;
-		if (STRICT) {
-			if (hL < vs) sL = k.unR - 2 * aR;
-			else         sL = (((k.unL - aL) > (u_star - a_star)) ? (u_star - a_star) : (k.unL - aL));
-			if (hR < vs) sR = k.unL + 2 * aL;
-			else         sR = (((k.unR + aR) < (u_star + a_star)) ? (u_star + a_star) : (k.unR + aR));
-		} else {
-			sL = (hL < vs) ? (k.unR - 2 * aR) : fmin_(k.unL - aL, u_star - a_star);
-			sR = (hR < vs) ? (k.unL + 2 * aL) : fmax_(k.unR + aR, u_star + a_star);
-		}
+		if (hL < vs) sL = k.unR - 2 * aR;
+		else         sL = (((k.unL - aL) > (u_star - a_star)) ? (u_star - a_star) : (k.unL - aL));
+		if (hR < vs) sR = k.unL + 2 * aL;
+		else         sR = (((k.unR + aR) < (u_star + a_star)) ? (u_star + a_star) : (k.unR + aR));
 		k.sL = sL; k.sR = sR; k.sLsR = sL * sR;
 
-		// region selection (:174-177); NaN wave speeds fall through to "right" exactly as in the reference.
-		// s_M is only ever compared with zero: FAST decides the sign from numerator and denominator.
+		// region selection (:174-177); NaN wave speeds fall through to "right" exactly as in the reference
 		const T sm_num = sL * hR * (k.unR - sR) - sR * hL * (k.unL - sL);
 		const T sm_den = hR * (k.unR - sR) - hL * (k.unL - sL);
-		bool sm_nonneg;
-		if (STRICT) sm_nonneg = (sm_num / sm_den) >= T(0);
-		else        sm_nonneg = (sm_den < T(0)) ? (sm_num <= T(0)) : ((sm_num / sm_den) >= T(0));
+		const bool sm_nonneg = (sm_num / sm_den) >= T(0);
 		k.bLeft = sL >= T(0);
 		k.bMid1 = sL < T(0) && sR >= T(0) && sm_nonneg;
 		const bool bMid2 = sL < T(0) && sR >= T(0) && !k.bMid1;
 		k.bRight = !k.bLeft && !k.bMid1 && !bMid2;
-		k.inv_ds = STRICT ? T(0) : rcp_fast(sR - sL);
+		k.inv_ds = T(0);
 
-		oL = finish_wet<AXIS, STRICT>(k, shL, true, stopL);
-		// The two finishes differ only through the shift, which is non-zero only where a cell's level lies below
-		// its neighbour's bed.  FAST reuses the first result where the shifts agree (bit-identical by construction).
-		if (!STRICT && WANT_L && WANT_R) {
-			oR = oL;
-			if (shL != shR) oR = refinish_wet<AXIS>(k, oL, shR, false, stopR);     // skipped wave-wide where no lane needs it
-			oR.eta_nb = etaL - shR;
-			oR.stop = stopR;
-		} else {
-			oR = finish_wet<AXIS, STRICT>(k, shR, false, stopR);
-		}
+		oL = finish_wet<AXIS>(k, shL, true, stopL);
+		oR = finish_wet<AXIS>(k, shR, false, stopR);
 	}
 	FacePair<T> out;
 	out.forL = oL;
