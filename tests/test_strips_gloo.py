@@ -71,3 +71,17 @@ def test_partition_covers_grid_once():
         assert parts[0][0] == 0 and parts[-1][1] == rows
         for (a0, a1, l0, l1), (b0, b1, m0, m1) in zip(parts, parts[1:]):
             assert a1 == b0 and l1 == a1 + g and m0 == b0 - g
+
+
+def test_partition_with_two_reaches_of_ghost_rows_and_period_needs_the_cxx_loop():
+    """exchange_period = 2 stores 2g ghost rows per interior side (partition's third argument) and belongs to the library's
+    own strip loop: the torch loop of this module exchanges after every iteration and must refuse it."""
+    from hipims_mi import strips
+    parts = strips.partition(100, 3, 2)
+    assert parts == [(0, 33, 0, 35), (33, 66, 31, 68), (66, 100, 64, 100)]
+    with pytest.raises(ValueError, match="thinner than its halo"):
+        strips.partition(12, 4, 2)
+    with pytest.raises(ValueError, match="exchange_period"):
+        strips.StripRunner(32, 64, world=1, exchange_period=3, engine_factory=lambda *a: None, init_process_group=False)
+    with pytest.raises(ValueError, match="C\\+\\+ strip loop"):
+        strips.StripRunner(32, 64, world=1, exchange_period=2, engine_factory=lambda *a: None, init_process_group=False)
