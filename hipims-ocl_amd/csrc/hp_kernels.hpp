@@ -169,10 +169,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, con
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, (int)HP_SRD_FLAGS);
 }
 
+// cache policy of the three access streams (aux operand: bit 1 = nt on gfx940+); all default -- see DESIGN 4 K1 for what
+// selective non-temporal streams measured
+#ifndef HP_AUX_STATE_LD
+#define HP_AUX_STATE_LD 0
+#endif
+#ifndef HP_AUX_STATE_ST
+#define HP_AUX_STATE_ST 0
+#endif
+#ifndef HP_AUX_SCALAR_LD
+#define HP_AUX_SCALAR_LD 0
+#endif
 __device__ __forceinline__ State4<double> buf_load_state(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, double)
 {
-	const hp_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-	const hp_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff + 16, (int)soff, 0);
+	const hp_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, HP_AUX_STATE_LD);
+	const hp_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff + 16, (int)soff, HP_AUX_STATE_LD);
 	State4<double> s;
 	s.z    = __hiloint2double((int)a.y, (int)a.x); s.zmax = __hiloint2double((int)a.w, (int)a.z);
 	s.qx   = __hiloint2double((int)b.y, (int)b.x); s.qy   = __hiloint2double((int)b.w, (int)b.z);
@@ -180,19 +191,19 @@ __device__ __forceinline__ State4<double> buf_load_state(__amdgpu_buffer_rsrc_t 
 }
 __device__ __forceinline__ State4<float> buf_load_state(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, float)
 {
-	const hp_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+	const hp_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, HP_AUX_STATE_LD);
 	State4<float> s;
 	s.z = __uint_as_float(a.x); s.zmax = __uint_as_float(a.y); s.qx = __uint_as_float(a.z); s.qy = __uint_as_float(a.w);
 	return s;
 }
 __device__ __forceinline__ double buf_load_scalar(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, double)
 {
-	const hp_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+	const hp_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, HP_AUX_SCALAR_LD);
 	return __hiloint2double((int)a.y, (int)a.x);
 }
 __device__ __forceinline__ float buf_load_scalar(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, float)
 {
-	return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+	return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, HP_AUX_SCALAR_LD));
 }
 // Store hazard.  On gfx950 a 16-byte buffer store reads its VGPR operands -- the data AND the per-lane offset -- over
 // several cycles AFTER it has issued; a VALU instruction that overwrites one of them in the next slots changes what lanes
@@ -219,8 +230,8 @@ __device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgp
 	a.z = (unsigned)__double2loint(s.zmax); a.w = (unsigned)__double2hiint(s.zmax);
 	b.x = (unsigned)__double2loint(s.qx); b.y = (unsigned)__double2hiint(s.qx);
 	b.z = (unsigned)__double2loint(s.qy); b.w = (unsigned)__double2hiint(s.qy);
-	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, 0);
-	__builtin_amdgcn_raw_buffer_store_b128(b, r, (int)voff + 16, (int)soff, 0);
+	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, HP_AUX_STATE_ST);
+	__builtin_amdgcn_raw_buffer_store_b128(b, r, (int)voff + 16, (int)soff, HP_AUX_STATE_ST);
 	store_fence(a, voff, soff);
 	store_fence(b, voff, soff);
 }
@@ -229,7 +240,7 @@ __device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu
 	asm volatile("" : "+v"(voff));
 	hp_u32x4 a;
 	a.x = __float_as_uint(s.z); a.y = __float_as_uint(s.zmax); a.z = __float_as_uint(s.qx); a.w = __float_as_uint(s.qy);
-	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, 0);
+	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, HP_AUX_STATE_ST);
 	store_fence(a, voff, soff);
 }
 
