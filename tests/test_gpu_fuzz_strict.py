@@ -1,0 +1,112 @@
+"""Seeded differential fuzzing: STRICT HIP engine vs the oracle, bit for bit, over random combinations of everything the hot
+path has a switch for -- grid shape (tile and wavefront edges), scheme, precision, friction, uniform vs spatially varying
+Manning n, quirks Q1 / Q9, dynamic vs fixed timestep, a sync point inside the run, uniform rain, uniform loss, coarse (fused)
+and fine (stand-alone pass) gridded rain, cell boundaries with all four definitions, and how the iterations are cut into
+batches.  Every case is a few thousand cells and a few hundred iterations: the whole file runs in about a minute.
+
+Bit identity is only promised where the oracle and the engine run the same algorithm: MUSCL-Hancock in snapshot order
+(quirk Q6), boundaries in the order added (Q7)."""
+import numpy as np
+import pytest
+
+import hipims_mi as hp
+import oracle
+from hipims_mi import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = 160
+
+
+def make_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    scheme = int(rng.choice([hp.SCHEME_GODUNOV, hp.SCHEME_GODUNOV, hp.SCHEME_MUSCL_HANCOCK, hp.SCHEME_INERTIAL]))
+    precision = str(rng.choice(["f64", "f64", "f32"]))
+    cols = int(rng.choice([7, 33, 62, 63, 64, 65, 124, 125, 190, 257]))
+    rows = int(rng.choice([6, 17, 18, 19, 37, 64, 101]))
+    dx = float(rng.choice([1.0, 2.0, 0.5]))
+    real = np.float64 if precision == "f64" else np.float32
+    st, bed, man = syn.s_rough(cols, rows, dtype=real, seed=int(rng.integers(1, 10 ** 6)), amplitude=float(rng.uniform(0.1, 0.8)),
+                               pool_level=float(rng.uniform(-0.2, 0.5)), manning=None if rng.random() < 0.6 else 0.035)
+    if scheme == hp.SCHEME_INERTIAL:                       # gentler initial discharges: the scheme is not positivity preserving
+        st[..., 2:] *= 0.1
+    if rng.random() < 0.25:                                # a few disabled cells (the domain's nulls)
+        ys, xs = rng.integers(1, rows - 1, 3), rng.integers(1, cols - 1, 3)
+        st[ys, xs, 0] = -9999.0; st[ys, xs, 1] = -9999.0; st[ys, xs, 2:] = 0
+    quirks = oracle.QUIRKS_REFERENCE
+    if rng.random() < 0.3:
+        quirks &= ~hp.QUIRK_CFL_READS_PRIMARY
+    if rng.random() < 0.3:
+        quirks &= ~hp.QUIRK_BDY_TRUNCATED
+    kw = dict(friction=bool(rng.random() < 0.8), dynamic_dt=bool(rng.random() < 0.85))
+    fixed_dt = float(rng.choice([0.002, 0.004])) * dx       # well inside the CFL limit of these states: a fixed step that blows
+                                                             # the run up (NaNs on both sides) has no bits left to compare
+    bdy = []
+    if scheme != hp.SCHEME_MUSCL_HANCOCK:                  # (MUSCL-Hancock never applies them, quirk Q8)
+        if rng.random() < 0.5:
+            bdy.append(("uniform", hp.UNIFORM_RAIN_INTENSITY, np.array([[0.0, rng.uniform(10, 200)], [5.0, rng.uniform(10, 200)], [10.0, 0.0]]), 5.0, 10.0))
+        if rng.random() < 0.3:
+            bdy.append(("uniform", hp.UNIFORM_LOSS_RATE, np.array([[0.0, rng.uniform(1, 30)], [100.0, 5.0]]), 100.0, 100.0))
+        if rng.random() < 0.5:
+            coarse = rng.random() < 0.6                    # >= 64 model cells per grid cell: rides in the flux kernel
+            res = dx * (64 if coarse else 8)
+            gr, gc = int(np.ceil(rows * dx / res)) + 1, int(np.ceil(cols * dx / res)) + 1
+            bdy.append(("gridded", int(rng.choice([hp.GRIDDED_RAIN_INTENSITY, hp.GRIDDED_MASS_FLUX])),
+                        rng.uniform(0.0, 300.0, (3, gr, gc)) * (1.0 if rng.random() < 0.5 else 1e-3), res, 4.0))
+        if rng.random() < 0.3 and cols > 12 and rows > 8:
+            cells = np.array([int(rng.integers(2, rows - 2)) * cols + int(rng.integers(2, cols - 2)) for _ in range(4)], np.uint64)
+            series = np.array([[0.0, 0.3, 0.05, -0.02], [50.0, 0.5, 0.08, 0.03], [100.0, 0.2, 0.0, 0.0]])
+            bdy.append(("cell", int(rng.integers(0, 3)), int(rng.integers(0, 4)), np.unique(cells), series, 50.0, 100.0))
+        rng.shuffle(bdy)
+    total = int(rng.integers(40, 260))
+    cuts, left = [], total
+    while left > 0:
+        n = int(min(left, rng.choice([1, 1, 2, 3, 7, 20, 64, 1000])))
+        cuts.append(n); left -= n
+    target = float(rng.choice([1e9, 1e9, rng.uniform(0.05, 1.5)]))
+    return dict(scheme=scheme, precision=precision, cols=cols, rows=rows, dx=dx, st=st, bed=bed, man=man, quirks=quirks, kw=kw,
+                fixed_dt=fixed_dt, bdy=bdy, cuts=cuts, target=target)
+
+
+def attach(sim, bdy):
+    for b in bdy:
+        if b[0] == "uniform":
+            sim.add_uniform(b[1], b[2], b[3], b[4])
+        elif b[0] == "gridded":
+            sim.add_gridded(b[1], b[2], b[3], 0.0, 0.0, b[4])
+        else:
+            sim.add_cell(b[1], b[2], b[3], b[4], b[5], b[6])
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_strict_engine_equals_the_oracle_on_a_random_configuration(seed):
+    c = make_case(seed)
+    oq = c["quirks"] & ~(oracle.Q6_MUSCL_SERIAL if c["scheme"] == hp.SCHEME_MUSCL_HANCOCK else 0)
+    ref = oracle.OracleSim(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=oq,
+                           friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], fixed_dt=c["fixed_dt"],
+                           dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001)
+    dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3,
+                    friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"],
+                    dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=hp.MATH_STRICT)
+    for s in (ref, dom):
+        s.upload(c["st"], c["bed"], c["man"])
+        attach(s, c["bdy"])
+    dom.set_target_time(c["target"]); ref.set_target(c["target"])
+    what = f"seed {seed}: scheme {c['scheme']} {c['precision']} {c['cols']}x{c['rows']} bdy {[b[0] for b in c['bdy']]} cuts {c['cuts'][:6]} target {c['target']:.3g}"
+    done = 0
+    for n in c["cuts"]:
+        ref.run(n); dom.step_batch(n)
+        done += n
+        if n >= 20 or done == sum(c["cuts"]):              # (a download after every single-iteration batch would dominate the run time)
+            want = ref.download()
+            if not np.isfinite(want[c["st"][..., 1] > -9000]).all():
+                pytest.skip("the oracle's own run is not finite: " + what)
+            assert np.array_equal(dom.download(), want), what + f" after {done} iterations"
+    if not np.isfinite(ref.download()[c["st"][..., 1] > -9000]).all():
+        pytest.skip("the oracle's own run is not finite: " + what)
+    sc, sr = dom.read_scalars(), ref.scalars()
+    assert sc["time"] == sr["t"] and sc["timestep"] == sr["dt"], what
+    assert sc["batch_successful"] == sr["batch_ok"] and sc["batch_skipped"] == sr["batch_skipped"], what
+    assert sc["time_hydrological"] == sr["t_hydro"], what
+    assert np.isfinite(dom.download()[c["st"][..., 1] > -9000]).all(), what
+    dom.close()
