@@ -110,3 +110,27 @@ def test_strict_engine_equals_the_oracle_on_a_random_configuration(seed):
     assert sc["time_hydrological"] == sr["t_hydro"], what
     assert np.isfinite(dom.download()[c["st"][..., 1] > -9000]).all(), what
     dom.close()
+
+
+@pytest.mark.parametrize("seed", range(0, N_CASES, 4))
+def test_fast_engine_does_not_depend_on_how_the_iterations_are_batched(seed):
+    """The FAST flavour has no oracle to be bit-identical to, but it owes the same bits to itself however the run is cut:
+    one batch (area boundaries fused into the flux kernel wherever they qualify), the random cuts, and single-iteration
+    batches (never fused)."""
+    c = make_case(seed)
+    total = sum(c["cuts"])
+    outs = []
+    for plan in ([total], c["cuts"], [1] * total):
+        dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3,
+                        friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"],
+                        dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=hp.MATH_FAST)
+        dom.upload(c["st"], c["bed"], c["man"])
+        attach(dom, c["bdy"])
+        dom.set_target_time(c["target"])
+        for n in plan:
+            dom.step_batch(n)
+        outs.append((dom.download(), dom.read_scalars()))
+        dom.close()
+    for out, sc in outs[1:]:
+        assert np.array_equal(out, outs[0][0], equal_nan=True), seed
+        assert sc["time"] == outs[0][1]["time"] and sc["timestep"] == outs[0][1]["timestep"]
