@@ -1317,23 +1317,18 @@ int strip_handshake(hp_domain* d)
 	double all[8];
 	char* slot = (char*)d->cfl_slot + (size_t)SLOT_HANDSHAKE * d->esize;
 	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
-	if (d->desc.precision == 8) {
-		HIP_TRY(hipMemcpyAsync(slot, mine, sizeof mine, hipMemcpyHostToDevice, d->stream));
-	} else {
-		float f[8]; for (int i = 0; i < 8; ++i) f[i] = (float)mine[i];
-		HIP_TRY(hipMemcpyAsync(slot, f, sizeof f, hipMemcpyHostToDevice, d->stream));
-		HIP_TRY(hipStreamSynchronize(d->stream));                       // `f` leaves scope
-	}
+	// staged through the domain's pinned block (bytes 256..511; hp_read_scalars uses the first 128): an asynchronous copy
+	// must not read from, or land in, this function's stack
+	char* pinned = (char*)d->host_scalars + 256;
+	HIP_TRY(hipStreamSynchronize(d->stream));                           // nothing of an earlier handshake is still in flight
+	if (d->desc.precision == 8) std::memcpy(pinned, mine, sizeof mine);
+	else { float* f = (float*)pinned; for (int i = 0; i < 8; ++i) f[i] = (float)mine[i]; }
+	HIP_TRY(hipMemcpyAsync(slot, pinned, 8 * d->esize, hipMemcpyHostToDevice, d->stream));
 	RCCL_TRY(g_rccl.AllReduce(slot, slot + 8 * d->esize, 8, type, ncclMax, d->comm, d->stream));
-	if (d->desc.precision == 8) {
-		HIP_TRY(hipMemcpyAsync(all, slot + 8 * d->esize, sizeof all, hipMemcpyDeviceToHost, d->stream));
-		HIP_TRY(hipStreamSynchronize(d->stream));
-	} else {
-		float f[8];
-		HIP_TRY(hipMemcpyAsync(f, slot + 8 * d->esize, sizeof f, hipMemcpyDeviceToHost, d->stream));
-		HIP_TRY(hipStreamSynchronize(d->stream));
-		for (int i = 0; i < 8; ++i) all[i] = f[i];
-	}
+	HIP_TRY(hipMemcpyAsync(pinned + 128, slot + 8 * d->esize, 8 * d->esize, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	if (d->desc.precision == 8) std::memcpy(all, pinned + 128, sizeof all);
+	else { const float* f = (const float*)(pinned + 128); for (int i = 0; i < 8; ++i) all[i] = f[i]; }
 	if (all[2] != -all[3]) return fail(HP_ERR_STATE, "the strips disagree on the ping-pong phase (different iteration counts?)");
 	if (all[4] != -all[5] || all[6] != -all[7]) return fail(HP_ERR_STATE, "the strips disagree on their ghost rows");
 	d->strip_any_bdy = all[0] > 0.0;
