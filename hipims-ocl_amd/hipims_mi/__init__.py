@@ -321,6 +321,9 @@ class Domain:
                                                        rel.size, ser.ctypes.data_as(C.c_void_p), ser.shape[0], interval,
                                                        length), "hp_boundary_add_cell")
 
+    def clear_boundaries(self):
+        _check(self.lib, self.lib.hp_boundary_clear(self.h), "hp_boundary_clear")
+
     def boundaries_fused(self):
         """True when rain / loss ride in the flux kernel's store epilogue instead of a pass of their own."""
         f = C.c_int(0)

@@ -129,3 +129,38 @@ def test_a_cell_boundary_among_them_keeps_the_stand_alone_passes():
     dom.add_cell(2, 1, g["cells"], g["series"], 5.0, 20.0)
     assert not dom.boundaries_fused()
     dom.close()
+
+
+def test_boundaries_added_and_cleared_between_batches_and_a_checkpoint_in_between():
+    """The host changes the boundary set while the run is under way, takes a device-side checkpoint mid-way and rolls back
+    to it: the fused path (long batches) and the never-fused path (single-iteration batches) must agree bit for bit."""
+    cols, rows, dx = 150, 90, 2.0
+    st, bed, man = syn.s_rough(cols, rows, manning=None)
+    rng = np.random.default_rng(9)
+    grids = rng.uniform(0.0, 250.0, (3, 3, 4))
+
+    def run(single):
+        dom = hp.Domain(cols, rows, dx=dx)
+        dom.upload(st, bed, man)
+        dom.set_target_time(1e9)
+        step = (lambda n: [dom.step_batch(1) for _ in range(n)]) if single else dom.step_batch
+        step(30)
+        dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, [[0.0, 90.0], [3600.0, 90.0]], 3600.0, 3600.0)
+        step(41)
+        dom.state_save()
+        step(25)
+        dom.clear_boundaries()
+        step(13)
+        dom.state_restore()                                   # back to iteration 71 (the boundary set is the host's business)
+        dom.add_gridded(hp.GRIDDED_RAIN_INTENSITY, grids, 128.0, 0.0, 0.0, 10.0)
+        assert dom.boundaries_fused()
+        step(60)
+        out, sc = dom.download(), dom.read_scalars()
+        dom.close()
+        return out, sc
+
+    a, sa = run(False)
+    b, sb = run(True)
+    assert np.array_equal(a, b)
+    assert sa["time"] == sb["time"] and sa["timestep"] == sb["timestep"] and sa["time_hydrological"] == sb["time_hydrological"]
+    assert (a[..., 0] - bed).max() > 1e-3
