@@ -15,8 +15,10 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 using namespace hp;
 
@@ -51,6 +53,12 @@ int fail(int code, const std::string& msg)
 	if (hp_log_sink_t sink = g_log_sink.load(std::memory_order_acquire))
 		sink(HP_LOG_MODEL_STOP, g_last_error.c_str(), g_log_user.load(std::memory_order_acquire));
 	return code;
+}
+
+void log_line(int level, const std::string& msg)
+{
+	if (hp_log_sink_t sink = g_log_sink.load(std::memory_order_acquire))
+		sink(level, msg.c_str(), g_log_user.load(std::memory_order_acquire));
 }
 
 #define HIP_TRY(expr)                                                                                  \
@@ -133,9 +141,18 @@ struct hp_domain {
 	ncclComm_t       comm = nullptr;
 	int              comm_rank = 0, comm_world = 1;
 	hipEvent_t       ev_xchg = nullptr;               // ghost rows of the iteration in flight have arrived
+	// the maximum over all strips through peer-written mailboxes (hp_strip_peer_*; PeerBox in hp_kernels.hpp)
+	unsigned long long*  peer_mine = nullptr;         // this rank's mailbox (uncached device memory)
+	unsigned long long** peer_table = nullptr;        // device: every rank's mailbox as this device addresses it
+	std::vector<void*>   peer_mapped;                 // IPC mappings to close
+	int              peer_world = 0, peer_rank = 0;
+	bool             peer_agreed = false;             // every rank of the communicator passed the connection test: the strip loop uses them
+	uint64_t         peer_rounds = 0;                 // reductions so far (its parity picks the mailbox set; the same on every rank)
 };
 
 namespace {
+
+void peer_release(hp_domain* d);      // (mailboxes of the peer-written maximum, further down)
 
 // stencil reach of the scheme = ghost rows one iteration consumes
 inline long strip_ghosts(const hp_domain* d) { return d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK ? 2 : 1; }
@@ -484,16 +501,34 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	return HP_OK;
 }
 
+// kernel argument of a reduction through the mailboxes (one per reduction: its parity picks the mailbox set)
+static long peer_timeout_ms()
+{
+	static const long ms = std::getenv("HP_PEER_TIMEOUT_MS") ? std::atol(std::getenv("HP_PEER_TIMEOUT_MS")) : 10000;
+	return ms > 0 ? ms : 10000;
+}
+PeerBox peer_box(hp_domain* d, bool use, long timeout_ms = 0)
+{
+	PeerBox box{};
+	if (!use) return box;
+	box.mine = d->peer_mine; box.peer = d->peer_table;
+	box.world = d->peer_world; box.rank = d->peer_rank;
+	box.set = (int)(d->peer_rounds++ & 1);
+	box.timeout = (unsigned long long)(timeout_ms > 0 ? timeout_ms : peer_timeout_ms()) * 100000ull;   // wall_clock64: 100 MHz
+	return box;
+}
+
 template <typename T> int step_end_impl(hp_domain* d)
 {
 	const Params<T> p = make_params<T>(d);
+	const PeerBox box = peer_box(d, (d->adv_fresh & 4) != 0);
 	if (d->halo_overlap) {                    // (also after an unsplit iteration: the NEXT one may be split and fork from here)
 		hipExtLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, nullptr, d->ev_fork, 0, p,
-		                      (Scalars<T>*)d->scalars, (T*)d->cfl_slot, d->adv_fresh);
+		                      (Scalars<T>*)d->scalars, (T*)d->cfl_slot, d->adv_fresh, box);
 		d->fork_is_advance = true;                                        // cleared by anything else queued on the stream
 	} else {
 		hipLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, p, (Scalars<T>*)d->scalars,
-		                   (T*)d->cfl_slot, d->adv_fresh);
+		                   (T*)d->cfl_slot, d->adv_fresh, box);
 	}
 	HIP_TRY(hipGetLastError());
 	d->use_alt ^= 1;                                                      // Threaded_runBatch :1300
@@ -801,6 +836,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	hipSetDevice(d->desc.device);
 	if (d->stream) hipStreamSynchronize(d->stream);
 	if (d->stream_halo) hipStreamSynchronize(d->stream_halo);
+	peer_release(d);
 	for (auto& b : d->bdy) { hipFree(b.data); hipFree(b.cells); }
 	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
@@ -1088,11 +1124,11 @@ int hp_update_timestep(hp_domain_t* d)
 	if (d->desc.precision == 8) {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
 		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
-		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, 1);
+		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, 1, PeerBox{});
 	} else {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
 		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
-		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, 1);
+		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, 1, PeerBox{});
 	}
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
@@ -1153,7 +1189,14 @@ int hp_read_scalars(hp_domain_t* d, hp_scalars_t* out)
 	if (rc != HP_OK) return rc;
 	if (!out) return fail(HP_ERR_INVALID, "out == NULL");
 	HIP_TRY(hipMemcpyAsync(d->host_scalars, d->scalars, 128, hipMemcpyDeviceToHost, d->stream));
+	uint64_t* peer_error = (uint64_t*)((char*)d->host_scalars + 480);
+	*peer_error = 0;
+	if (d->peer_agreed)                      // the mailboxes' sticky error word: a strip that was not heard from in time
+		HIP_TRY(hipMemcpyAsync(peer_error, d->peer_mine + PEER_WORD_ERROR, 8, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
+	if (*peer_error)
+		return fail(HP_ERR_HIP, "the maximum over the strips is incomplete: rank " + std::to_string((long)*peer_error - 1) +
+		                        " was not heard from within the time limit (HP_PEER_TIMEOUT_MS)");
 	if (d->desc.precision == 8) {
 		const Scalars<double>* s = (const Scalars<double>*)d->host_scalars;
 		out->time = s->t; out->timestep = s->dt; out->time_hydrological = s->t_hydro; out->time_target = s->t_sync;
@@ -1284,7 +1327,10 @@ template <typename T> __global__ void copy_scalar(T* to, const T* from) { *to = 
 // rank whose own buffer was not priced this iteration contributes the local maximum it remembers.
 int strip_allreduce_max(hp_domain* d, bool first_of_batch)
 {
-	if (!d->desc.dynamic_dt || d->comm_world <= 1) return HP_OK;
+	// (measurement knob, tools/strong_probe.py: a communicator of ONE rank normally skips the reduction; with the knob it goes
+	// through it -- the library's all-reduce or its own mailbox -- so that the cost of the step can be timed on one GPU)
+	static const bool lonely_too = std::getenv("HP_STRIP_REDUCE_ALWAYS") && std::atoi(std::getenv("HP_STRIP_REDUCE_ALWAYS")) != 0;
+	if (!d->desc.dynamic_dt || (d->comm_world <= 1 && !lonely_too)) return HP_OK;
 	const bool q1 = (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0, muscl = d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK;
 	const bool basic = d->desc.kernel == HP_KERNEL_BASIC && d->desc.scheme == HP_SCHEME_GODUNOV;
 	const bool dst_is_primary = d->use_alt == 1;
@@ -1299,6 +1345,10 @@ int strip_allreduce_max(hp_domain* d, bool first_of_batch)
 		if (d->desc.precision == 8) hipLaunchKernelGGL(copy_scalar<double>, dim3(1), dim3(1), 0, d->stream, (double*)d->cfl_slot, (const double*)d->cfl_slot + SLOT_LOCAL);
 		else                        hipLaunchKernelGGL(copy_scalar<float>, dim3(1), dim3(1), 0, d->stream, (float*)d->cfl_slot, (const float*)d->cfl_slot + SLOT_LOCAL);
 		HIP_TRY(hipGetLastError());
+	}
+	if (d->peer_agreed) {                                              // the advance kernel itself trades the values with the peers
+		d->adv_fresh = 7;
+		return HP_OK;
 	}
 	RCCL_TRY(g_rccl.AllReduce(d->cfl_slot, (char*)d->cfl_slot + (size_t)SLOT_GLOBAL * d->esize, 1, type, ncclMax, d->comm, d->stream));
 	d->adv_fresh = 3;                                                  // advance_time: take the maximum from SLOT_GLOBAL
@@ -1333,6 +1383,53 @@ int strip_handshake(hp_domain* d)
 	if (all[4] != -all[5] || all[6] != -all[7]) return fail(HP_ERR_STATE, "the strips disagree on their ghost rows");
 	d->strip_any_bdy = all[0] > 0.0;
 	d->strip_any_full = all[1] > 0.0;
+	return HP_OK;
+}
+
+// ---- peer-written mailboxes: set-up and tear-down ----
+struct PeerTicket {                     // HP_PEER_TICKET_BYTES, travels between the ranks by the host's own means
+	uint64_t          magic;
+	uint64_t          process;          // a number drawn once per process: same number = same address space
+	uint64_t          address;          // the mailbox in its owner's address space
+	int32_t           device, rank;
+	hipIpcMemHandle_t handle;           // for everybody else
+	unsigned char     pad[HP_PEER_TICKET_BYTES - 32 - sizeof(hipIpcMemHandle_t)];
+};
+static_assert(sizeof(PeerTicket) == HP_PEER_TICKET_BYTES, "HP_PEER_TICKET_BYTES");
+constexpr uint64_t PEER_MAGIC = 0x68702d7065657231ull;           // "hp-peer1"
+
+uint64_t process_token()
+{
+	static const uint64_t token = [] {
+		std::random_device rd;
+		return ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)getpid() << 20);
+	}();
+	return token;
+}
+
+void peer_release(hp_domain* d)
+{
+	d->peer_agreed = false;
+	if (!d->peer_mine && !d->peer_table && d->peer_mapped.empty()) return;
+	if (d->stream) hipStreamSynchronize(d->stream);
+	for (void* m : d->peer_mapped) hipIpcCloseMemHandle(m);
+	d->peer_mapped.clear();
+	if (d->peer_table) { hipFree(d->peer_table); d->peer_table = nullptr; }
+	if (d->peer_mine)  { hipFree(d->peer_mine);  d->peer_mine = nullptr; }
+	d->peer_world = 0; d->peer_rank = 0; d->peer_rounds = 0;
+}
+
+// one reduction of a caller-given value through the mailboxes, result and error word read back
+int peer_round_now(hp_domain* d, double value, long timeout_ms, double* result, uint64_t* error)
+{
+	const PeerBox box = peer_box(d, true, timeout_ms);
+	hipLaunchKernelGGL(peer_round, dim3(1), dim3(64), 0, d->stream, box, value);
+	HIP_TRY(hipGetLastError());
+	uint64_t* pinned = (uint64_t*)((char*)d->host_scalars + 480);
+	HIP_TRY(hipMemcpyAsync(pinned, d->peer_mine + PEER_WORD_ERROR, 16, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	*error = pinned[0];
+	std::memcpy(result, &pinned[1], 8);
 	return HP_OK;
 }
 } // namespace
@@ -1379,6 +1476,7 @@ int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out)
 	out->comm_rank = d->comm_rank;
 	out->halo_overlap = d->halo_overlap ? 1 : 0;
 	out->ghost_rows = (int32_t)d->ghost_rows;
+	out->peer_max = d->peer_agreed ? 1 : 0;
 	if (d->comm && g_rccl.CommCount) {
 		int n = -1;
 		RCCL_TRY(g_rccl.CommCount(d->comm, &n));
@@ -1422,6 +1520,7 @@ int hp_strip_comm_init(hp_domain_t* d, const void* id, int rank, int world)
 int hp_strip_comm_destroy(hp_domain_t* d)
 {
 	if (!d) return HP_OK;
+	peer_release(d);
 	if (d->comm) {
 		hipStreamSynchronize(d->stream);
 		if (d->stream_halo) hipStreamSynchronize(d->stream_halo);
@@ -1429,6 +1528,131 @@ int hp_strip_comm_destroy(hp_domain_t* d)
 		d->comm = nullptr;
 	}
 	d->comm_world = 1; d->comm_rank = 0;
+	return HP_OK;
+}
+
+// ---- the maximum over all strips without a collective: peer-written mailboxes (PeerBox, hp_kernels.hpp) ----
+int hp_strip_peer_ticket(hp_domain_t* d, void* ticket_out)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!ticket_out) return fail(HP_ERR_INVALID, "ticket_out == NULL");
+	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	peer_release(d);
+	// uncached: a peer's store must be what this device's next load sees, whichever cache it would have sat in
+	void* box = nullptr;
+	HIP_TRY(hipExtMallocWithFlags(&box, PEER_WORDS * sizeof(unsigned long long), hipDeviceMallocUncached));
+	d->peer_mine = (unsigned long long*)box;
+	HIP_TRY(hipMemsetAsync(d->peer_mine, 0xff, 2 * PEER_MAX_RANKS * sizeof(unsigned long long), d->stream));       // every word EMPTY
+	HIP_TRY(hipMemsetAsync(d->peer_mine + PEER_WORD_ERROR, 0, (PEER_WORDS - PEER_WORD_ERROR) * sizeof(unsigned long long), d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));                            // ... before anybody learns where it is
+	PeerTicket t;
+	std::memset(&t, 0, sizeof t);
+	t.magic = PEER_MAGIC; t.process = process_token(); t.address = (uint64_t)(uintptr_t)d->peer_mine;
+	t.device = d->desc.device; t.rank = -1;
+	if (hipIpcGetMemHandle(&t.handle, d->peer_mine) != hipSuccess) {
+		(void)hipGetLastError();                                         // other processes cannot map it; ranks of THIS process still can
+		std::memset(&t.handle, 0, sizeof t.handle);
+	}
+	std::memcpy(ticket_out, &t, sizeof t);
+	return HP_OK;
+}
+
+int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int rank, int* active)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (active) *active = 0;
+	if (!tickets || count < 1 || count > PEER_MAX_RANKS || rank < 0 || rank >= count)
+		return fail(HP_ERR_INVALID, "bad mailbox arguments (1.." + std::to_string(PEER_MAX_RANKS) + " ranks)");
+	if (!d->peer_mine) return fail(HP_ERR_STATE, "hp_strip_peer_connect without hp_strip_peer_ticket");
+	if (d->comm && (count != d->comm_world || rank != d->comm_rank))
+		return fail(HP_ERR_INVALID, "mailbox ranks do not match the communicator's");
+	const PeerTicket* t = (const PeerTicket*)tickets;
+	if (t[rank].magic != PEER_MAGIC || t[rank].address != (uint64_t)(uintptr_t)d->peer_mine || t[rank].process != process_token())
+		return fail(HP_ERR_INVALID, "tickets[rank] is not this domain's ticket");
+	// map every peer's mailbox; a failure here is not an error of the call: the connection test below fails on every
+	// rank alike (the others never hear from this one) and the run stays on the collective
+	std::vector<unsigned long long*> table((size_t)count, nullptr);
+	bool mapped = true;
+	std::string why;
+	for (int r = 0; r < count && mapped; ++r) {
+		if (t[r].magic != PEER_MAGIC) { mapped = false; why = "ticket " + std::to_string(r) + " is not a ticket"; break; }
+		if (t[r].process == process_token()) {                           // same address space (ranks as threads, or one process driving several GPUs)
+			table[(size_t)r] = (unsigned long long*)(uintptr_t)t[r].address;
+			if (t[r].device != d->desc.device) {
+				const hipError_t e = hipDeviceEnablePeerAccess(t[r].device, 0);
+				if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { mapped = false; why = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); }
+				(void)hipGetLastError();
+			}
+		} else {
+			void* m = nullptr;
+			const hipError_t e = hipIpcOpenMemHandle(&m, t[r].handle, hipIpcMemLazyEnablePeerAccess);
+			if (e != hipSuccess) { (void)hipGetLastError(); mapped = false; why = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e); }
+			else { d->peer_mapped.push_back(m); table[(size_t)r] = (unsigned long long*)m; }
+		}
+	}
+	d->peer_world = count; d->peer_rank = rank; d->peer_rounds = 0;
+	uint64_t error = 1;
+	double got = 0.0;
+	if (mapped) {
+		if (!d->peer_table) HIP_TRY(hipMalloc((void**)&d->peer_table, PEER_MAX_RANKS * sizeof(unsigned long long*)));
+		HIP_TRY(hipMemcpy(d->peer_table, table.data(), (size_t)count * sizeof(unsigned long long*), hipMemcpyHostToDevice));
+		// connection test: two reductions (one per mailbox set) of rank + 1 and -(rank + 1) must give `count` and -1
+		const long test_ms = std::getenv("HP_PEER_TEST_MS") ? std::atol(std::getenv("HP_PEER_TEST_MS")) : 3000;
+		if ((rc = peer_round_now(d, (double)(rank + 1), test_ms, &got, &error)) != HP_OK) return rc;
+		bool ok = error == 0 && got == (double)count;
+		if (ok) {
+			if ((rc = peer_round_now(d, -(double)(rank + 1), test_ms, &got, &error)) != HP_OK) return rc;
+			ok = error == 0 && got == -1.0;
+		}
+		if (!ok && why.empty()) why = error ? "rank " + std::to_string((long)error - 1) + " was not heard from" : "wrong maximum";
+		error = ok ? 0 : 1;
+	}
+	if (error) log_line(HP_LOG_WARNING, "peer-written maximum not available on rank " + std::to_string(rank) + ": " + why);
+	if (d->comm && d->comm_world > 1) {
+		// every rank must take the same road: one MAX over the ranks' verdicts through the collective library
+		char* slot = (char*)d->cfl_slot + (size_t)SLOT_HANDSHAKE * d->esize;
+		char* pinned = (char*)d->host_scalars + 256;
+		const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
+		if (d->desc.precision == 8) { const double v = error ? 1.0 : 0.0; std::memcpy(pinned, &v, 8); }
+		else                        { const float v = error ? 1.0f : 0.0f; std::memcpy(pinned, &v, 4); }
+		HIP_TRY(hipMemcpyAsync(slot, pinned, d->esize, hipMemcpyHostToDevice, d->stream));
+		RCCL_TRY(g_rccl.AllReduce(slot, slot + 8 * d->esize, 1, type, ncclMax, d->comm, d->stream));
+		HIP_TRY(hipMemcpyAsync(pinned + 128, slot + 8 * d->esize, d->esize, hipMemcpyDeviceToHost, d->stream));
+		HIP_TRY(hipStreamSynchronize(d->stream));
+		double any = 0.0;
+		if (d->desc.precision == 8) std::memcpy(&any, pinned + 128, 8);
+		else { float f; std::memcpy(&f, pinned + 128, 4); any = f; }
+		d->peer_agreed = any == 0.0;
+		if (active) *active = d->peer_agreed ? 1 : 0;
+		if (!d->peer_agreed) peer_release(d);
+	} else {
+		// no communicator: nothing to agree through (diagnostic use, hp_strip_peer_round); the strip loop is not touched
+		if (active) *active = error ? 0 : 1;
+		if (error) peer_release(d);
+	}
+	return HP_OK;
+}
+
+int hp_strip_peer_round(hp_domain_t* d, double value, double* max_out)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!max_out) return fail(HP_ERR_INVALID, "max_out == NULL");
+	if (!d->peer_mine || !d->peer_table || d->peer_world < 1) return fail(HP_ERR_STATE, "no mailboxes connected");
+	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	uint64_t error = 0;
+	if ((rc = peer_round_now(d, value, 0, max_out, &error)) != HP_OK) return rc;
+	if (error) return fail(HP_ERR_HIP, "peer-written maximum: rank " + std::to_string((long)error - 1) + " was not heard from in time");
+	return HP_OK;
+}
+
+int hp_strip_peer_disconnect(hp_domain_t* d)
+{
+	if (!d) return HP_OK;
+	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	peer_release(d);
 	return HP_OK;
 }
 
@@ -1484,15 +1708,17 @@ int hp_strip_update_timestep(hp_domain_t* d)
 	} else {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
 	}
-	const bool reduced = d->desc.dynamic_dt && d->comm_world > 1;
-	if (reduced)
+	const bool reduced = d->desc.dynamic_dt && d->comm_world > 1, by_peers = reduced && d->peer_agreed;
+	if (reduced && !by_peers)
 		RCCL_TRY(g_rccl.AllReduce(d->cfl_slot, (char*)d->cfl_slot + (size_t)SLOT_GLOBAL * d->esize, 1, type, ncclMax, d->comm, d->stream));
+	const int fresh = by_peers ? 7 : reduced ? 3 : 1;
+	const PeerBox box = peer_box(d, by_peers);
 	if (d->desc.precision == 8)
 		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
-		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, reduced ? 3 : 1);
+		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, fresh, box);
 	else
 		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
-		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, reduced ? 3 : 1);
+		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, fresh, box);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }

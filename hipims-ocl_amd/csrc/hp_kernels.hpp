@@ -131,11 +131,98 @@ __device__ __forceinline__ void advance_body(const Params<T>& p, Scalars<T>* sc,
 	sc->batch_ok = ok; sc->batch_skipped = skipped;
 }
 
-template <bool UPDATE_ONLY, typename T>
-__global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const int fresh)
+// -------------------------------------------------------------------------------------------------
+// The maximum over all strips, written by the strips themselves ("one-shot all-gather-to-all over direct
+// links, then a local max"; stands where the reference's MPI_Allreduce is, MPI/CMPIManager.cpp:852-861).
+//
+//   Every rank owns a MAILBOX in uncached device memory that its peers address directly (xGMI peer access, through
+//   an IPC mapping when the peer is another process): 2 sets x 64 words, word [set][r] written by rank r only.  A
+//   reduction is one pass of the advance kernel's wavefront: lane r stores this rank's value into rank r's mailbox
+//   (one 8-byte system-scope store per peer), then polls its own mailbox's word r until rank r's value has arrived,
+//   empties it, and the wavefront folds the 64 lanes.  No collective kernel, no launch besides the advance kernel
+//   that runs anyway.
+//
+//   Two sets are enough: rank P can only write reduction n+2 after it has finished reduction n+1, which needs THIS
+//   rank's value n+1, which this rank publishes (release) after it emptied set n%2 in reduction n -- so the write
+//   of n+2 is ordered behind the emptying it must not precede.
+//
+//   The poll is bounded: a peer that never shows up (a rank that died, a mapping that does not do what it should)
+//   raises the mailbox's sticky error word instead of hanging the GPU; later reductions then return at once and the
+//   host reads the error with the scalars (hp_read_scalars).
+// -------------------------------------------------------------------------------------------------
+constexpr int PEER_MAX_RANKS = 64, PEER_WORD_ERROR = 2 * PEER_MAX_RANKS, PEER_WORD_RESULT = PEER_WORD_ERROR + 1,
+              PEER_WORDS = PEER_WORD_ERROR + 8;
+constexpr unsigned long long PEER_EMPTY = ~0ull;       // no finite value, and not the NaN arithmetic produces
+
+struct PeerBox {
+	unsigned long long*        mine;      // this rank's mailbox
+	unsigned long long* const* peer;      // device table: rank r's mailbox as this device addresses it
+	int                        world, rank, set;
+	unsigned long long         timeout;   // wall_clock64 ticks (100 MHz)
+};
+
+__device__ __forceinline__ unsigned long long peer_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned long long peer_bits(float v)  { return (unsigned long long)__float_as_uint(v); }
+__device__ __forceinline__ void peer_value(unsigned long long w, double& v) { v = __longlong_as_double((long long)w); }
+__device__ __forceinline__ void peer_value(unsigned long long w, float& v)  { v = __uint_as_float((unsigned)w); }
+
+__device__ __forceinline__ double atomic_peek(double* s)
 {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	advance_body<UPDATE_ONLY>(p, sc, slot, fresh);
+	return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float atomic_peek(float* s)
+{
+	return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// all 64 lanes of one wavefront; returns the maximum over the ranks' values (wave_max's `>`: a NaN never wins)
+template <typename T>
+__device__ __forceinline__ T peer_reduce_max(const PeerBox& box, const T local)
+{
+	const int lane = threadIdx.x & 63;
+	T v = local;
+	if (lane < box.world) {
+		unsigned long long* inbox = box.mine + box.set * PEER_MAX_RANKS + lane;
+		__hip_atomic_store(box.peer[lane] + box.set * PEER_MAX_RANKS + box.rank, peer_bits(local), __ATOMIC_RELEASE,
+		                   __HIP_MEMORY_SCOPE_SYSTEM);
+		const bool broken = __hip_atomic_load(box.mine + PEER_WORD_ERROR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+		const unsigned long long t0 = wall_clock64();
+		unsigned long long w;
+		for (;;) {
+			w = __hip_atomic_load(inbox, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+			if (w != PEER_EMPTY) break;
+			if (broken || wall_clock64() - t0 > box.timeout) break;
+			__builtin_amdgcn_s_sleep(1);
+		}
+		if (w != PEER_EMPTY) {
+			__hip_atomic_store(inbox, PEER_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			peer_value(w, v);
+		} else {
+			__hip_atomic_store(box.mine + PEER_WORD_ERROR, 1ull + (unsigned long long)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+	return wave_max(v);
+}
+
+// fresh bit 2: the maximum over all strips comes through the mailboxes (this kernel puts it where bit 1 says it is)
+template <bool UPDATE_ONLY, typename T>
+__global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const int fresh, const PeerBox box)
+{
+	if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+	if (fresh & 4) {
+		const T local = atomic_peek(slot);            // slot[0] is only ever touched by memory-side atomics
+		const T all = peer_reduce_max(box, local);
+		if (threadIdx.x == 0) slot[SLOT_GLOBAL] = all;
+	}
+	if (threadIdx.x != 0) return;
+	advance_body<UPDATE_ONLY>(p, sc, slot, fresh & 3);
+}
+
+// diagnostic / connection test: one reduction of a caller-given word (hp_strip_peer_round)
+__global__ void peer_round(const PeerBox box, const double value)
+{
+	const double all = peer_reduce_max(box, value);
+	if (threadIdx.x == 0) box.mine[PEER_WORD_RESULT] = peer_bits(all);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -34,7 +34,8 @@ EXPORTS = [
     "hp_force_timestep", "hp_reset_counters", "hp_update_timestep", "hp_step_batch", "hp_read_scalars",
     "hp_sync", "hp_is_busy", "hp_step_begin", "hp_step_end", "hp_step_needs_reduction", "hp_device_ptr", "hp_stream", "hp_set_halo_overlap",
     "hp_stream_halo", "hp_comm_load", "hp_comm_unique_id", "hp_strip_comm_init", "hp_strip_step_batch", "hp_strip_update_timestep",
-    "hp_strip_comm_destroy", "hp_strip_info", "hp_timer_start",
+    "hp_strip_comm_destroy", "hp_strip_info", "hp_strip_peer_ticket", "hp_strip_peer_connect", "hp_strip_peer_round",
+    "hp_strip_peer_disconnect", "hp_timer_start",
     "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read",
 ]
 
@@ -77,7 +78,7 @@ class DomainDesc(C.Structure):
 
 class StripInfo(C.Structure):
     _fields_ = [("library", C.c_char * 256), ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32),
-                ("halo_overlap", C.c_int32), ("ghost_rows", C.c_int32)]
+                ("halo_overlap", C.c_int32), ("ghost_rows", C.c_int32), ("peer_max", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class ScalarsOut(C.Structure):
@@ -150,6 +151,10 @@ def load_library(path: str | None = None):
     lib.hp_strip_update_timestep.argtypes = [C.c_void_p]
     lib.hp_strip_comm_destroy.argtypes = [C.c_void_p]
     lib.hp_strip_info.argtypes = [C.c_void_p, C.POINTER(StripInfo)]
+    lib.hp_strip_peer_ticket.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hp_strip_peer_connect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    lib.hp_strip_peer_round.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double)]
+    lib.hp_strip_peer_disconnect.argtypes = [C.c_void_p]
     lib.hp_timer_start.argtypes = [C.c_void_p]
     lib.hp_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.hp_kernel_timing.argtypes = [C.c_void_p, C.c_int]
@@ -166,6 +171,7 @@ def _check(lib, rc, what):
 
 
 COMM_ID_BYTES = 128
+PEER_TICKET_BYTES = 128
 
 
 def comm_load(path: str | None = None):
@@ -377,7 +383,29 @@ class Domain:
         info = StripInfo()
         _check(self.lib, self.lib.hp_strip_info(self.h, C.byref(info)), "hp_strip_info")
         return dict(library=info.library.decode(errors="replace"), comm_ranks=info.comm_ranks, comm_rank=info.comm_rank,
-                    halo_overlap=bool(info.halo_overlap), ghost_rows=info.ghost_rows)
+                    halo_overlap=bool(info.halo_overlap), ghost_rows=info.ghost_rows, peer_max=bool(info.peer_max))
+
+    # ---- the maximum over the strips through peer-written mailboxes (hp_strip_peer_*) ----
+    def strip_peer_ticket(self) -> bytes:
+        buf = C.create_string_buffer(PEER_TICKET_BYTES)
+        _check(self.lib, self.lib.hp_strip_peer_ticket(self.h, buf), "hp_strip_peer_ticket")
+        return buf.raw
+
+    def strip_peer_connect(self, tickets, rank) -> bool:
+        """`tickets`: every rank's ticket, in rank order.  Collective.  True: the mailboxes are in use from now on."""
+        blob = b"".join(tickets)
+        assert len(blob) == PEER_TICKET_BYTES * len(tickets)
+        active = C.c_int(0)
+        _check(self.lib, self.lib.hp_strip_peer_connect(self.h, blob, len(tickets), int(rank), C.byref(active)), "hp_strip_peer_connect")
+        return bool(active.value)
+
+    def strip_peer_round(self, value: float) -> float:
+        out = C.c_double(0.0)
+        _check(self.lib, self.lib.hp_strip_peer_round(self.h, float(value), C.byref(out)), "hp_strip_peer_round")
+        return out.value
+
+    def strip_peer_disconnect(self):
+        _check(self.lib, self.lib.hp_strip_peer_disconnect(self.h), "hp_strip_peer_disconnect")
 
     def strip_comm_destroy(self):
         _check(self.lib, self.lib.hp_strip_comm_destroy(self.h), "hp_strip_comm_destroy")

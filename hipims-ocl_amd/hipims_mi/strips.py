@@ -222,6 +222,13 @@ class StripRunner:
             if world > 1:
                 dist.broadcast_object_list(box, src=0)        # the id travels by the host's own means (here: torch)
             self.domain.strip_comm_init(box[0], rank, world)
+            # the maximum over the strips: peer-written mailboxes where every rank can reach every other one's (the
+            # library tests that and the ranks agree), the collective library's all-reduce otherwise
+            self.peer_max = False
+            if world > 1 and os.environ.get("HIPIMS_MI_PEER_MAX", "1") != "0":
+                tickets = [None] * world
+                dist.all_gather_object(tickets, self.domain.strip_peer_ticket())
+                self.peer_max = self.domain.strip_peer_connect(tickets, rank)
         self.south = rank - 1 if rank > 0 else None
         self.north = rank + 1 if rank < world - 1 else None
         self.staged = engine_factory is None and backend == "gloo"      # device buffers, host transport (rehearsal)

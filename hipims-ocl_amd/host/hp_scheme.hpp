@@ -74,6 +74,12 @@ public:
 	// inside the library (hp_strip_step_batch).  Every rank must ask for the same batch sizes: the automatic queue
 	// (sized from each process's own wall clock) is off in this mode.
 	void   setStrip(int rank, int world, const void* commId, long globalRows, long rowOffset);
+	// The maximum over the strips through peer-written mailboxes instead of the collective library's all-reduce
+	// (hp_strip_peer_*): after prepareAll every rank hands out its ticket (HP_PEER_TICKET_BYTES), the host gathers them in
+	// rank order -- as it distributed commId -- and every rank calls connectPeers with all of them.  Returns whether the
+	// mailboxes are in use (all ranks get the same answer; false = the all-reduce stays).
+	bool   getPeerTicket(void* ticketOut);
+	bool   connectPeers(const void* tickets);
 	// model::doError's place (main.cpp:631-652): every failure of the library is also handed to this sink
 	static void setLogSink(hp_log_sink_t sink, void* user) { hp_set_log_sink(sink, user); }
 

@@ -52,6 +52,10 @@ int main(int argc, char** argv)
 	std::vector<unsigned> iters(outputs, 0);
 	std::vector<int> failed(world, 0);
 	Rendezvous meet; meet.world = world;
+	// the maximum over the strips: peer-written mailboxes unless HIPIMS_MI_PEER_MAX=0 (then the collective library's all-reduce)
+	const bool peer_max = !(std::getenv("HIPIMS_MI_PEER_MAX") && std::atoi(std::getenv("HIPIMS_MI_PEER_MAX")) == 0) && world > 1;
+	std::vector<char> tickets((size_t)world * HP_PEER_TICKET_BYTES, 0);
+	std::vector<int> peers_active(world, 0);
 
 	auto rank_main = [&](const int r) {
 		const long own_lo = (long)r * rows / world, own_hi = (long)(r + 1) * rows / world;
@@ -75,8 +79,10 @@ int main(int argc, char** argv)
 		scheme.setStrip(r, world, id, rows, lo);
 		scheme.prepareAll();
 		if (!scheme.isReady()) { std::fprintf(stderr, "rank %d prepareAll failed: %s\n", r, scheme.lastError().c_str()); failed[r] = 1; }
-		meet.wait();
+		if (peer_max && !failed[r] && !scheme.getPeerTicket(&tickets[(size_t)r * HP_PEER_TICKET_BYTES])) failed[r] = 1;
+		meet.wait();                                            // (the tickets have travelled: shared memory stands in for the host's broadcast)
 		if (std::any_of(failed.begin(), failed.end(), [](int f) { return f != 0; })) return;
+		if (peer_max) peers_active[r] = scheme.connectPeers(tickets.data()) ? 1 : 0;
 		scheme.prepareSimulation();
 
 		double target = freq;
@@ -112,6 +118,8 @@ int main(int argc, char** argv)
 	for (int r = 0; r < world; ++r) threads.emplace_back(rank_main, r);
 	for (auto& t : threads) t.join();
 	if (std::any_of(failed.begin(), failed.end(), [](int f) { return f != 0; })) return 3;
+	std::fprintf(stderr, "maximum over the strips: %s\n", peer_max && std::all_of(peers_active.begin(), peers_active.end(), [](int a) { return a != 0; })
+	                                                          ? "peer-written mailboxes" : "all-reduce");
 	for (int o = 0; o < outputs; ++o) {
 		double v = 0.0, s = 0.0;
 		for (int r = 0; r < world; ++r) { v += vol[r][o]; s += sum[r][o]; }

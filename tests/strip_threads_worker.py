@@ -2,7 +2,7 @@
 per-iteration strip loop -- with WORLD ranks that are threads of this process sharing the one GPU, over the in-process
 test double of the collective library (tests/fake_rccl), and compares the gathered strips with the single domain
 bit for bit.   usage: strip_threads_worker.py <world> <scheme 0|1|2> <f64|f32> <overlap 0|1> <rain 0|1> [exchange period 1|2]
-[boundary on rank k only: -1 = on all]"""
+[boundary on rank k only: -2 = no cell boundary] [maximum over the strips: 1 = peer-written mailboxes (default), 0 = all-reduce]"""
 import os
 import sys
 import threading
@@ -10,6 +10,9 @@ import threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hipims-ocl_amd")]
 os.environ["HIPIMS_MI_NO_TORCH"] = "1"
+# every rank's streams on hardware queues of their own: a rank's advance kernel WAITS for the other ranks' kernels, which
+# must not sit behind it in a shared queue (one process per GPU in production; here up to 4 ranks x 2 streams share one)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np  # noqa: E402
 
 import hipims_mi as hp  # noqa: E402
@@ -18,6 +21,7 @@ from hipims_mi import strips, synthetic as syn  # noqa: E402
 world, scheme, precision, overlap, rain_on = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
 period = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 cell_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -2          # >= 0: a cell boundary that only THAT rank is told about
+peer_max = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 cols, rows, steps = 300, 157, 90
 real = np.float64 if precision == "f64" else np.float32
 g = strips.ghost_rows(scheme) * period                             # ghost rows stored per interior side
@@ -56,6 +60,7 @@ hp._check(lib, lib.hp_comm_load(os.path.join(ROOT, "tests", "fake_rccl", "libfak
 uid = hp.comm_unique_id()
 got, scal, errors = [None] * world, [None] * world, []
 start = threading.Barrier(world)
+tickets, peers_active = [None] * world, [None] * world
 
 
 def rank_main(r):
@@ -69,6 +74,11 @@ def rank_main(r):
         info = dom.strip_info()                           # an explicit choice survives comm_init
         assert info["halo_overlap"] == bool(overlap) and info["comm_rank"] == r and info["ghost_rows"] == g, info
         dom.set_target_time(1e9)
+        if peer_max:
+            tickets[r] = dom.strip_peer_ticket()
+            start.wait()                                  # the tickets travel "by the host's own means"
+            peers_active[r] = dom.strip_peer_connect(tickets, r)
+            assert peers_active[r] and dom.strip_info()["peer_max"], "mailboxes not connected"
         start.wait()
         dom.strip_update_timestep()                       # tst_Reduce + all-reduce + tst_UpdateTimestep, as after any upload
         for n in (1, 2, steps - 3):                       # odd and even batch lengths: both ping-pong phases at batch ends
@@ -100,6 +110,6 @@ if not same:
     print("differing cells:", len(bad), "rows", sorted(set(bad[:, 0].tolist()))[:20], "cols", sorted(set(bad[:, 1].tolist()))[:12],
           "strip edges", [pp[:2] for pp in parts], flush=True)
 times = {(s["time"], s["timestep"]) for s in scal}
-print("ranks", world, "scheme", scheme, precision, "overlap", overlap, "rain", rain_on, "period", period, "cell boundary on rank", cell_rank, "bit-identical", same, "times", times,
+print("ranks", world, "scheme", scheme, precision, "overlap", overlap, "rain", rain_on, "period", period, "cell boundary on rank", cell_rank, "peer-written maximum", peers_active, "bit-identical", same, "times", times,
       "single", (want_sc["time"], want_sc["timestep"]), flush=True)
 os._exit(0 if same and times == {(want_sc["time"], want_sc["timestep"])} else 1)

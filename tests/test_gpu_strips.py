@@ -247,6 +247,7 @@ def test_bench_line_names_the_collective_library_on_the_cxx_loop():
     assert "rccl" in info["library"] and info["comm_ranks"] == 1 and info["comm_rank"] == 0
 
 
+@pytest.mark.parametrize("peer_max", [1, 0])
 @pytest.mark.parametrize("world,scheme,precision,overlap,rain,period,cell_rank", [
     (2, hp.SCHEME_GODUNOV, "f64", 1, 0, 1, -2), (3, hp.SCHEME_GODUNOV, "f64", 0, 0, 1, -2), (4, hp.SCHEME_GODUNOV, "f32", 1, 1, 1, -2),
     (2, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 1, -2), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 1, -2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 1, -2),
@@ -256,12 +257,14 @@ def test_bench_line_names_the_collective_library_on_the_cxx_loop():
     (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 2, -2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 2, -2), (3, hp.SCHEME_GODUNOV, "f64", 1, 1, 2, -2),
     # a cell boundary that only the strip holding its cells is told about: the other ranks must still enter every collective
     (3, hp.SCHEME_GODUNOV, "f64", 1, 0, 1, 1), (3, hp.SCHEME_GODUNOV, "f64", 1, 0, 2, 2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 2, 0)])
-def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, rain, period, cell_rank):
+def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, rain, period, cell_rank, peer_max):
     """hp_strip_step_batch / hp_strip_update_timestep with 2-4 REAL ranks: the ranks are threads of one process sharing
     the GPU, the collective library is the in-process test double tests/fake_rccl (RCCL itself refuses two ranks on
     one device).  Everything on the engine's side of the nine ncclXxx entry points is the production code: which rows
     are sent and received where, on which stream, behind which events, and which iterations all-reduce.  The gathered
-    strips must equal the single domain bit for bit, and every rank must report the single domain's time and dt."""
+    strips must equal the single domain bit for bit, and every rank must report the single domain's time and dt.
+    peer_max = 1: the maximum over the strips travels through the peer-written mailboxes (hp_strip_peer_*: the advance
+    kernels of the ranks write to and wait for each other); 0: through the (test double's) all-reduce."""
     import subprocess
     import sys
     lib = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
@@ -269,6 +272,51 @@ def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, ra
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", lib,
                                os.path.join(os.path.dirname(lib), "fake_rccl.cpp")])
     res = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "strip_threads_worker.py"), str(world),
-                          str(scheme), precision, str(overlap), str(rain), str(period), str(cell_rank)], capture_output=True, text=True, timeout=600)
+                          str(scheme), precision, str(overlap), str(rain), str(period), str(cell_rank), str(peer_max)],
+                         capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "bit-identical True" in res.stdout
+    assert ("peer-written maximum [True" in res.stdout) == bool(peer_max)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_mailboxes_between_processes(world, tmp_path):
+    """The peer-written maximum between PROCESSES: every rank maps the other ranks' mailboxes through IPC handles
+    (hipIpcGetMemHandle / hipIpcOpenMemHandle on uncached device memory), passes the library's connection test, and
+    200 reductions of known values come out right on every rank.  The ranks share the box's one GPU -- what this
+    cannot show is the xGMI hop between two GPUs; what it does show is that a store by another process's kernel is
+    seen by this process's polling kernel, in both mailbox sets, with the bounded wait never expiring."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HP_PEER_TEST_MS="20000")
+    procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "peer_ipc_worker.py"), str(r), str(world), str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append("TIMEOUT " + p.communicate()[0])
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("wrong maxima 0" in o for o in outs), "\n".join(outs)
+    print("\n".join(o.strip().splitlines()[-1] for o in outs))
+
+
+def test_peer_mailboxes_report_a_missing_rank_instead_of_hanging():
+    """A rank that never shows up: the connection test's bounded wait expires, the call says "not active" (and why, through
+    the log sink) and returns -- the GPU is not left spinning."""
+    import time
+    dom = hp.Domain(64, 64)
+    try:
+        mine = dom.strip_peer_ticket()
+        ghost = bytearray(mine)                       # "rank 1": a ticket for a mailbox nobody will ever write from -- this one's own
+        os.environ["HP_PEER_TEST_MS"] = "300"
+        t0 = time.perf_counter()
+        active = dom.strip_peer_connect([mine, bytes(ghost)], 0)
+        assert not active and time.perf_counter() - t0 < 5.0
+        with pytest.raises(hp.HipimsError):
+            dom.strip_peer_round(1.0)                 # nothing is connected any more
+    finally:
+        os.environ.pop("HP_PEER_TEST_MS", None)
+        dom.close()
