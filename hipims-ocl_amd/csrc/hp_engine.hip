@@ -148,6 +148,12 @@ struct hp_domain {
 	int              peer_world = 0, peer_rank = 0;
 	bool             peer_agreed = false;             // every rank of the communicator passed the connection test: the strip loop uses them
 	uint64_t         peer_rounds = 0;                 // reductions so far (its parity picks the mailbox set; the same on every rank)
+	// ghost rows written straight into the neighbours' state buffers (PeerPush): [side: 0 south, 1 north][ping-pong buffer]
+	void*            peer_state[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+	long             peer_rows[2] = {0, 0};           // the neighbours' local row counts
+	unsigned*        push_arrived = nullptr;          // device counter of the push blocks
+	bool             peer_direct = false;             // every rank reached its neighbours' buffers: no transfer library inside an iteration
+	bool             push_now = false;                // this iteration's advance kernel carries the ghost rows
 };
 
 namespace {
@@ -522,13 +528,36 @@ template <typename T> int step_end_impl(hp_domain* d)
 {
 	const Params<T> p = make_params<T>(d);
 	const PeerBox box = peer_box(d, (d->adv_fresh & 4) != 0);
-	if (d->halo_overlap) {                    // (also after an unsplit iteration: the NEXT one may be split and fork from here)
+	if (d->push_now) {
+		// the ghost rows travel inside the advance kernel (PeerPush): the first / last `ghost_rows` owned rows of the state
+		// this iteration wrote go into the neighbours' ghost rows of the same ping-pong buffer
+		const long G = d->ghost_rows, rows = d->desc.rows;
+		const size_t row_bytes = (size_t)d->desc.cols * 4 * d->esize;
+		const int b = d->use_alt ^ 1;
+		const char* mine = (const char*)d->state[b];
+		PeerPush push{};
+		push.count = (unsigned)((size_t)G * row_bytes / 16);
+		push.arrived = d->push_arrived;
+		if (d->peer_state[0][b]) {
+			push.from[0] = (const uint4*)(mine + (size_t)G * row_bytes);
+			push.to[0] = (uint4*)((char*)d->peer_state[0][b] + (size_t)(d->peer_rows[0] - G) * row_bytes);
+		}
+		if (d->peer_state[1][b]) {
+			push.from[1] = (const uint4*)(mine + (size_t)(rows - 2 * G) * row_bytes);
+			push.to[1] = (uint4*)d->peer_state[1][b];
+		}
+		const unsigned blocks = (push.to[0] || push.to[1]) ? std::min(32u, (push.count + 1023u) / 1024u) : 1u;
+		hipLaunchKernelGGL((advance_time<false, T>), dim3(blocks), dim3(256), 0, d->stream, p, (Scalars<T>*)d->scalars,
+		                   (T*)d->cfl_slot, d->adv_fresh, box, push);
+		d->push_now = false;
+		d->fork_is_advance = false;
+	} else if (d->halo_overlap && !d->peer_direct) {   // (also after an unsplit iteration: the NEXT one may be split and fork from here)
 		hipExtLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, nullptr, d->ev_fork, 0, p,
-		                      (Scalars<T>*)d->scalars, (T*)d->cfl_slot, d->adv_fresh, box);
+		                      (Scalars<T>*)d->scalars, (T*)d->cfl_slot, d->adv_fresh, box, PeerPush{});
 		d->fork_is_advance = true;                                        // cleared by anything else queued on the stream
 	} else {
 		hipLaunchKernelGGL((advance_time<false, T>), dim3(1), dim3(64), 0, d->stream, p, (Scalars<T>*)d->scalars,
-		                   (T*)d->cfl_slot, d->adv_fresh, box);
+		                   (T*)d->cfl_slot, d->adv_fresh, box, PeerPush{});
 	}
 	HIP_TRY(hipGetLastError());
 	d->use_alt ^= 1;                                                      // Threaded_runBatch :1300
@@ -1124,11 +1153,11 @@ int hp_update_timestep(hp_domain_t* d)
 	if (d->desc.precision == 8) {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
 		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
-		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, 1, PeerBox{});
+		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, 1, PeerBox{}, PeerPush{});
 	} else {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
 		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
-		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, 1, PeerBox{});
+		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, 1, PeerBox{}, PeerPush{});
 	}
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
@@ -1330,7 +1359,11 @@ int strip_allreduce_max(hp_domain* d, bool first_of_batch)
 	// (measurement knob, tools/strong_probe.py: a communicator of ONE rank normally skips the reduction; with the knob it goes
 	// through it -- the library's all-reduce or its own mailbox -- so that the cost of the step can be timed on one GPU)
 	static const bool lonely_too = std::getenv("HP_STRIP_REDUCE_ALWAYS") && std::atoi(std::getenv("HP_STRIP_REDUCE_ALWAYS")) != 0;
-	if (!d->desc.dynamic_dt || (d->comm_world <= 1 && !lonely_too)) return HP_OK;
+	if (d->comm_world <= 1 && !lonely_too) return HP_OK;
+	if (!d->desc.dynamic_dt) {
+		if (d->peer_direct) d->adv_fresh = 4;                          // fixed timestep: nothing to reduce, the round still hands the rows over
+		return HP_OK;
+	}
 	const bool q1 = (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0, muscl = d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK;
 	const bool basic = d->desc.kernel == HP_KERNEL_BASIC && d->desc.scheme == HP_SCHEME_GODUNOV;
 	const bool dst_is_primary = d->use_alt == 1;
@@ -1338,6 +1371,7 @@ int strip_allreduce_max(hp_domain* d, bool first_of_batch)
 	if (!everyone) {
 		if (d->adv_fresh) return fail(HP_ERR_STATE, "a strip priced a new maximum on an iteration the other ranks do not reduce "
 		                                            "(boundaries or uploads changed inside a batch?)");
+		if (d->peer_direct) d->adv_fresh = 4;                          // a round all the same: it is what hands the ghost rows over (PeerPush)
 		return HP_OK;
 	}
 	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
@@ -1392,8 +1426,12 @@ struct PeerTicket {                     // HP_PEER_TICKET_BYTES, travels between
 	uint64_t          process;          // a number drawn once per process: same number = same address space
 	uint64_t          address;          // the mailbox in its owner's address space
 	int32_t           device, rank;
-	hipIpcMemHandle_t handle;           // for everybody else
-	unsigned char     pad[HP_PEER_TICKET_BYTES - 32 - sizeof(hipIpcMemHandle_t)];
+	hipIpcMemHandle_t handle;           // ... and for everybody else
+	uint64_t          state[2];         // the two state buffers (the strip neighbours write their ghost rows), likewise
+	hipIpcMemHandle_t state_handle[2];
+	int64_t           rows, cols, ghost_rows, row_offset;
+	int32_t           precision, state_shareable;
+	unsigned char     pad[HP_PEER_TICKET_BYTES - 32 - 3 * sizeof(hipIpcMemHandle_t) - 16 - 32 - 8];
 };
 static_assert(sizeof(PeerTicket) == HP_PEER_TICKET_BYTES, "HP_PEER_TICKET_BYTES");
 constexpr uint64_t PEER_MAGIC = 0x68702d7065657231ull;           // "hp-peer1"
@@ -1410,10 +1448,13 @@ uint64_t process_token()
 void peer_release(hp_domain* d)
 {
 	d->peer_agreed = false;
-	if (!d->peer_mine && !d->peer_table && d->peer_mapped.empty()) return;
+	if (!d->peer_mine && !d->peer_table && d->peer_mapped.empty() && !d->push_arrived) return;
 	if (d->stream) hipStreamSynchronize(d->stream);
 	for (void* m : d->peer_mapped) hipIpcCloseMemHandle(m);
 	d->peer_mapped.clear();
+	d->peer_direct = false; d->push_now = false;
+	for (auto& side : d->peer_state) side[0] = side[1] = nullptr;
+	if (d->push_arrived) { hipFree(d->push_arrived); d->push_arrived = nullptr; }
 	if (d->peer_table) { hipFree(d->peer_table); d->peer_table = nullptr; }
 	if (d->peer_mine)  { hipFree(d->peer_mine);  d->peer_mine = nullptr; }
 	d->peer_world = 0; d->peer_rank = 0; d->peer_rounds = 0;
@@ -1477,6 +1518,7 @@ int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out)
 	out->halo_overlap = d->halo_overlap ? 1 : 0;
 	out->ghost_rows = (int32_t)d->ghost_rows;
 	out->peer_max = d->peer_agreed ? 1 : 0;
+	out->peer_halo = d->peer_direct ? 1 : 0;
 	if (d->comm && g_rccl.CommCount) {
 		int n = -1;
 		RCCL_TRY(g_rccl.CommCount(d->comm, &n));
@@ -1554,6 +1596,17 @@ int hp_strip_peer_ticket(hp_domain_t* d, void* ticket_out)
 		(void)hipGetLastError();                                         // other processes cannot map it; ranks of THIS process still can
 		std::memset(&t.handle, 0, sizeof t.handle);
 	}
+	t.state_shareable = 1;
+	for (int b = 0; b < 2; ++b) {
+		t.state[b] = (uint64_t)(uintptr_t)d->state[b];
+		if (hipIpcGetMemHandle(&t.state_handle[b], d->state[b]) != hipSuccess) {
+			(void)hipGetLastError();
+			std::memset(&t.state_handle[b], 0, sizeof t.state_handle[b]);
+			t.state_shareable = 0;
+		}
+	}
+	t.rows = d->desc.rows; t.cols = d->desc.cols; t.ghost_rows = d->ghost_rows; t.row_offset = d->desc.row_offset;
+	t.precision = d->desc.precision;
 	std::memcpy(ticket_out, &t, sizeof t);
 	return HP_OK;
 }
@@ -1593,6 +1646,43 @@ int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int ra
 		}
 	}
 	d->peer_world = count; d->peer_rank = rank; d->peer_rounds = 0;
+	// the strip neighbours' state buffers, for the ghost rows (PeerPush).  Optional on top of the mailboxes: when any rank
+	// cannot have it the rows keep travelling through the collective library's send / receive
+	static const bool direct_wanted = !(std::getenv("HP_PEER_DIRECT") && std::atoi(std::getenv("HP_PEER_DIRECT")) == 0);
+	bool direct = mapped && direct_wanted && d->comm != nullptr;
+	std::string why_not_direct = direct_wanted ? "" : "switched off (HP_PEER_DIRECT=0)";
+	for (int side = 0; side < 2 && direct; ++side) {
+		const int r = side == 0 ? rank - 1 : rank + 1;
+		if (r < 0 || r >= count) continue;
+		const PeerTicket& n = t[r];
+		if (n.cols != d->desc.cols || n.precision != d->desc.precision || n.ghost_rows != d->ghost_rows || d->own_hi - d->own_lo < d->ghost_rows ||
+		    (side == 1 && n.row_offset != d->desc.row_offset + d->desc.rows - 2 * d->ghost_rows) ||
+		    (side == 0 && n.row_offset + n.rows - 2 * d->ghost_rows != d->desc.row_offset)) {
+			direct = false; why_not_direct = "rank " + std::to_string(r) + "'s strip does not adjoin this one"; break;
+		}
+		d->peer_rows[side] = (long)n.rows;
+		for (int b = 0; b < 2 && direct; ++b) {
+			if (n.process == process_token()) {
+				d->peer_state[side][b] = (void*)(uintptr_t)n.state[b];
+				if (n.device != d->desc.device) {
+					const hipError_t e = hipDeviceEnablePeerAccess(n.device, 0);
+					if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { direct = false; why_not_direct = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); }
+					(void)hipGetLastError();
+				}
+			} else if (!n.state_shareable) {
+				direct = false; why_not_direct = "rank " + std::to_string(r) + " could not export its state buffers";
+			} else {
+				void* m = nullptr;
+				const hipError_t e = hipIpcOpenMemHandle(&m, n.state_handle[b], hipIpcMemLazyEnablePeerAccess);
+				if (e != hipSuccess) { (void)hipGetLastError(); direct = false; why_not_direct = std::string("hipIpcOpenMemHandle (state): ") + hipGetErrorString(e); }
+				else { d->peer_mapped.push_back(m); d->peer_state[side][b] = m; }
+			}
+		}
+	}
+	if (direct && !d->push_arrived) {
+		HIP_TRY(hipMalloc((void**)&d->push_arrived, 64));
+		HIP_TRY(hipMemset(d->push_arrived, 0, 64));
+	}
 	uint64_t error = 1;
 	double got = 0.0;
 	if (mapped) {
@@ -1610,23 +1700,28 @@ int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int ra
 		error = ok ? 0 : 1;
 	}
 	if (error) log_line(HP_LOG_WARNING, "peer-written maximum not available on rank " + std::to_string(rank) + ": " + why);
-	if (d->comm && d->comm_world > 1) {
+	if (!error && !direct && d->comm) log_line(HP_LOG_INFORMATION, "ghost rows stay with the collective library on rank " + std::to_string(rank) + ": " + why_not_direct);
+	if (d->comm) {
 		// every rank must take the same road: one MAX over the ranks' verdicts through the collective library
-		char* slot = (char*)d->cfl_slot + (size_t)SLOT_HANDSHAKE * d->esize;
-		char* pinned = (char*)d->host_scalars + 256;
-		const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
-		if (d->desc.precision == 8) { const double v = error ? 1.0 : 0.0; std::memcpy(pinned, &v, 8); }
-		else                        { const float v = error ? 1.0f : 0.0f; std::memcpy(pinned, &v, 4); }
-		HIP_TRY(hipMemcpyAsync(slot, pinned, d->esize, hipMemcpyHostToDevice, d->stream));
-		RCCL_TRY(g_rccl.AllReduce(slot, slot + 8 * d->esize, 1, type, ncclMax, d->comm, d->stream));
-		HIP_TRY(hipMemcpyAsync(pinned + 128, slot + 8 * d->esize, d->esize, hipMemcpyDeviceToHost, d->stream));
-		HIP_TRY(hipStreamSynchronize(d->stream));
-		double any = 0.0;
-		if (d->desc.precision == 8) std::memcpy(&any, pinned + 128, 8);
-		else { float f; std::memcpy(&f, pinned + 128, 4); any = f; }
-		d->peer_agreed = any == 0.0;
-		if (active) *active = d->peer_agreed ? 1 : 0;
+		double verdict[2] = {error ? 1.0 : 0.0, direct ? 0.0 : 1.0};
+		if (d->comm_world > 1) {
+			char* slot = (char*)d->cfl_slot + (size_t)SLOT_HANDSHAKE * d->esize;
+			char* pinned = (char*)d->host_scalars + 256;
+			const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
+			if (d->desc.precision == 8) std::memcpy(pinned, verdict, 16);
+			else { const float v[2] = {(float)verdict[0], (float)verdict[1]}; std::memcpy(pinned, v, 8); }
+			HIP_TRY(hipMemcpyAsync(slot, pinned, 2 * d->esize, hipMemcpyHostToDevice, d->stream));
+			RCCL_TRY(g_rccl.AllReduce(slot, slot + 8 * d->esize, 2, type, ncclMax, d->comm, d->stream));
+			HIP_TRY(hipMemcpyAsync(pinned + 128, slot + 8 * d->esize, 2 * d->esize, hipMemcpyDeviceToHost, d->stream));
+			HIP_TRY(hipStreamSynchronize(d->stream));
+			if (d->desc.precision == 8) std::memcpy(verdict, pinned + 128, 16);
+			else { float f[2]; std::memcpy(f, pinned + 128, 8); verdict[0] = f[0]; verdict[1] = f[1]; }
+		}
+		d->peer_agreed = verdict[0] == 0.0;
+		d->peer_direct = d->peer_agreed && verdict[1] == 0.0;
+		if (active) *active = d->peer_agreed ? (d->peer_direct ? 2 : 1) : 0;
 		if (!d->peer_agreed) peer_release(d);
+		else if (!d->peer_direct) for (auto& side : d->peer_state) side[0] = side[1] = nullptr;
 	} else {
 		// no communicator: nothing to agree through (diagnostic use, hp_strip_peer_round); the strip loop is not touched
 		if (active) *active = error ? 0 : 1;
@@ -1674,10 +1769,11 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 		// exchanged (ghost_rows = g: every iteration; 2g: every second one, and only those iterations are split into a
 		// halo and an interior launch)
 		const bool exchange = d->ghost_valid - g < g;
-		d->split_now = exchange;
+		d->split_now = exchange && !d->peer_direct;   // (rows that travel inside the advance kernel need no launch of their own)
 		if ((rc = dispatch_begin(d)) != HP_OK) return rc;
 		if (exchange) {
-			if ((rc = strip_halo_exchange(d)) != HP_OK) return rc;
+			if (d->peer_direct) d->push_now = true;
+			else if ((rc = strip_halo_exchange(d)) != HP_OK) return rc;
 			d->ghost_valid = d->ghost_rows;
 		} else {
 			d->ghost_valid -= g;
@@ -1687,7 +1783,7 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 		// the exchange sits between advance_time and the next flux launch on the stream graph: its event, not
 		// advance_time's, is what the next halo launch may fork from only if nothing else was queued -- keep it simple
 		// and let hp_step_begin record its own fork event whenever a transfer was queued on the domain's stream
-		if (!d->halo_overlap) d->fork_is_advance = false;
+		if (!d->halo_overlap || d->peer_direct) d->fork_is_advance = false;
 	}
 	d->fuse_next = 0;
 	d->split_now = true;
@@ -1715,10 +1811,10 @@ int hp_strip_update_timestep(hp_domain_t* d)
 	const PeerBox box = peer_box(d, by_peers);
 	if (d->desc.precision == 8)
 		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
-		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, fresh, box);
+		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, fresh, box, PeerPush{});
 	else
 		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
-		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, fresh, box);
+		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, fresh, box, PeerPush{});
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }

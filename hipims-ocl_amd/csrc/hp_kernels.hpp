@@ -204,15 +204,45 @@ __device__ __forceinline__ T peer_reduce_max(const PeerBox& box, const T local)
 	return wave_max(v);
 }
 
-// fresh bit 2: the maximum over all strips comes through the mailboxes (this kernel puts it where bit 1 says it is)
+// Ghost rows written straight into the strip neighbours' memory (CDomainLink::pushToBuffer / pullFromBuffer and CMPIManager's
+// block exchange, Domain/Links/CDomainLink.cpp:168-270, MPI/CMPIManager.cpp:555-709, without a transfer library in between):
+// the blocks of the advance kernel copy this strip's first / last owned rows of the NEW state into the neighbours' ghost
+// rows (peer addresses over xGMI), and the block that finishes last runs the mailbox round and the time advance.  The
+// round doubles as the hand-over: a neighbour's advance kernel returns only after THIS kernel has published, which is after
+// every row has left (release at system scope), and its next flux launch starts after that; and this strip's next flux
+// launch -- whose rows will be written into the neighbours' OTHER buffer -- starts only after the neighbours have published,
+// i.e. after the flux launch that still read that buffer.  Hence one round per iteration, also on the iterations that need
+// no new maximum (quirk Q1).
+struct PeerPush {
+	const uint4* from[2];      // [0]: rows for the south neighbour, [1]: for the north one (this strip's new state)
+	uint4*       to[2];        // the neighbours' ghost rows, as this device addresses them; nullptr = no neighbour / nothing to send
+	unsigned     count;        // uint4 per side
+	unsigned*    arrived;      // blocks done (zero between launches)
+};
+
+// fresh bit 2: a round through the mailboxes; bit 1 then says whether its result is the maximum to use
 template <bool UPDATE_ONLY, typename T>
-__global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const int fresh, const PeerBox box)
+__global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const int fresh, const PeerBox box, const PeerPush push)
 {
-	if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+	if (gridDim.x > 1 || push.to[0] || push.to[1]) {
+		for (int side = 0; side < 2; ++side) {
+			if (!push.to[side]) continue;
+			for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < push.count; i += gridDim.x * blockDim.x)
+				push.to[side][i] = push.from[side][i];
+		}
+		__shared__ unsigned last;
+		__threadfence_system();                                   // this thread's rows are out ...
+		__syncthreads();                                          // ... and so are the whole block's
+		if (threadIdx.x == 0) last = __hip_atomic_fetch_add(push.arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+		__syncthreads();
+		if (!last) return;
+		if (threadIdx.x == 0) __hip_atomic_store(push.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	} else if (blockIdx.x != 0) return;
+	if (threadIdx.x >= 64) return;
 	if (fresh & 4) {
 		const T local = atomic_peek(slot);            // slot[0] is only ever touched by memory-side atomics
 		const T all = peer_reduce_max(box, local);
-		if (threadIdx.x == 0) slot[SLOT_GLOBAL] = all;
+		if (threadIdx.x == 0 && (fresh & 2)) slot[SLOT_GLOBAL] = all;
 	}
 	if (threadIdx.x != 0) return;
 	advance_body<UPDATE_ONLY>(p, sc, slot, fresh & 3);

@@ -78,7 +78,7 @@ class DomainDesc(C.Structure):
 
 class StripInfo(C.Structure):
     _fields_ = [("library", C.c_char * 256), ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32),
-                ("halo_overlap", C.c_int32), ("ghost_rows", C.c_int32), ("peer_max", C.c_int32), ("reserved0", C.c_int32)]
+                ("halo_overlap", C.c_int32), ("ghost_rows", C.c_int32), ("peer_max", C.c_int32), ("peer_halo", C.c_int32)]
 
 
 class ScalarsOut(C.Structure):
@@ -171,7 +171,7 @@ def _check(lib, rc, what):
 
 
 COMM_ID_BYTES = 128
-PEER_TICKET_BYTES = 128
+PEER_TICKET_BYTES = 384
 
 
 def comm_load(path: str | None = None):
@@ -383,7 +383,8 @@ class Domain:
         info = StripInfo()
         _check(self.lib, self.lib.hp_strip_info(self.h, C.byref(info)), "hp_strip_info")
         return dict(library=info.library.decode(errors="replace"), comm_ranks=info.comm_ranks, comm_rank=info.comm_rank,
-                    halo_overlap=bool(info.halo_overlap), ghost_rows=info.ghost_rows, peer_max=bool(info.peer_max))
+                    halo_overlap=bool(info.halo_overlap), ghost_rows=info.ghost_rows, peer_max=bool(info.peer_max),
+                    peer_halo=bool(info.peer_halo))
 
     # ---- the maximum over the strips through peer-written mailboxes (hp_strip_peer_*) ----
     def strip_peer_ticket(self) -> bytes:
@@ -391,13 +392,15 @@ class Domain:
         _check(self.lib, self.lib.hp_strip_peer_ticket(self.h, buf), "hp_strip_peer_ticket")
         return buf.raw
 
-    def strip_peer_connect(self, tickets, rank) -> bool:
-        """`tickets`: every rank's ticket, in rank order.  Collective.  True: the mailboxes are in use from now on."""
+    def strip_peer_connect(self, tickets, rank) -> int:
+        """`tickets`: every rank's ticket, in rank order.  Collective.  0: everything stays with the collective library,
+        1: the maximum over the strips goes through the mailboxes, 2: and the ghost rows are written by the strips into
+        each other's buffers."""
         blob = b"".join(tickets)
         assert len(blob) == PEER_TICKET_BYTES * len(tickets)
         active = C.c_int(0)
         _check(self.lib, self.lib.hp_strip_peer_connect(self.h, blob, len(tickets), int(rank), C.byref(active)), "hp_strip_peer_connect")
-        return bool(active.value)
+        return int(active.value)
 
     def strip_peer_round(self, value: float) -> float:
         out = C.c_double(0.0)

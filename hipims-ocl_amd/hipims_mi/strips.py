@@ -224,7 +224,7 @@ class StripRunner:
             self.domain.strip_comm_init(box[0], rank, world)
             # the maximum over the strips: peer-written mailboxes where every rank can reach every other one's (the
             # library tests that and the ranks agree), the collective library's all-reduce otherwise
-            self.peer_max = False
+            self.peer_max = 0
             if world > 1 and os.environ.get("HIPIMS_MI_PEER_MAX", "1") != "0":
                 tickets = [None] * world
                 dist.all_gather_object(tickets, self.domain.strip_peer_ticket())

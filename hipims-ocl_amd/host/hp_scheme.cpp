@@ -110,12 +110,12 @@ bool CSchemeMI::getPeerTicket(void* ticketOut)
 	return bReady && bStrip && check(hp_strip_peer_ticket(hpDomain, ticketOut), "hp_strip_peer_ticket");
 }
 
-bool CSchemeMI::connectPeers(const void* tickets)
+int CSchemeMI::connectPeers(const void* tickets)
 {
 	int active = 0;
 	if (!bReady || !bStrip || !check(hp_strip_peer_connect(hpDomain, tickets, iStripWorld, iStripRank, &active), "hp_strip_peer_connect"))
-		return false;
-	return active != 0;
+		return 0;
+	return active;
 }
 
 void CSchemeMI::prepareSimulation()

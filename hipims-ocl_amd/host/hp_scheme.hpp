@@ -76,10 +76,11 @@ public:
 	void   setStrip(int rank, int world, const void* commId, long globalRows, long rowOffset);
 	// The maximum over the strips through peer-written mailboxes instead of the collective library's all-reduce
 	// (hp_strip_peer_*): after prepareAll every rank hands out its ticket (HP_PEER_TICKET_BYTES), the host gathers them in
-	// rank order -- as it distributed commId -- and every rank calls connectPeers with all of them.  Returns whether the
-	// mailboxes are in use (all ranks get the same answer; false = the all-reduce stays).
+	// rank order -- as it distributed commId -- and every rank calls connectPeers with all of them.  Returns what all ranks
+	// agreed on: 2 = ghost rows and maxima are written by the strips into each other's memory (nothing of the collective
+	// library inside an iteration), 1 = the maxima only, 0 = everything stays with the library.
 	bool   getPeerTicket(void* ticketOut);
-	bool   connectPeers(const void* tickets);
+	int    connectPeers(const void* tickets);
 	// model::doError's place (main.cpp:631-652): every failure of the library is also handed to this sink
 	static void setLogSink(hp_log_sink_t sink, void* user) { hp_set_log_sink(sink, user); }
 

@@ -82,7 +82,7 @@ int main(int argc, char** argv)
 		if (peer_max && !failed[r] && !scheme.getPeerTicket(&tickets[(size_t)r * HP_PEER_TICKET_BYTES])) failed[r] = 1;
 		meet.wait();                                            // (the tickets have travelled: shared memory stands in for the host's broadcast)
 		if (std::any_of(failed.begin(), failed.end(), [](int f) { return f != 0; })) return;
-		if (peer_max) peers_active[r] = scheme.connectPeers(tickets.data()) ? 1 : 0;
+		if (peer_max) peers_active[r] = scheme.connectPeers(tickets.data());
 		scheme.prepareSimulation();
 
 		double target = freq;
@@ -118,8 +118,9 @@ int main(int argc, char** argv)
 	for (int r = 0; r < world; ++r) threads.emplace_back(rank_main, r);
 	for (auto& t : threads) t.join();
 	if (std::any_of(failed.begin(), failed.end(), [](int f) { return f != 0; })) return 3;
-	std::fprintf(stderr, "maximum over the strips: %s\n", peer_max && std::all_of(peers_active.begin(), peers_active.end(), [](int a) { return a != 0; })
-	                                                          ? "peer-written mailboxes" : "all-reduce");
+	const int level = peer_max ? *std::min_element(peers_active.begin(), peers_active.end()) : 0;
+	std::fprintf(stderr, "maximum over the strips: %s; ghost rows: %s\n", level >= 1 ? "peer-written mailboxes" : "all-reduce",
+	             level >= 2 ? "written by the strips" : "send / receive");
 	for (int o = 0; o < outputs; ++o) {
 		double v = 0.0, s = 0.0;
 		for (int r = 0; r < world; ++r) { v += vol[r][o]; s += sum[r][o]; }

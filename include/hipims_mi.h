@@ -276,7 +276,7 @@ typedef struct {
 	int32_t halo_overlap;        /* 1: halo rows on their own stream, the transfer overlaps the interior launch */
 	int32_t ghost_rows;          /* ghost rows per interior side: the stencil reach (exchange every iteration) or twice that (every second) */
 	int32_t peer_max;            /* 1: the maximum over the strips travels through peer-written mailboxes, 0: through the library's all-reduce */
-	int32_t reserved0;
+	int32_t peer_halo;           /* 1: the ghost rows are written by the strips into each other's state buffers, 0: sent and received through the library */
 } hp_strip_info_t;
 int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out);
 
@@ -285,21 +285,28 @@ int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out);
  * Every strip owns a small mailbox in uncached device memory which the other strips' GPUs write directly over xGMI; the
  * advance kernel that runs after every flux launch anyway stores its maximum into every peer's mailbox, waits for theirs
  * and folds them -- no collective kernel on the critical path of an iteration.
- *   hp_strip_peer_ticket   allocates the mailbox and describes it (address for ranks of the same process, an IPC handle
- *                          for other processes) in HP_PEER_TICKET_BYTES that the host hands to every rank by its own
- *                          means, like the communicator id;
- *   hp_strip_peer_connect  takes all ranks' tickets in rank order (count <= 64), maps the peers' mailboxes and runs a
- *                          connection test (two reductions with known answers, bounded wait).  COLLECTIVE.  With a
- *                          communicator the ranks then agree (one all-reduce) whether ALL of them passed: *active = 1 and
- *                          hp_strip_step_batch / hp_strip_update_timestep use the mailboxes from now on, or *active = 0
- *                          and everything stays on the library's all-reduce (the reason goes to the log sink as a
- *                          warning; the call still returns HP_OK).  Without a communicator (diagnostic use) *active is
- *                          this rank's own verdict;
+ *   hp_strip_peer_ticket   allocates the mailbox and describes it and the domain's two state buffers (addresses for ranks
+ *                          of the same process, IPC handles for other processes) in HP_PEER_TICKET_BYTES that the host
+ *                          hands to every rank by its own means, like the communicator id;
+ *   hp_strip_peer_connect  takes all ranks' tickets in rank order (count <= 64), maps the peers' mailboxes and the strip
+ *                          neighbours' state buffers and runs a connection test (two reductions with known answers,
+ *                          bounded wait).  COLLECTIVE.  With a communicator the ranks then agree (one all-reduce) on what
+ *                          ALL of them can do:
+ *                            *active = 2  mailboxes and ghost rows: hp_strip_step_batch runs ONE flux launch and one
+ *                                         advance launch per iteration and calls nothing of the collective library inside
+ *                                         an iteration -- the advance kernel's blocks copy the strip's edge rows into the
+ *                                         neighbours' ghost rows (CDomainLink's push / pull, Domain/Links/CDomainLink.cpp:
+ *                                         168-270) and its mailbox round, held on every iteration, is the hand-over;
+ *                            *active = 1  mailboxes only (a rank could not map a neighbour's buffers, or HP_PEER_DIRECT=0
+ *                                         in some rank's environment): the rows keep going through ncclSend / ncclRecv;
+ *                            *active = 0  nothing: everything stays with the library (the reason goes to the log sink as
+ *                                         a warning; the call still returns HP_OK).
+ *                          Without a communicator (diagnostic use) *active is this rank's own verdict on its mailboxes;
  *   hp_strip_peer_round    one reduction of a caller-given value (diagnostic; COLLECTIVE over the connected ranks);
  *   hp_strip_peer_disconnect  unmaps and frees (also done by hp_strip_comm_destroy and hp_domain_destroy).
  * A strip that is not heard from within HP_PEER_TIMEOUT_MS (environment, default 10000) raises a sticky error instead of
  * hanging the GPU: hp_read_scalars then fails with HP_ERR_HIP. */
-#define HP_PEER_TICKET_BYTES 128
+#define HP_PEER_TICKET_BYTES 384
 int hp_strip_peer_ticket(hp_domain_t* d, void* ticket_out);
 int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int rank, int* active);
 int hp_strip_peer_round(hp_domain_t* d, double value, double* max_out);

@@ -2,7 +2,7 @@
 per-iteration strip loop -- with WORLD ranks that are threads of this process sharing the one GPU, over the in-process
 test double of the collective library (tests/fake_rccl), and compares the gathered strips with the single domain
 bit for bit.   usage: strip_threads_worker.py <world> <scheme 0|1|2> <f64|f32> <overlap 0|1> <rain 0|1> [exchange period 1|2]
-[boundary on rank k only: -2 = no cell boundary] [maximum over the strips: 1 = peer-written mailboxes (default), 0 = all-reduce]"""
+[boundary on rank k only: -2 = no cell boundary] [2 = mailboxes and ghost rows written by the strips themselves (default), 1 = mailboxes for the maximum only, 0 = everything through the library]"""
 import os
 import sys
 import threading
@@ -21,7 +21,9 @@ from hipims_mi import strips, synthetic as syn  # noqa: E402
 world, scheme, precision, overlap, rain_on = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
 period = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 cell_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -2          # >= 0: a cell boundary that only THAT rank is told about
-peer_max = int(sys.argv[8]) if len(sys.argv) > 8 else 1
+peer_max = int(sys.argv[8]) if len(sys.argv) > 8 else 2
+if peer_max == 1:
+    os.environ["HP_PEER_DIRECT"] = "0"
 cols, rows, steps = 300, 157, 90
 real = np.float64 if precision == "f64" else np.float32
 g = strips.ghost_rows(scheme) * period                             # ghost rows stored per interior side
@@ -78,7 +80,8 @@ def rank_main(r):
             tickets[r] = dom.strip_peer_ticket()
             start.wait()                                  # the tickets travel "by the host's own means"
             peers_active[r] = dom.strip_peer_connect(tickets, r)
-            assert peers_active[r] and dom.strip_info()["peer_max"], "mailboxes not connected"
+            info = dom.strip_info()
+            assert peers_active[r] == peer_max and info["peer_max"] and info["peer_halo"] == (peer_max == 2), (peers_active[r], info)
         start.wait()
         dom.strip_update_timestep()                       # tst_Reduce + all-reduce + tst_UpdateTimestep, as after any upload
         for n in (1, 2, steps - 3):                       # odd and even batch lengths: both ping-pong phases at batch ends

@@ -98,7 +98,7 @@ def test_cpp_host_automatic_queue_runs():
     assert np.allclose(times, [0.25, 0.5, 0.75, 1.0], atol=1e-9)
 
 
-@pytest.mark.parametrize("scheme_name,world,peer_max", [("godunov", 2, 1), ("godunov", 3, 1), ("muscl", 3, 1), ("godunov", 3, 0)])
+@pytest.mark.parametrize("scheme_name,world,peer_max", [("godunov", 2, 2), ("godunov", 3, 2), ("muscl", 3, 2), ("godunov", 3, 1), ("godunov", 3, 0)])
 def test_cpp_host_strip_mode_matches_the_single_domain(scheme_name, world, peer_max):
     """CSchemeMI in strip mode (setStrip -> hp_strip_comm_init / hp_strip_step_batch / hp_strip_update_timestep): the C++
     host runs one scheme per row strip -- ranks as threads on the one GPU, collective library = the tests' in-process
@@ -113,10 +113,11 @@ def test_cpp_host_strip_mode_matches_the_single_domain(scheme_name, world, peer_
     cols, rows, duration, freq, batch = 320, 161, 1.5, 0.5, 25
     strips_run = subprocess.run([exe, fake, str(world), str(cols), str(rows), str(duration), str(freq), scheme_name, str(batch)],
                                 capture_output=True, text=True, timeout=300,
-                                env=dict(os.environ, HIPIMS_MI_PEER_MAX=str(peer_max), GPU_MAX_HW_QUEUES="16"))
+                                env=dict(os.environ, HIPIMS_MI_PEER_MAX=str(min(peer_max, 1)), HP_PEER_DIRECT=str(int(peer_max == 2)), GPU_MAX_HW_QUEUES="16"))
     assert strips_run.returncode == 0, strips_run.stdout + strips_run.stderr
     # the maximum over the strips: through the peer-written mailboxes (CSchemeMI::getPeerTicket / connectPeers) or the all-reduce
     assert ("maximum over the strips: peer-written mailboxes" in strips_run.stderr) == bool(peer_max), strips_run.stderr
+    assert ("ghost rows: written by the strips" in strips_run.stderr) == (peer_max == 2), strips_run.stderr
     single = subprocess.run([EXE, str(cols), str(rows), str(duration), str(freq), scheme_name, str(batch)],
                             capture_output=True, text=True, timeout=300)
     assert single.returncode == 0, single.stderr

@@ -247,7 +247,7 @@ def test_bench_line_names_the_collective_library_on_the_cxx_loop():
     assert "rccl" in info["library"] and info["comm_ranks"] == 1 and info["comm_rank"] == 0
 
 
-@pytest.mark.parametrize("peer_max", [1, 0])
+@pytest.mark.parametrize("peer_max", [2, 1, 0])
 @pytest.mark.parametrize("world,scheme,precision,overlap,rain,period,cell_rank", [
     (2, hp.SCHEME_GODUNOV, "f64", 1, 0, 1, -2), (3, hp.SCHEME_GODUNOV, "f64", 0, 0, 1, -2), (4, hp.SCHEME_GODUNOV, "f32", 1, 1, 1, -2),
     (2, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 1, -2), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 1, -2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 1, -2),
@@ -263,8 +263,9 @@ def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, ra
     one device).  Everything on the engine's side of the nine ncclXxx entry points is the production code: which rows
     are sent and received where, on which stream, behind which events, and which iterations all-reduce.  The gathered
     strips must equal the single domain bit for bit, and every rank must report the single domain's time and dt.
-    peer_max = 1: the maximum over the strips travels through the peer-written mailboxes (hp_strip_peer_*: the advance
-    kernels of the ranks write to and wait for each other); 0: through the (test double's) all-reduce."""
+    peer_max = 2: nothing of the collective library inside an iteration -- the advance kernels write the ghost rows into
+    the neighbours' buffers and trade the maxima through the mailboxes (hp_strip_peer_*), waiting for each other;
+    1: the mailboxes for the maximum, the (test double's) send / receive for the rows; 0: everything through the double."""
     import subprocess
     import sys
     lib = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
@@ -276,7 +277,7 @@ def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, ra
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "bit-identical True" in res.stdout
-    assert ("peer-written maximum [True" in res.stdout) == bool(peer_max)
+    assert (f"peer-written maximum [{peer_max}" in res.stdout) == bool(peer_max)
 
 
 @pytest.mark.parametrize("world", [2, 4])
