@@ -1648,7 +1648,7 @@ int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int ra
 	d->peer_world = count; d->peer_rank = rank; d->peer_rounds = 0;
 	// the strip neighbours' state buffers, for the ghost rows (PeerPush).  Optional on top of the mailboxes: when any rank
 	// cannot have it the rows keep travelling through the collective library's send / receive
-	static const bool direct_wanted = !(std::getenv("HP_PEER_DIRECT") && std::atoi(std::getenv("HP_PEER_DIRECT")) == 0);
+	const bool direct_wanted = !(std::getenv("HP_PEER_DIRECT") && std::atoi(std::getenv("HP_PEER_DIRECT")) == 0);
 	bool direct = mapped && direct_wanted && d->comm != nullptr;
 	std::string why_not_direct = direct_wanted ? "" : "switched off (HP_PEER_DIRECT=0)";
 	for (int side = 0; side < 2 && direct; ++side) {

@@ -6,10 +6,20 @@
 //   ncclSend / ncclRecv inside a group: the receiver copies device-to-device on ITS stream after the sender's stream
 //   has reached the send (event), and the sender's stream then waits for the copy (event) -- the ordering RCCL gives.
 //   ncclAllReduce(MAX, 1..8 elements, in or out of place): through the host, with a generation barrier over the ranks.
+// RANKS THAT ARE PROCESSES (tests/strip_procs_worker.py: the ghost rows and maxima then travel through IPC mappings, which
+// is what that test is about): with FAKE_RCCL_SHM=<file> in the environment the all-reduce's meeting point is that file,
+// mapped by every process (created zero-filled by the test); send / receive are not available in this mode.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -26,13 +36,19 @@ struct Shared {
 	unsigned long long generation = 0;
 	double acc[8] = {0}, result[8] = {0};
 };
+struct ShmBlock { unsigned long long lock, generation; int arrived, pad; double acc[8], result[8]; };   // zero-filled file
+struct ShmLock {
+	ShmBlock* b;
+	explicit ShmLock(ShmBlock* blk) : b(blk) { while (__atomic_exchange_n(&b->lock, 1ull, __ATOMIC_ACQUIRE)) sched_yield(); }
+	~ShmLock() { __atomic_store_n(&b->lock, 0ull, __ATOMIC_RELEASE); }
+};
 struct Op { bool send; void* buf; size_t bytes; int peer; hipStream_t stream; };
 thread_local std::vector<Op> t_ops;
 thread_local int t_depth = 0;
 size_t type_size(ncclDataType_t t) { return t == ncclDouble ? 8 : 4; }
 }
 
-struct ncclComm { int rank, world; Shared* sh; };
+struct ncclComm { int rank, world; Shared* sh; ShmBlock* shm; };
 
 extern "C" {
 
@@ -48,8 +64,17 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int world, ncclUniqueId id, int 
 {
 	Shared* sh;
 	std::memcpy(&sh, id.internal, sizeof sh);
+	if (const char* path = std::getenv("FAKE_RCCL_SHM")) {        // ranks are processes: `sh` belongs to whoever made the id
+		const int fd = open(path, O_RDWR);
+		if (fd < 0) return ncclSystemError;
+		void* m = mmap(nullptr, sizeof(ShmBlock), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+		close(fd);
+		if (m == MAP_FAILED) return ncclSystemError;
+		*comm = new ncclComm{rank, world, nullptr, (ShmBlock*)m};
+		return ncclSuccess;
+	}
 	{ std::lock_guard<std::mutex> l(sh->m); sh->world = world; }
-	*comm = new ncclComm{rank, world, sh};
+	*comm = new ncclComm{rank, world, sh, nullptr};
 	return ncclSuccess;
 }
 
@@ -60,6 +85,7 @@ ncclResult_t ncclGroupStart() { ++t_depth; return ncclSuccess; }
 static ncclResult_t flush(ncclComm_t comm)
 {
 	Shared* sh = comm->sh;
+	if (!sh) return ncclInvalidUsage;                             // (process ranks: all-reduce only)
 	std::vector<Op> ops; ops.swap(t_ops);
 	// 1. post every send: the parcel becomes visible together with an event that marks the sender's stream position
 	for (const Op& o : ops) if (o.send) {
@@ -131,7 +157,22 @@ ncclResult_t ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, ncc
 	else { if (hipMemcpy(vf, sendbuf, 4 * count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError; for (size_t i = 0; i < count; ++i) v[i] = vf[i]; }
 	Shared* sh = comm->sh;
 	double result[8];
-	{
+	if (ShmBlock* b = comm->shm) {
+		unsigned long long gen;
+		{
+			ShmLock l(b);
+			gen = b->generation;
+			for (size_t i = 0; i < count; ++i) if (b->arrived == 0 || v[i] > b->acc[i]) b->acc[i] = v[i];
+			if (++b->arrived == comm->world) { for (size_t i = 0; i < count; ++i) b->result[i] = b->acc[i]; b->arrived = 0; __atomic_store_n(&b->generation, gen + 1, __ATOMIC_RELEASE); }
+		}
+		const auto t0 = std::chrono::steady_clock::now();
+		while (__atomic_load_n(&b->generation, __ATOMIC_ACQUIRE) == gen) {
+			if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return ncclSystemError;   // a rank went missing
+			sched_yield();
+		}
+		ShmLock l(b);
+		for (size_t i = 0; i < count; ++i) result[i] = b->result[i];
+	} else {
 		std::unique_lock<std::mutex> l(sh->m);
 		const unsigned long long gen = sh->generation;
 		for (size_t i = 0; i < count; ++i) if (sh->arrived == 0 || v[i] > sh->acc[i]) sh->acc[i] = v[i];

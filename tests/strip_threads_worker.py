@@ -24,6 +24,9 @@ cell_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -2          # >= 0: a cel
 peer_max = int(sys.argv[8]) if len(sys.argv) > 8 else 2
 if peer_max == 1:
     os.environ["HP_PEER_DIRECT"] = "0"
+variant = sys.argv[9] if len(sys.argv) > 9 else ""                  # "fixed": TIMESTEP_FIXED; "basic": the one-work-item-per-cell kernel; "noq1": quirk Q1 off
+extra = {"fixed": dict(dynamic_dt=False, dt_fixed=0.004, dt_initial=0.004), "basic": dict(kernel=hp.KERNEL_BASIC),
+         "noq1": dict(quirks=hp.QUIRKS_REFERENCE & ~hp.QUIRK_CFL_READS_PRIMARY), "": {}}[variant]
 cols, rows, steps = 300, 157, 90
 real = np.float64 if precision == "f64" else np.float32
 g = strips.ghost_rows(scheme) * period                             # ghost rows stored per interior side
@@ -50,7 +53,7 @@ def attach(dom, rank=None):
         dom.add_cell(hp.DEPTH_IS_DEPTH, hp.DISCHARGE_IGNORE, cell_ids, cell_series, 1000.0, 2000.0)
 
 
-single = hp.Domain(cols, rows, dx=dx, scheme=scheme, precision=precision)
+single = hp.Domain(cols, rows, dx=dx, scheme=scheme, precision=precision, **extra)
 single.upload(st, bed, man); attach(single); single.set_target_time(1e9)
 single.update_timestep()
 single.step_batch(steps)
@@ -69,7 +72,7 @@ def rank_main(r):
     try:
         own_lo, own_hi, lo, hi = parts[r]
         dom = hp.Domain(cols, hi - lo, dx=dx, scheme=scheme, precision=precision, global_rows=rows, row_offset=lo,
-                        ghost_rows=g if period > 1 else 0)
+                        ghost_rows=g if period > 1 else 0, **extra)
         dom.upload(st[lo:hi], bed[lo:hi], man[lo:hi]); attach(dom, r)
         dom.set_halo_overlap(bool(overlap))
         dom.strip_comm_init(uid, r, world)
@@ -113,6 +116,6 @@ if not same:
     print("differing cells:", len(bad), "rows", sorted(set(bad[:, 0].tolist()))[:20], "cols", sorted(set(bad[:, 1].tolist()))[:12],
           "strip edges", [pp[:2] for pp in parts], flush=True)
 times = {(s["time"], s["timestep"]) for s in scal}
-print("ranks", world, "scheme", scheme, precision, "overlap", overlap, "rain", rain_on, "period", period, "cell boundary on rank", cell_rank, "peer-written maximum", peers_active, "bit-identical", same, "times", times,
+print("ranks", world, "scheme", scheme, precision, "overlap", overlap, "rain", rain_on, "period", period, "cell boundary on rank", cell_rank, "variant", variant or "-", "peer-written maximum", peers_active, "bit-identical", same, "times", times,
       "single", (want_sc["time"], want_sc["timestep"]), flush=True)
 os._exit(0 if same and times == {(want_sc["time"], want_sc["timestep"])} else 1)

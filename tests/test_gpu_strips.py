@@ -280,6 +280,19 @@ def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, ra
     assert (f"peer-written maximum [{peer_max}" in res.stdout) == bool(peer_max)
 
 
+@pytest.mark.parametrize("variant,period", [("fixed", 1), ("fixed", 2), ("basic", 1), ("noq1", 1), ("noq1", 2)])
+def test_cxx_strip_loop_direct_transport_variants(variant, period):
+    """The strips' own transport (level 2) on the iterations' other shapes: a fixed timestep (nothing to reduce -- the
+    mailbox round is then only the hand-over of the rows), the cross-check kernel (a separate reduction launch every
+    iteration) and quirk Q1 off (a new maximum on EVERY iteration)."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "strip_threads_worker.py"), "3", str(hp.SCHEME_GODUNOV), "f64",
+                          "1", "0", str(period), "-2", "2", variant], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "bit-identical True" in res.stdout and "peer-written maximum [2, 2, 2]" in res.stdout
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_peer_mailboxes_between_processes(world, tmp_path):
     """The peer-written maximum between PROCESSES: every rank maps the other ranks' mailboxes through IPC handles
@@ -321,3 +334,57 @@ def test_peer_mailboxes_report_a_missing_rank_instead_of_hanging():
     finally:
         os.environ.pop("HP_PEER_TEST_MS", None)
         dom.close()
+
+
+@pytest.mark.parametrize("world,scheme,precision,rain,period", [
+    (2, hp.SCHEME_GODUNOV, "f64", 0, 1), (3, hp.SCHEME_GODUNOV, "f32", 1, 1), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 0, 1), (2, hp.SCHEME_GODUNOV, "f64", 1, 2)])
+def test_cxx_strip_loop_with_ranks_that_are_processes(world, scheme, precision, rain, period, tmp_path):
+    """The strip loop as it runs in production -- one PROCESS per rank -- on the one GPU of the box: every rank maps its
+    neighbours' state buffers and all ranks' mailboxes through IPC handles, the advance kernels write ghost rows and maxima
+    into the other processes' memory, and nothing of the collective library is called inside an iteration (the tests' double
+    serves the start-of-batch handshake through a shared file; it has no send / receive in this mode, so a fall-back to the
+    library's transport would fail the run).  The gathered strips equal the single domain bit for bit; every rank reports its
+    time and dt."""
+    import subprocess
+    import sys
+    from hipims_mi import synthetic as syn
+    lib = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", lib,
+                               os.path.join(os.path.dirname(lib), "fake_rccl.cpp")])
+    shm = tmp_path / "allreduce.shm"
+    shm.write_bytes(bytes(4096))
+    env = dict(os.environ, FAKE_RCCL_SHM=str(shm), HP_PEER_TEST_MS="20000")
+    procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "strip_procs_worker.py"), str(r), str(world), str(tmp_path),
+                               str(scheme), precision, str(rain), str(period)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(world)]
+    # the single domain, meanwhile, in this process
+    cols, rows, steps = 300, 157, 90
+    real = np.float64 if precision == "f64" else np.float32
+    if rain:
+        st, bed, man, rn = syn.s_rain_rows(cols, rows, 0, rows, dx=2.0, dtype=real)
+        dx = 2.0
+    else:
+        st, bed, man = syn.s_rough(cols, rows, dtype=real)
+        rn, dx = None, 1.0
+    single = hp.Domain(cols, rows, dx=dx, scheme=scheme, precision=precision)
+    single.upload(st, bed, man)
+    if rn is not None:
+        single.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rn["grids"], rn["resolution"], rn["off_x"], rn["off_y"], rn["interval"])
+    single.set_target_time(1e9)
+    single.update_timestep()
+    single.step_batch(steps)
+    want, want_sc = single.download(), single.read_scalars()
+    single.close()
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append("TIMEOUT " + p.communicate()[0])
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    got = np.concatenate([np.load(tmp_path / f"owned.{r}.npy") for r in range(world)], axis=0)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    stamp = "time %.17g dt %.17g" % (want_sc["time"], want_sc["timestep"])
+    assert all(stamp in o for o in outs), (stamp, outs)
