@@ -275,6 +275,13 @@ def main():
     elapsed, k_ms, k_n = runs[len(runs) // 2]
     k_ms = sorted(r[1] for r in runs)[len(runs) // 2]
     sc = runner.domain.read_scalars()
+    # ---- N > 1: a number is only a measurement if the strips really saw each other's rows.  After the timed batch every
+    #      rank's ghost rows must equal, bit for bit, the rows their owners hold -- checked over torch.distributed's own
+    #      channel, whatever transport the strip loop used (RCCL send/receive, or the strips' direct writes over xGMI) ----
+    ghost_rows_bad = runner.verify_ghost_rows() if world > 1 else 0
+    if ghost_rows_bad:
+        raise SystemExit(f"bench.py --gpus {world}: {ghost_rows_bad} ghost-row cells differ from their owners' values after the "
+                         f"timed batch -- the strips did not exchange correctly; no line is printed for a broken run")
 
     # ---- the same kernel with a spatially varying Manning array (the uniform n of S-DAM is passed as a scalar and
     #      its 8 B/cell are not streamed): one more repeat, N = 1 only ----
@@ -321,7 +328,8 @@ def main():
                        "area_boundaries": ("none" if args.workload != "s-rain" else
                                            "fused into the flux kernel's store epilogue" if runner.domain.boundaries_fused() else "separate pass"),
                        "timed_steps": [args.warmup + args.evolve_steps, args.warmup + args.evolve_steps + args.steps],
-                       "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"]},
+                       "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"],
+                       **({"ghost_rows_verified_after_timed_batch": True} if world > 1 else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": runner.flux_kernel_name, "avg_launch_ms": k_ms, "launches_sampled": k_n,

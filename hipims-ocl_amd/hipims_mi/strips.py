@@ -359,6 +359,27 @@ class StripRunner:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def verify_ghost_rows(self):
+        """After a batch: do this strip's ghost rows hold, bit for bit, what their owners hold?  (The exchange follows the
+        last iteration of a batch whenever one reach of ghost rows is stored.)  Every rank sends the edge rows it owns to
+        the neighbours by torch.distributed -- a channel that has nothing to do with the transport under test -- and
+        compares.  Returns the largest number of differing cells any rank found (0 = verified); collective."""
+        g, n = self.g, self.local_rows_total
+        dom = self.engine.domain
+        edges = {}
+        if self.south is not None:
+            edges[self.south] = dom.download(row0=g, nrows=g)                   # my first owned rows = the south neighbour's north ghost rows
+        if self.north is not None:
+            edges[self.north] = dom.download(row0=n - 2 * g, nrows=g)
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, edges)
+        bad = 0
+        if self.south is not None:
+            bad += int((dom.download(row0=0, nrows=g).view(np.uint8) != everyone[self.south][self.rank].view(np.uint8)).reshape(-1, 4 * dom.real().itemsize).any(axis=1).sum())
+        if self.north is not None:
+            bad += int((dom.download(row0=n - g, nrows=g).view(np.uint8) != everyone[self.north][self.rank].view(np.uint8)).reshape(-1, 4 * dom.real().itemsize).any(axis=1).sum())
+        return int(self.max_over_ranks(float(bad)))
+
     def gather_owned(self):
         """All ranks' owned rows assembled on every rank (tests)."""
         local = self.engine.download()

@@ -232,6 +232,7 @@ def test_bench_multi_rank_branch_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and d["value"] > 0
     assert "REHEARSAL" in d["config"]["parallelism"] and "cpu_baseline" not in d
     assert d["config"]["successful_iterations"] == 35 and d["roofline"]["cells_per_launch"] == 512 * (512 + 1)
+    assert d["config"]["ghost_rows_verified_after_timed_batch"] is True     # each strip's ghost rows == their owners' rows, bit for bit
 
 
 def test_bench_line_names_the_collective_library_on_the_cxx_loop():
