@@ -210,6 +210,8 @@ def test_multi_process_rehearsal_on_one_gpu(scheme, world, tmp_path):
     assert np.array_equal(got["state"], single.download())
     assert float(got["t"]) == sc["time"] and float(got["dt"]) == sc["timestep"]
     assert int(got["skipped"]) == sc["batch_skipped"] > 0
+    # bench.py's guard on N > 1 runs: nothing to report after the run, one spoiled ghost cell is reported
+    assert int(got["clean"]) == 0 and int(got["spoiled"]) == 1
 
 
 def test_bench_multi_rank_branch_rehearsal():
