@@ -27,7 +27,7 @@ if peer_max == 1:
 variant = sys.argv[9] if len(sys.argv) > 9 else ""                  # "fixed": TIMESTEP_FIXED; "basic": the one-work-item-per-cell kernel; "noq1": quirk Q1 off
 extra = {"fixed": dict(dynamic_dt=False, dt_fixed=0.004, dt_initial=0.004), "basic": dict(kernel=hp.KERNEL_BASIC),
          "noq1": dict(quirks=hp.QUIRKS_REFERENCE & ~hp.QUIRK_CFL_READS_PRIMARY), "": {}}[variant]
-cols, rows, steps = 300, 157, 90
+cols, rows, steps = (int(v) for v in os.environ.get("STRIP_WORKER_GRID", "300,157,90").split(","))   # (soak runs: a bigger grid, more iterations)
 real = np.float64 if precision == "f64" else np.float32
 g = strips.ghost_rows(scheme) * period                             # ghost rows stored per interior side
 if rain_on:
