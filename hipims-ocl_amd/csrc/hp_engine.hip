@@ -546,7 +546,8 @@ template <typename T> int step_end_impl(hp_domain* d)
 			push.from[1] = (const uint4*)(mine + (size_t)(rows - 2 * G) * row_bytes);
 			push.to[1] = (uint4*)d->peer_state[1][b];
 		}
-		const unsigned blocks = (push.to[0] || push.to[1]) ? std::min(32u, (push.count + 1023u) / 1024u) : 1u;
+		static const unsigned per_block = std::getenv("HP_PUSH_PER_BLOCK") ? (unsigned)std::atoi(std::getenv("HP_PUSH_PER_BLOCK")) : 1024u;
+		const unsigned blocks = (push.to[0] || push.to[1]) ? std::min(32u, (push.count + per_block - 1u) / per_block) : 1u;
 		hipLaunchKernelGGL((advance_time<false, T>), dim3(blocks), dim3(256), 0, d->stream, p, (Scalars<T>*)d->scalars,
 		                   (T*)d->cfl_slot, d->adv_fresh, box, push);
 		d->push_now = false;
