@@ -1680,24 +1680,29 @@ int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int ra
 			}
 		}
 	}
+	// (from here to the agreement nothing returns early: a rank that left now would leave the others waiting in the all-reduce)
 	if (direct && !d->push_arrived) {
-		HIP_TRY(hipMalloc((void**)&d->push_arrived, 64));
-		HIP_TRY(hipMemset(d->push_arrived, 0, 64));
+		if (hipMalloc((void**)&d->push_arrived, 64) != hipSuccess || hipMemset(d->push_arrived, 0, 64) != hipSuccess) {
+			(void)hipGetLastError();
+			direct = false; why_not_direct = "no memory for the push counter";
+		}
 	}
 	uint64_t error = 1;
 	double got = 0.0;
+	if (mapped && !d->peer_table && hipMalloc((void**)&d->peer_table, PEER_MAX_RANKS * sizeof(unsigned long long*)) != hipSuccess) {
+		(void)hipGetLastError();
+		mapped = false; why = "no memory for the mailbox table";
+	}
+	if (mapped && hipMemcpy(d->peer_table, table.data(), (size_t)count * sizeof(unsigned long long*), hipMemcpyHostToDevice) != hipSuccess) {
+		(void)hipGetLastError();
+		mapped = false; why = "mailbox table upload failed";
+	}
 	if (mapped) {
-		if (!d->peer_table) HIP_TRY(hipMalloc((void**)&d->peer_table, PEER_MAX_RANKS * sizeof(unsigned long long*)));
-		HIP_TRY(hipMemcpy(d->peer_table, table.data(), (size_t)count * sizeof(unsigned long long*), hipMemcpyHostToDevice));
 		// connection test: two reductions (one per mailbox set) of rank + 1 and -(rank + 1) must give `count` and -1
 		const long test_ms = std::getenv("HP_PEER_TEST_MS") ? std::atol(std::getenv("HP_PEER_TEST_MS")) : 3000;
-		if ((rc = peer_round_now(d, (double)(rank + 1), test_ms, &got, &error)) != HP_OK) return rc;
-		bool ok = error == 0 && got == (double)count;
-		if (ok) {
-			if ((rc = peer_round_now(d, -(double)(rank + 1), test_ms, &got, &error)) != HP_OK) return rc;
-			ok = error == 0 && got == -1.0;
-		}
-		if (!ok && why.empty()) why = error ? "rank " + std::to_string((long)error - 1) + " was not heard from" : "wrong maximum";
+		bool ok = peer_round_now(d, (double)(rank + 1), test_ms, &got, &error) == HP_OK && error == 0 && got == (double)count;
+		if (ok) ok = peer_round_now(d, -(double)(rank + 1), test_ms, &got, &error) == HP_OK && error == 0 && got == -1.0;
+		if (!ok && why.empty()) why = error ? "rank " + std::to_string((long)error - 1) + " was not heard from" : "wrong maximum, or the test launch failed";
 		error = ok ? 0 : 1;
 	}
 	if (error) log_line(HP_LOG_WARNING, "peer-written maximum not available on rank " + std::to_string(rank) + ": " + why);

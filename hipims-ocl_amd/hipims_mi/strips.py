@@ -198,6 +198,7 @@ class StripRunner:
         if loop is None:
             loop = os.environ.get("HIPIMS_MI_STRIP_LOOP", "cxx" if (engine_factory is None and backend == "nccl") else "torch")
         self.loop = loop
+        self.peer_max = 0          # what the ranks agreed on (C++ loop): 0 library, 1 mailboxes, 2 mailboxes + pushed ghost rows
         if exchange_period > 1 and loop != "cxx":
             raise ValueError("several iterations per exchange are the C++ strip loop's (loop='cxx')")
         if loop == "cxx":
@@ -224,7 +225,6 @@ class StripRunner:
             self.domain.strip_comm_init(box[0], rank, world)
             # the maximum over the strips: peer-written mailboxes where every rank can reach every other one's (the
             # library tests that and the ranks agree), the collective library's all-reduce otherwise
-            self.peer_max = 0
             if world > 1 and os.environ.get("HIPIMS_MI_PEER_MAX", "1") != "0":
                 tickets = [None] * world
                 dist.all_gather_object(tickets, self.domain.strip_peer_ticket())

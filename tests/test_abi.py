@@ -96,6 +96,23 @@ def test_strip_info_without_a_domain_reports_no_communicator():
     assert lib.hp_strip_info(None, None) == -1
 
 
+def test_peer_transport_entry_points_reject_missing_domains_and_match_the_header():
+    """hp_strip_peer_*: argument errors are error codes (no GPU needed), and the binding's ticket size and strip-info layout
+    are the header's."""
+    import re
+    lib = hipims_mi.load_library()
+    buf = C.create_string_buffer(hipims_mi.PEER_TICKET_BYTES)
+    active, out = C.c_int(7), C.c_double(0.0)
+    assert lib.hp_strip_peer_ticket(None, buf) < 0
+    assert lib.hp_strip_peer_connect(None, buf, 1, 0, C.byref(active)) < 0
+    assert lib.hp_strip_peer_round(None, 1.0, C.byref(out)) < 0
+    assert lib.hp_strip_peer_disconnect(None) == 0                      # like hp_strip_comm_destroy(NULL): nothing to do
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hipims_mi.h")).read()
+    assert int(re.search(r"#define HP_PEER_TICKET_BYTES (\d+)", header).group(1)) == hipims_mi.PEER_TICKET_BYTES
+    assert C.sizeof(hipims_mi.StripInfo) == 256 + 6 * 4
+    assert [f[0] for f in hipims_mi.StripInfo._fields_][-2:] == ["peer_max", "peer_halo"]
+
+
 def test_bench_never_runs_a_smaller_job_than_asked_for():
     """`python bench.py --gpus 8` without a launcher's environment used to run N = 1 and print
     "n_gpus": 1.  It now starts the ranks itself -- and where the GPUs are not there it must refuse."""
