@@ -6,6 +6,8 @@ batches.  Every case is a few thousand cells and a few hundred iterations: the w
 
 Bit identity is only promised where the oracle and the engine run the same algorithm: MUSCL-Hancock in snapshot order
 (quirk Q6), boundaries in the order added (Q7)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,7 +17,7 @@ from hipims_mi import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = 160
+N_CASES = int(os.environ.get("HIPIMS_MI_FUZZ_CASES", "160"))          # (a soak run: HIPIMS_MI_FUZZ_CASES=2000)
 
 
 def make_case(seed):
