@@ -418,9 +418,11 @@ int launch_flux(hp_domain* d, const void* src, void* dst, int cfl_mode, int part
 	}
 	if (d->desc.kernel == HP_KERNEL_BASIC) {
 		if (part == PART_INTERIOR) return HP_OK;                          // no split for the cross-check kernel
-		const dim3 block(64, 4), grid = grid2d(p.cols, p.rows, block);
+		long lo, hi;
+		launch_rows(d, 1, lo, hi);
+		const dim3 block(64, 4), grid = grid2d(p.cols, hi - lo, block);
 		hipLaunchKernelGGL((godunov_basic<STRICT, T>), grid, block, 0, stream, p, (const Scalars<T>*)d->scalars,
-		                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning);
+		                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning, lo, hi);
 		HIP_TRY(hipGetLastError());
 		return HP_OK;
 	}

@@ -13,11 +13,14 @@ namespace hp {
 template <bool STRICT, typename T>
 __global__ __launch_bounds__(256) void godunov_basic(const Params<T> p, const Scalars<T>* __restrict__ sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
-                                                     State4<T>* __restrict__ dst, const T* __restrict__ manning)
+                                                     State4<T>* __restrict__ dst, const T* __restrict__ manning,
+                                                     const long y_lo, const long y_hi)
 {
+	// rows [y_lo, y_hi): all but the edge ring of a whole domain; for a row strip what launch_rows says -- a strip's ghost rows
+	// are its neighbours' to write (and, with the strips' own transport, written by them while this launch still runs)
 	const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const long y = (long)blockIdx.y * blockDim.y + threadIdx.y;
-	if (x >= p.cols - 1 || y >= p.rows - 1 || x <= 0 || y <= 0) return;          // :183-187
+	const long y = (long)blockIdx.y * blockDim.y + threadIdx.y + y_lo;
+	if (x >= p.cols - 1 || y >= y_hi || x <= 0) return;                           // :183-187
 	const size_t id = (size_t)y * p.cols + x;
 	const T dt = sc->dt;
 

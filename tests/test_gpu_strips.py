@@ -283,17 +283,29 @@ def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, ra
     assert (f"peer-written maximum [{peer_max}" in res.stdout) == bool(peer_max)
 
 
-@pytest.mark.parametrize("variant,period", [("fixed", 1), ("fixed", 2), ("basic", 1), ("noq1", 1), ("noq1", 2)])
+@pytest.mark.parametrize("variant,period", [("fixed", 1), ("fixed", 2), ("basic", 1), ("basic", 2), ("noq1", 1), ("noq1", 2)])
 def test_cxx_strip_loop_direct_transport_variants(variant, period):
     """The strips' own transport (level 2) on the iterations' other shapes: a fixed timestep (nothing to reduce -- the
     mailbox round is then only the hand-over of the rows), the cross-check kernel (a separate reduction launch every
-    iteration) and quirk Q1 off (a new maximum on EVERY iteration)."""
+    iteration; with two reaches of ghost rows it used to update the inner ghost rows as well -- which the neighbours'
+    advance kernels write at the same time: found by tools/strip_fuzz.py, the kernel now keeps to the launch's rows) and
+    quirk Q1 off (a new maximum on EVERY iteration)."""
     import subprocess
     import sys
     res = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "strip_threads_worker.py"), "3", str(hp.SCHEME_GODUNOV), "f64",
                           "1", "0", str(period), "-2", "2", variant], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "bit-identical True" in res.stdout and "peer-written maximum [2, 2, 2]" in res.stdout
+
+
+def test_strip_fuzz_a_few_seeds():
+    """tools/strip_fuzz.py: random world / scheme / precision / exchange period / rain / overlap / transport level / variant /
+    grid shape, each bit for bit against the single domain.  20 seeds here; 600 were run as a soak (profiles/r03ag_strip_fuzz.txt)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "strip_fuzz.py"), "1000", "20"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "failed: 0 of 20" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("world", [2, 4])
