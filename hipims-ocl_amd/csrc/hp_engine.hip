@@ -237,8 +237,13 @@ template <typename T> int launch_reduce(hp_domain* d, const void* state, long ro
 	unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
 	if (blocks > 2048) blocks = 2048;
 	if (blocks < 1) blocks = 1;
-	hipLaunchKernelGGL(cfl_reduce<T>, dim3(blocks), dim3(256), 0, d->stream, p, (const State4<T>*)state,
-	                   (const T*)d->bed, row_lo, row_hi, (T*)d->cfl_slot);
+	// in the domain's own arithmetic: the same buffer prices to the same bits here and in the flux kernels' fused epilogue
+	if (d->desc.math_mode == HP_MATH_STRICT)
+		hipLaunchKernelGGL((cfl_reduce<true, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const State4<T>*)state,
+		                   (const T*)d->bed, row_lo, row_hi, (T*)d->cfl_slot);
+	else
+		hipLaunchKernelGGL((cfl_reduce<false, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const State4<T>*)state,
+		                   (const T*)d->bed, row_lo, row_hi, (T*)d->cfl_slot);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -254,9 +259,14 @@ template <typename T> int price_edge_ring(hp_domain* d)
 	const long north = at_north ? d->desc.rows - w : -1;
 	// side columns of the owned rows, minus the rows already covered by south/north
 	const long lo = d->own_lo + (at_south ? w : 0), hi = d->own_hi - (at_north ? w : 0);
-	for (int b = 0; b < 2; ++b)
-		hipLaunchKernelGGL(cfl_edge_ring<T>, dim3(64), dim3(256), 0, d->stream, p, (const State4<T>*)d->state[b],
-		                   (const T*)d->bed, lo, hi, south, north, w, (T*)d->cfl_slot + SLOT_EDGE + b);
+	for (int b = 0; b < 2; ++b) {
+		if (d->desc.math_mode == HP_MATH_STRICT)
+			hipLaunchKernelGGL((cfl_edge_ring<true, T>), dim3(64), dim3(256), 0, d->stream, p, (const State4<T>*)d->state[b],
+			                   (const T*)d->bed, lo, hi, south, north, w, (T*)d->cfl_slot + SLOT_EDGE + b);
+		else
+			hipLaunchKernelGGL((cfl_edge_ring<false, T>), dim3(64), dim3(256), 0, d->stream, p, (const State4<T>*)d->state[b],
+			                   (const T*)d->bed, lo, hi, south, north, w, (T*)d->cfl_slot + SLOT_EDGE + b);
+	}
 	HIP_TRY(hipGetLastError());
 	d->edge_dirty = false;
 	return HP_OK;

@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 // max wave speed over the edge ring (cells no kernel ever writes): the `w` outermost columns on rows
 // [row_lo,row_hi) plus the `w` outermost rows at the global south / north end when this strip holds them
 // (south / north = first such local row, or -1).  w = 1 (Godunov) or 2 (MUSCL-Hancock).  Priced once per upload.
-template <typename T>
+template <bool STRICT, typename T>
 __global__ __launch_bounds__(256) void cfl_edge_ring(const Params<T> p, const State4<T>* __restrict__ state,
                                                      const T* __restrict__ bed, const long row_lo, const long row_hi,
                                                      const long south, const long north, const int w,
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(256) void cfl_edge_ring(const Params<T> p, const St
 		}
 		const size_t id = (size_t)y * p.cols + x;
 		const State4<T> c = state[id];
-		const T s = cfl_speed<true>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs, p.simplified_cfl != 0);
+		const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs, p.simplified_cfl != 0);
 		if (s > m) m = s;
 	}
 	m = wave_max(m);
@@ -1246,7 +1246,10 @@ __global__ __launch_bounds__(256) void cfl_edge_ring(const Params<T> p, const St
 //     tst_Reduce (CLDynamicTimestep.clc:166-249) + the serial max of tst_Advance_Normal (:75-80) as
 //     wavefront shuffle -> LDS across the block's waves -> one exact atomic max per block.
 // -------------------------------------------------------------------------------------------------
-template <typename T>
+//     STRICT = the domain's arithmetic: a buffer must price to the same bits whichever kernel prices it -- this one after an
+//     upload, the flux kernels' fused epilogue afterwards (FAST's reciprocal / square-root forms differ from the IEEE ones in
+//     the last bit; a strip that re-uses its remembered maximum next to a single domain that re-prices showed it, round 3).
+template <bool STRICT, typename T>
 __global__ __launch_bounds__(256) void cfl_reduce(const Params<T> p, const State4<T>* __restrict__ state,
                                                   const T* __restrict__ bed, const long row_lo, const long row_hi,
                                                   T* __restrict__ slot)
@@ -1257,7 +1260,7 @@ __global__ __launch_bounds__(256) void cfl_reduce(const Params<T> p, const State
 	for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last;
 	     i += (size_t)gridDim.x * blockDim.x) {
 		const State4<T> c = state[i];
-		const T s = cfl_speed<true>(c.z, c.zmax, c.qx, c.qy, bed[i], p.qs, p.simplified_cfl != 0);
+		const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, bed[i], p.qs, p.simplified_cfl != 0);
 		if (s > m) m = s;
 	}
 	m = wave_max(m);

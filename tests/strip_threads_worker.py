@@ -56,6 +56,8 @@ def attach(dom, rank=None):
 single = hp.Domain(cols, rows, dx=dx, scheme=scheme, precision=precision, **extra)
 single.upload(st, bed, man); attach(single); single.set_target_time(1e9)
 single.update_timestep()
+batches = [int(v) for v in os.environ["STRIP_WORKER_BATCHES"].split(",")] if "STRIP_WORKER_BATCHES" in os.environ else [1, 2, steps - 3]
+steps = sum(batches)
 single.step_batch(steps)
 want, want_sc = single.download(), single.read_scalars()
 single.close()
@@ -87,7 +89,7 @@ def rank_main(r):
             assert peers_active[r] == peer_max and info["peer_max"] and info["peer_halo"] == (peer_max == 2), (peers_active[r], info)
         start.wait()
         dom.strip_update_timestep()                       # tst_Reduce + all-reduce + tst_UpdateTimestep, as after any upload
-        for n in (1, 2, steps - 3):                       # odd and even batch lengths: both ping-pong phases at batch ends
+        for n in batches:                                 # odd and even batch lengths: both ping-pong phases at batch ends
             dom.strip_step_batch(n)
         dom.sync()
         got[r] = dom.download()[own_lo - lo:own_hi - lo]
@@ -113,6 +115,8 @@ out = np.concatenate(got, axis=0)
 same = np.array_equal(out.view(np.uint8), want.view(np.uint8))
 if not same:
     bad = np.argwhere((out != want).any(axis=-1))
+    worst = np.abs(out.astype(np.float64) - want.astype(np.float64)).max(axis=-1)
+    print("largest difference %.3e at (row, col) %s; first differing cells %s" % (worst.max(), np.unravel_index(worst.argmax(), worst.shape), bad[:6].tolist()), flush=True)
     print("differing cells:", len(bad), "rows", sorted(set(bad[:, 0].tolist()))[:20], "cols", sorted(set(bad[:, 1].tolist()))[:12],
           "strip edges", [pp[:2] for pp in parts], flush=True)
 times = {(s["time"], s["timestep"]) for s in scal}

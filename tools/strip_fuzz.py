@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Random strip configurations through tests/strip_threads_worker.py (2-4 thread ranks on the one GPU, the library's own strip
 loop), each compared bit for bit with the single domain: world, scheme, precision, iterations per exchange, rain, halo overlap,
-transport level (0 library, 1 mailboxes, 2 mailboxes + pushed ghost rows), variant (fixed dt, cross-check kernel, Q1 off) and
-grid shape are drawn from a seeded generator.   usage: strip_fuzz.py <first seed> <count>"""
+transport level (0 library, 1 mailboxes, 2 mailboxes + pushed ghost rows), variant (fixed dt, cross-check kernel, Q1 off), a cell
+boundary that only one rank knows, and grid shape are drawn from a seeded generator.   usage: strip_fuzz.py <first seed> <count>"""
 import os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,13 +22,14 @@ for seed in range(first, first + count):
     cols = int(rng.integers(70, 900))
     rows = int(rng.integers(world * (3 * g + 4), world * (3 * g + 4) + 300))
     steps = int(rng.integers(12, 120))
+    cell_rank = int(rng.integers(0, world)) if (scheme == 0 and cols > 110 and rng.random() < 0.3) else -2    # a cell boundary only ONE rank is told about
     env = dict(os.environ, STRIP_WORKER_GRID=f"{cols},{rows},{steps}")
     cmd = [sys.executable, os.path.join(ROOT, "tests", "strip_threads_worker.py"), str(world), str(scheme), precision, str(overlap), str(rain),
-           str(period), "-2", str(level), variant]
+           str(period), str(cell_rank), str(level), variant]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     ok = r.returncode == 0 and "bit-identical True" in r.stdout
     bad += not ok
     print("seed", seed, "ok" if ok else "FAILED", "world", world, "scheme", scheme, precision, "period", period, "rain", rain, "overlap", overlap,
-          "level", level, "variant", variant or "-", "grid", (cols, rows, steps), "" if ok else (r.stdout + r.stderr)[-600:], flush=True)
+          "level", level, "variant", variant or "-", "cell boundary on rank", cell_rank, "grid", (cols, rows, steps), "" if ok else (r.stdout + r.stderr)[-600:], flush=True)
 print("failed:", bad, "of", count)
 sys.exit(1 if bad else 0)
