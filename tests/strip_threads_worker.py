@@ -24,9 +24,9 @@ cell_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -2          # >= 0: a cel
 peer_max = int(sys.argv[8]) if len(sys.argv) > 8 else 2
 if peer_max == 1:
     os.environ["HP_PEER_DIRECT"] = "0"
-variant = sys.argv[9] if len(sys.argv) > 9 else ""                  # "fixed": TIMESTEP_FIXED; "basic": the one-work-item-per-cell kernel; "noq1": quirk Q1 off
+variant = sys.argv[9] if len(sys.argv) > 9 else ""                  # "fixed": TIMESTEP_FIXED; "basic": the one-work-item-per-cell kernel; "noq1": quirk Q1 off; "strict": STRICT arithmetic
 extra = {"fixed": dict(dynamic_dt=False, dt_fixed=0.004, dt_initial=0.004), "basic": dict(kernel=hp.KERNEL_BASIC),
-         "noq1": dict(quirks=hp.QUIRKS_REFERENCE & ~hp.QUIRK_CFL_READS_PRIMARY), "": {}}[variant]
+         "noq1": dict(quirks=hp.QUIRKS_REFERENCE & ~hp.QUIRK_CFL_READS_PRIMARY), "strict": dict(math_mode=hp.MATH_STRICT), "": {}}[variant]
 cols, rows, steps = (int(v) for v in os.environ.get("STRIP_WORKER_GRID", "300,157,90").split(","))   # (soak runs: a bigger grid, more iterations)
 real = np.float64 if precision == "f64" else np.float32
 g = strips.ghost_rows(scheme) * period                             # ghost rows stored per interior side
