@@ -1,6 +1,6 @@
 """Seeded differential fuzzing: STRICT HIP engine vs the oracle, bit for bit, over random combinations of everything the hot
 path has a switch for -- grid shape (tile and wavefront edges), scheme, precision, friction, uniform vs spatially varying
-Manning n, quirks Q1 / Q9, dynamic vs fixed timestep, a sync point inside the run, uniform rain, uniform loss, coarse (fused)
+Manning n, quirks Q1 / Q9, the tuned and the cross-check kernel, dynamic vs fixed timestep, a sync point inside the run, uniform rain, uniform loss, coarse (fused)
 and fine (stand-alone pass) gridded rain, cell boundaries with all four definitions, and how the iterations are cut into
 batches.  Every case is a few thousand cells and a few hundred iterations: the whole file runs in about a minute.
 
@@ -66,7 +66,9 @@ def make_case(seed):
         n = int(min(left, rng.choice([1, 1, 2, 3, 7, 20, 64, 1000])))
         cuts.append(n); left -= n
     target = float(rng.choice([1e9, 1e9, rng.uniform(0.05, 1.5)]))
-    return dict(scheme=scheme, precision=precision, cols=cols, rows=rows, dx=dx, st=st, bed=bed, man=man, quirks=quirks, kw=kw,
+    # (drawn last, so that the cases of earlier rounds keep their configurations) the one-work-item-per-cell cross-check kernel
+    kernel = hp.KERNEL_BASIC if (scheme == hp.SCHEME_GODUNOV and rng.random() < 0.15) else hp.KERNEL_AUTO
+    return dict(kernel=kernel, scheme=scheme, precision=precision, cols=cols, rows=rows, dx=dx, st=st, bed=bed, man=man, quirks=quirks, kw=kw,
                 fixed_dt=fixed_dt, bdy=bdy, cuts=cuts, target=target)
 
 
@@ -89,7 +91,7 @@ def test_strict_engine_equals_the_oracle_on_a_random_configuration(seed):
                            dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001)
     dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3,
                     friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"],
-                    dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=hp.MATH_STRICT)
+                    dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=hp.MATH_STRICT, kernel=c["kernel"])
     for s in (ref, dom):
         s.upload(c["st"], c["bed"], c["man"])
         attach(s, c["bdy"])
@@ -125,7 +127,7 @@ def test_fast_engine_does_not_depend_on_how_the_iterations_are_batched(seed):
     for plan in ([total], c["cuts"], [1] * total):
         dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3,
                         friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"],
-                        dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=hp.MATH_FAST)
+                        dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=hp.MATH_FAST, kernel=c["kernel"])
         dom.upload(c["st"], c["bed"], c["man"])
         attach(dom, c["bdy"])
         dom.set_target_time(c["target"])
