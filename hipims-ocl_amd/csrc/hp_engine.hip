@@ -952,9 +952,13 @@ int hp_state_save(hp_domain_t* d)
 	if (d->in_step) return fail(HP_ERR_STATE, "hp_state_save between hp_step_begin and hp_step_end");
 	const size_t bytes = d->cells * 4 * d->esize;
 	const size_t sc_bytes = d->desc.precision == 8 ? sizeof(Scalars<double>) : sizeof(Scalars<float>);
-	if (!d->saved_state) HIP_TRY(hipMalloc(&d->saved_state, bytes));
+	// BOTH ping-pong buffers: the one the next iteration writes is not dead -- cells whose whole neighbourhood is dry are left
+	// untouched by the flux kernel (quirk Q3) and keep what that buffer held, so a replay needs it too (a fuzz over random
+	// configurations found 6 % of them replaying differently when only the next-source buffer was kept, round 3)
+	if (!d->saved_state) HIP_TRY(hipMalloc(&d->saved_state, 2 * bytes));
 	if (!d->saved_scalars) HIP_TRY(hipMalloc(&d->saved_scalars, sc_bytes + CFL_SLOT_BYTES));
 	HIP_TRY(hipMemcpyAsync(d->saved_state, d->state[d->use_alt], bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync((char*)d->saved_state + bytes, d->state[d->use_alt ^ 1], bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->saved_scalars, d->scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
 	// the WHOLE slot block: running maximum, last maximum used (SLOT_SAVED), ring maxima (SLOT_EDGE) -- round 2 kept the first
 	// four elements only, which since the slots moved 256 B apart no longer included the remembered maximum
@@ -975,10 +979,11 @@ int hp_state_restore(hp_domain_t* d)
 	if (!d->saved_valid) return fail(HP_ERR_STATE, "hp_state_restore without a saved state");
 	const size_t bytes = d->cells * 4 * d->esize;
 	const size_t sc_bytes = d->desc.precision == 8 ? sizeof(Scalars<double>) : sizeof(Scalars<float>);
-	// both ping-pong buffers, as rollbackSimulation writes them (CSchemeGodunov.cpp:1496-1499); the ping-pong phase and
-	// the remembered CFL maxima return to what they were, so the steps that follow repeat the original ones bit for bit
-	HIP_TRY(hipMemcpyAsync(d->state[0], d->saved_state, bytes, hipMemcpyDeviceToDevice, d->stream));
-	HIP_TRY(hipMemcpyAsync(d->state[1], d->saved_state, bytes, hipMemcpyDeviceToDevice, d->stream));
+	// both ping-pong buffers return to what EACH of them held (rollbackSimulation writes the saved next-source state into both,
+	// CSchemeGodunov.cpp:1496-1499, after which its cells with an all-dry neighbourhood no longer continue as the original run
+	// did), and so do the ping-pong phase and the remembered CFL maxima: the steps that follow repeat the original ones bit for bit
+	HIP_TRY(hipMemcpyAsync(d->state[d->saved_use_alt], d->saved_state, bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->state[d->saved_use_alt ^ 1], (char*)d->saved_state + bytes, bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->scalars, d->saved_scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
 	d->use_alt = d->saved_use_alt;

@@ -153,10 +153,12 @@ int hp_domain_download(hp_domain_t* d, int which, void* host, int64_t row0, int6
 int hp_domain_upload_rows(hp_domain_t* d, const void* host, int64_t row0, int64_t nrows);
 
 /* Device-side checkpoint: what saveCurrentState + rollbackSimulation do through host memory (CSchemeGodunov.cpp:1720-1736,
- * :1474-1518), kept in HBM instead (a second copy of a 4096^2 fp64 state is 0.5 GB of 288).  hp_state_save copies the
- * next-source cell states and the time-control block; hp_state_restore writes the states back to BOTH ping-pong buffers
- * (as rollback does) and restores the time-control block, the ping-pong phase and the remembered CFL maxima: the steps
- * that follow repeat the original ones bit for bit.  The host may then adjust time / target / timestep with the calls
+ * :1474-1518), kept in HBM instead (two more copies of a 4096^2 fp64 state are 1 GB of 288).  hp_state_save copies BOTH
+ * ping-pong buffers and the time-control block; hp_state_restore puts each buffer, the time-control block, the ping-pong phase
+ * and the remembered CFL maxima back: the steps that follow repeat the original ones bit for bit.  (The reference's rollback
+ * writes the saved next-source state into both buffers; cells whose whole neighbourhood is dry, which the flux kernel leaves
+ * untouched -- quirk Q3 --, then continue from other values than in the original run.  A host that wants exactly that uploads
+ * the state it downloaded, as CSchemeMI::rollbackSimulation does.)  The host may then adjust time / target / timestep with the calls
  * below, exactly as the reference's rollback sequence does. */
 int hp_state_save(hp_domain_t* d);
 int hp_state_restore(hp_domain_t* d);

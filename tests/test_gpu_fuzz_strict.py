@@ -138,3 +138,44 @@ def test_fast_engine_does_not_depend_on_how_the_iterations_are_batched(seed):
     for out, sc in outs[1:]:
         assert np.array_equal(out, outs[0][0], equal_nan=True), seed
         assert sc["time"] == outs[0][1]["time"] and sc["timestep"] == outs[0][1]["timestep"]
+
+
+@pytest.mark.parametrize("seed", range(0, N_CASES, 4))
+def test_a_checkpoint_taken_anywhere_replays_to_the_same_bits(seed):
+    """hp_state_save / hp_state_restore (CSchemeGodunov::saveCurrentState / rollbackSimulation, CSchemeGodunov.cpp:1720-1736,
+    :1474-1518) on a random configuration: run part of the way, save, wander off for a random number of iterations (with a
+    different target time, so that the scalars really move), restore, finish -- and compare with the run that never left,
+    state and scalars, in the case's own arithmetic (every other case STRICT)."""
+    c = make_case(seed)
+    rng = np.random.default_rng(5000 + seed)
+    total = sum(c["cuts"])
+    at = int(rng.integers(1, total))
+    math_mode = hp.MATH_STRICT if seed % 8 == 0 else hp.MATH_FAST
+
+    def fresh():
+        dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3,
+                        friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"],
+                        dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=math_mode, kernel=c["kernel"])
+        dom.upload(c["st"], c["bed"], c["man"])
+        attach(dom, c["bdy"])
+        dom.set_target_time(c["target"])
+        return dom
+
+    straight = fresh()
+    straight.step_batch(at); straight.step_batch(total - at)
+    want, want_sc = straight.download(), straight.read_scalars()
+    straight.close()
+    dom = fresh()
+    dom.step_batch(at)
+    dom.state_save()
+    dom.set_target_time(c["target"] * 0.5 + 0.01)
+    for n in (int(rng.integers(1, 9)), int(rng.integers(1, 40))):
+        dom.step_batch(n)
+    dom.state_restore()
+    dom.set_target_time(c["target"])
+    dom.step_batch(total - at)
+    got, got_sc = dom.download(), dom.read_scalars()
+    dom.close()
+    assert np.array_equal(got, want, equal_nan=True), (seed, at, total)
+    for k in ("time", "timestep", "time_hydrological", "batch_timesteps"):
+        assert got_sc[k] == want_sc[k] or (np.isnan(got_sc[k]) and np.isnan(want_sc[k])), (seed, k, got_sc[k], want_sc[k])
