@@ -58,6 +58,7 @@ single.upload(st, bed, man); attach(single); single.set_target_time(1e9)
 single.update_timestep()
 batches = [int(v) for v in os.environ["STRIP_WORKER_BATCHES"].split(",")] if "STRIP_WORKER_BATCHES" in os.environ else [1, 2, steps - 3]
 steps = sum(batches)
+wander = [int(v) for v in os.environ["STRIP_WORKER_WANDER"].split(",")] if "STRIP_WORKER_WANDER" in os.environ else []   # iterations between a save and a restore
 single.step_batch(steps)
 want, want_sc = single.download(), single.read_scalars()
 single.close()
@@ -89,8 +90,13 @@ def rank_main(r):
             assert peers_active[r] == peer_max and info["peer_max"] and info["peer_halo"] == (peer_max == 2), (peers_active[r], info)
         start.wait()
         dom.strip_update_timestep()                       # tst_Reduce + all-reduce + tst_UpdateTimestep, as after any upload
-        for n in batches:                                 # odd and even batch lengths: both ping-pong phases at batch ends
+        for i, n in enumerate(batches):                   # odd and even batch lengths: both ping-pong phases at batch ends
             dom.strip_step_batch(n)
+            if i == 0 and wander:                         # a device checkpoint on every rank: save, run on, come back (bench.py's pre-warm does this)
+                dom.state_save()
+                for w in wander:
+                    dom.strip_step_batch(w)
+                dom.state_restore()
         dom.sync()
         got[r] = dom.download()[own_lo - lo:own_hi - lo]
         scal[r] = dom.read_scalars()

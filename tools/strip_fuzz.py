@@ -26,12 +26,18 @@ for seed in range(first, first + count):
     if variant == "" and rng.random() < 0.25:              # (drawn last: the seeds that found something keep their configurations)
         variant = "strict"
     env = dict(os.environ, STRIP_WORKER_GRID=f"{cols},{rows},{steps}")
+    extra = ""
+    if rng.random() < 0.35:                                # a checkpoint after a random first batch, a random walk away from it, and back
+        first_batch = int(rng.integers(1, steps - 2))
+        env["STRIP_WORKER_BATCHES"] = f"{first_batch},{steps - first_batch}"
+        env["STRIP_WORKER_WANDER"] = ",".join(str(int(v)) for v in rng.integers(1, 12, int(rng.integers(1, 3))))
+        extra = f"checkpoint after {first_batch}, away for {env['STRIP_WORKER_WANDER']}"
     cmd = [sys.executable, os.path.join(ROOT, "tests", "strip_threads_worker.py"), str(world), str(scheme), precision, str(overlap), str(rain),
            str(period), str(cell_rank), str(level), variant]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     ok = r.returncode == 0 and "bit-identical True" in r.stdout
     bad += not ok
     print("seed", seed, "ok" if ok else "FAILED", "world", world, "scheme", scheme, precision, "period", period, "rain", rain, "overlap", overlap,
-          "level", level, "variant", variant or "-", "cell boundary on rank", cell_rank, "grid", (cols, rows, steps), "" if ok else (r.stdout + r.stderr)[-600:], flush=True)
+          "level", level, "variant", variant or "-", "cell boundary on rank", cell_rank, "grid", (cols, rows, steps), extra, "" if ok else (r.stdout + r.stderr)[-600:], flush=True)
 print("failed:", bad, "of", count)
 sys.exit(1 if bad else 0)
