@@ -59,7 +59,23 @@ single.update_timestep()
 batches = [int(v) for v in os.environ["STRIP_WORKER_BATCHES"].split(",")] if "STRIP_WORKER_BATCHES" in os.environ else [1, 2, steps - 3]
 steps = sum(batches)
 wander = [int(v) for v in os.environ["STRIP_WORKER_WANDER"].split(",")] if "STRIP_WORKER_WANDER" in os.environ else []   # iterations between a save and a restore
-single.step_batch(steps)
+# a host write into ONE strip between the first two batches (CDomainLink::pushToBuffer's kind of write, hp_domain_upload_rows):
+# the level of a few cells of a row in the middle of that rank's owned rows is raised; the other ranks are not told
+poke_rank = int(os.environ.get("STRIP_WORKER_POKE", "-1"))
+poke_row = (parts[poke_rank][0] + parts[poke_rank][1]) // 2 if poke_rank >= 0 else -1
+
+
+def poke(dom, local_row):
+    row = dom.download(row0=local_row, nrows=1)
+    row[0, 10:20, 0] += 0.0625
+    row[0, 10:20, 1] = np.maximum(row[0, 10:20, 1], row[0, 10:20, 0])
+    dom.upload_rows(row, local_row)
+
+
+if poke_rank >= 0:
+    single.step_batch(batches[0]); poke(single, poke_row); single.step_batch(steps - batches[0])
+else:
+    single.step_batch(steps)
 want, want_sc = single.download(), single.read_scalars()
 single.close()
 
@@ -92,6 +108,8 @@ def rank_main(r):
         dom.strip_update_timestep()                       # tst_Reduce + all-reduce + tst_UpdateTimestep, as after any upload
         for i, n in enumerate(batches):                   # odd and even batch lengths: both ping-pong phases at batch ends
             dom.strip_step_batch(n)
+            if i == 0 and r == poke_rank:
+                poke(dom, poke_row - lo)
             if i == 0 and wander:                         # a device checkpoint on every rank: save, run on, come back (bench.py's pre-warm does this)
                 dom.state_save()
                 for w in wander:

@@ -32,6 +32,11 @@ for seed in range(first, first + count):
         env["STRIP_WORKER_BATCHES"] = f"{first_batch},{steps - first_batch}"
         env["STRIP_WORKER_WANDER"] = ",".join(str(int(v)) for v in rng.integers(1, 12, int(rng.integers(1, 3))))
         extra = f"checkpoint after {first_batch}, away for {env['STRIP_WORKER_WANDER']}"
+    elif rng.random() < 0.3 and cols > 40:                 # a host write into one strip's rows between two batches
+        first_batch = int(rng.integers(1, steps - 2))
+        env["STRIP_WORKER_BATCHES"] = f"{first_batch},{steps - first_batch}"
+        env["STRIP_WORKER_POKE"] = str(int(rng.integers(0, world)))
+        extra = f"rows of rank {env['STRIP_WORKER_POKE']} written by the host after {first_batch}"
     cmd = [sys.executable, os.path.join(ROOT, "tests", "strip_threads_worker.py"), str(world), str(scheme), precision, str(overlap), str(rain),
            str(period), str(cell_rank), str(level), variant]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
