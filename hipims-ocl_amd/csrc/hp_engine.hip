@@ -1167,13 +1167,16 @@ int hp_update_timestep(hp_domain_t* d)
 	if (d->desc.dynamic_dt && d->desc.global_rows != d->desc.rows)
 		return fail(HP_ERR_UNSUPPORTED, "hp_update_timestep on a row strip: the maximum must be all-reduced across "
 		                                "ranks not available through this call)");
-	// tst_Reduce reads the primary buffer (arg wiring CSchemeGodunov.cpp:922, :927), then tst_UpdateTimestep
+	// tst_Reduce reads the primary buffer (arg wiring CSchemeGodunov.cpp:922, :927), then tst_UpdateTimestep.  MUSCL-Hancock
+	// has ONE state buffer in the reference, updated in place -- its primary buffer is always the current state, which here
+	// is whichever ping-pong buffer the next iteration reads (found by the fuzz's update-timestep calls between batches)
+	const void* priced = d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK ? d->state[d->use_alt] : d->state[0];
 	if (d->desc.precision == 8) {
-		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, priced, d->own_lo, d->own_hi)) != HP_OK) return rc;
 		hipLaunchKernelGGL((advance_time<true, double>), dim3(1), dim3(64), 0, d->stream, make_params<double>(d),
 		                   (Scalars<double>*)d->scalars, (double*)d->cfl_slot, 1, PeerBox{}, PeerPush{});
 	} else {
-		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, priced, d->own_lo, d->own_hi)) != HP_OK) return rc;
 		hipLaunchKernelGGL((advance_time<true, float>), dim3(1), dim3(64), 0, d->stream, make_params<float>(d),
 		                   (Scalars<float>*)d->scalars, (float*)d->cfl_slot, 1, PeerBox{}, PeerPush{});
 	}
@@ -1822,10 +1825,11 @@ int hp_strip_update_timestep(hp_domain_t* d)
 	// tst_Reduce over the owned rows of the primary buffer, the maximum over all strips, then tst_UpdateTimestep on every
 	// rank redundantly (CSchemeGodunov.cpp:1189-1195, :1254-1260 with CMPIManager's reduction in between)
 	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
+	const void* priced = d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK ? d->state[d->use_alt] : d->state[0];     // (as hp_update_timestep)
 	if (d->desc.precision == 8) {
-		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, priced, d->own_lo, d->own_hi)) != HP_OK) return rc;
 	} else {
-		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+		if (d->desc.dynamic_dt && (rc = launch_reduce<float>(d, priced, d->own_lo, d->own_hi)) != HP_OK) return rc;
 	}
 	const bool reduced = d->desc.dynamic_dt && d->comm_world > 1, by_peers = reduced && d->peer_agreed;
 	if (reduced && !by_peers)

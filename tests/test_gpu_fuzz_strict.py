@@ -68,7 +68,16 @@ def make_case(seed):
     target = float(rng.choice([1e9, 1e9, rng.uniform(0.05, 1.5)]))
     # (drawn last, so that the cases of earlier rounds keep their configurations) the one-work-item-per-cell cross-check kernel
     kernel = hp.KERNEL_BASIC if (scheme == hp.SCHEME_GODUNOV and rng.random() < 0.15) else hp.KERNEL_AUTO
-    return dict(kernel=kernel, scheme=scheme, precision=precision, cols=cols, rows=rows, dx=dx, st=st, bed=bed, man=man, quirks=quirks, kw=kw,
+    # host calls between batches (the reference's scheme does all of these between its batches: setTargetTime, forceTimestep,
+    # tst_ResetCounters, tst_UpdateTimestep, and writeAll of a changed state -- CSchemeGodunov.cpp:1741-1811, :1178-1260):
+    # (index of the batch after which it happens, what, argument)
+    ops = []
+    if rng.random() < 0.4 and len(cuts) > 1:
+        for _ in range(int(rng.integers(1, 4))):
+            what = str(rng.choice(["target", "force_dt", "reset", "update", "upload"]))
+            arg = float(rng.uniform(0.02, 3.0)) if what == "target" else float(rng.choice([0.001, 0.0005]) * dx) if what == "force_dt" else float(rng.uniform(0.005, 0.05))
+            ops.append((int(rng.integers(0, len(cuts) - 1)), what, arg))
+    return dict(kernel=kernel, ops=ops, scheme=scheme, precision=precision, cols=cols, rows=rows, dx=dx, st=st, bed=bed, man=man, quirks=quirks, kw=kw,
                 fixed_dt=fixed_dt, bdy=bdy, cuts=cuts, target=target)
 
 
@@ -98,9 +107,30 @@ def test_strict_engine_equals_the_oracle_on_a_random_configuration(seed):
     dom.set_target_time(c["target"]); ref.set_target(c["target"])
     what = f"seed {seed}: scheme {c['scheme']} {c['precision']} {c['cols']}x{c['rows']} bdy {[b[0] for b in c['bdy']]} cuts {c['cuts'][:6]} target {c['target']:.3g}"
     done = 0
-    for n in c["cuts"]:
+    for i, n in enumerate(c["cuts"]):
         ref.run(n); dom.step_batch(n)
         done += n
+        for _, op, arg in (o for o in c["ops"] if o[0] == i):
+            what += f" [{op} after batch {i}]"
+            if op == "target":
+                dom.set_target_time(arg); ref.set_target(arg)
+            elif op == "force_dt":
+                dom.force_timestep(arg); ref.force_dt(arg)
+            elif op == "reset":
+                dom.reset_counters(); ref.reset_counters()
+            elif op == "update":
+                dom.update_timestep(); ref.update_timestep()
+            else:                                              # a changed state written to both (raises the level of the wet cells of a patch)
+                cur = ref.download()
+                if not np.isfinite(cur[c["st"][..., 1] > -9000]).all():
+                    pytest.skip("the oracle's own run is not finite: " + what)
+                assert np.array_equal(dom.download(), cur), what + " before the upload"
+                patch = cur[c["rows"] // 3:c["rows"] // 3 + 3, c["cols"] // 4:c["cols"] // 4 + 9]
+                wet = (patch[..., 0] - c["bed"][c["rows"] // 3:c["rows"] // 3 + 3, c["cols"] // 4:c["cols"] // 4 + 9] > 1e-3) & (patch[..., 1] > -9000)
+                patch[..., 0][wet] += np.asarray(arg, cur.dtype)
+                patch[..., 1][wet] = np.maximum(patch[..., 1][wet], patch[..., 0][wet])
+                dom.upload(cur); ref.upload(cur)
+                dom.update_timestep(); ref.update_timestep()   # as the reference does after any write of the states
         if n >= 20 or done == sum(c["cuts"]):              # (a download after every single-iteration batch would dominate the run time)
             want = ref.download()
             if not np.isfinite(want[c["st"][..., 1] > -9000]).all():
