@@ -640,6 +640,11 @@ template <typename T> int refresh_fusable_t(hp_domain* d)
 		}
 	}
 	if (!d->fused_list) HIP_TRY(hipMalloc(&d->fused_list, sizeof(AreaBdyList<double>)));
+	// the flux launches of a batch still in flight read this list: wait for them before it changes (hp_step_batch returns
+	// without waiting, and a blocking copy is not ordered behind a non-blocking stream -- a boundary added right after a
+	// batch call used to rain on that batch's remaining iterations; found by the fuzz's boundary-added-mid-run cases)
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	if (d->stream_halo) HIP_TRY(hipStreamSynchronize(d->stream_halo));
 	HIP_TRY(hipMemcpy(d->fused_list, &list, sizeof list, hipMemcpyHostToDevice));
 	d->fusable = true;
 	return HP_OK;

@@ -72,8 +72,14 @@ def poke(dom, local_row):
     dom.upload_rows(row, local_row)
 
 
-if poke_rank >= 0:
-    single.step_batch(batches[0]); poke(single, poke_row); single.step_batch(steps - batches[0])
+update_between = "STRIP_WORKER_UPDATE" in os.environ          # hp_update_timestep / hp_strip_update_timestep between the first two batches
+if poke_rank >= 0 or update_between:
+    single.step_batch(batches[0])
+    if poke_rank >= 0:
+        poke(single, poke_row)
+    if update_between:
+        single.update_timestep()
+    single.step_batch(steps - batches[0])
 else:
     single.step_batch(steps)
 want, want_sc = single.download(), single.read_scalars()
@@ -110,6 +116,8 @@ def rank_main(r):
             dom.strip_step_batch(n)
             if i == 0 and r == poke_rank:
                 poke(dom, poke_row - lo)
+            if i == 0 and update_between:
+                dom.strip_update_timestep()
             if i == 0 and wander:                         # a device checkpoint on every rank: save, run on, come back (bench.py's pre-warm does this)
                 dom.state_save()
                 for w in wander:

@@ -74,7 +74,7 @@ def make_case(seed):
     ops = []
     if rng.random() < 0.4 and len(cuts) > 1:
         for _ in range(int(rng.integers(1, 4))):
-            what = str(rng.choice(["target", "force_dt", "reset", "update", "upload"]))
+            what = str(rng.choice(["target", "force_dt", "reset", "update", "upload"] + (["rain"] if scheme != hp.SCHEME_MUSCL_HANCOCK else [])))
             arg = float(rng.uniform(0.02, 3.0)) if what == "target" else float(rng.choice([0.001, 0.0005]) * dx) if what == "force_dt" else float(rng.uniform(0.005, 0.05))
             ops.append((int(rng.integers(0, len(cuts) - 1)), what, arg))
     return dict(kernel=kernel, ops=ops, scheme=scheme, precision=precision, cols=cols, rows=rows, dx=dx, st=st, bed=bed, man=man, quirks=quirks, kw=kw,
@@ -120,6 +120,9 @@ def test_strict_engine_equals_the_oracle_on_a_random_configuration(seed):
                 dom.reset_counters(); ref.reset_counters()
             elif op == "update":
                 dom.update_timestep(); ref.update_timestep()
+            elif op == "rain":                                 # one more boundary from here on (the fused set changes mid-run)
+                series = np.array([[0.0, 40.0 + 1000.0 * arg], [20.0, 15.0], [40.0, 0.0]])
+                dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, series, 20.0, 40.0); ref.add_uniform(hp.UNIFORM_RAIN_INTENSITY, series, 20.0, 40.0)
             else:                                              # a changed state written to both (raises the level of the wet cells of a patch)
                 cur = ref.download()
                 if not np.isfinite(cur[c["st"][..., 1] > -9000]).all():

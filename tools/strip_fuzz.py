@@ -37,6 +37,14 @@ for seed in range(first, first + count):
         env["STRIP_WORKER_BATCHES"] = f"{first_batch},{steps - first_batch}"
         env["STRIP_WORKER_POKE"] = str(int(rng.integers(0, world)))
         extra = f"rows of rank {env['STRIP_WORKER_POKE']} written by the host after {first_batch}"
+        if rng.random() < 0.5:
+            env["STRIP_WORKER_UPDATE"] = "1"
+            extra += ", then an update of the timestep"
+    elif rng.random() < 0.25:
+        first_batch = int(rng.integers(1, steps - 2))
+        env["STRIP_WORKER_BATCHES"] = f"{first_batch},{steps - first_batch}"
+        env["STRIP_WORKER_UPDATE"] = "1"
+        extra = f"an update of the timestep after {first_batch}"
     cmd = [sys.executable, os.path.join(ROOT, "tests", "strip_threads_worker.py"), str(world), str(scheme), precision, str(overlap), str(rain),
            str(period), str(cell_rank), str(level), variant]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
