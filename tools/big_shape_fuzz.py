@@ -2,7 +2,8 @@
 """STRICT engine against the oracle, bit for bit, on grids TALL enough for the launch geometry of the big runs (XCD bands of
 >= 256 rows, 18-row tiles, several rounds of blocks, many column strips) -- shapes the test suite's fuzz (<= 257 x 101) never
 reaches.  Random shape, scheme, precision, rain, a few dozen iterations each (the oracle is a scalar CPU code).
-usage: big_shape_fuzz.py <first seed> <count>"""
+With a third argument `wide`: 5000-17000 columns by 30-90 rows instead (hundreds of column strips per row of tiles).
+usage: big_shape_fuzz.py <first seed> <count> [wide]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hipims-ocl_amd")]
@@ -18,7 +19,7 @@ for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     scheme = int(rng.choice([hp.SCHEME_GODUNOV, hp.SCHEME_GODUNOV, hp.SCHEME_MUSCL_HANCOCK, hp.SCHEME_INERTIAL]))
     precision = str(rng.choice(["f64", "f64", "f32"]))
-    cols, rows = int(rng.integers(90, 700)), int(rng.integers(2049, 2400))
+    cols, rows = (int(rng.integers(90, 700)), int(rng.integers(2049, 2400))) if len(sys.argv) < 4 else (int(rng.integers(5000, 17000)), int(rng.integers(30, 90)))
     real = np.float64 if precision == "f64" else np.float32
     rain = scheme == hp.SCHEME_GODUNOV and rng.random() < 0.5
     if rain:
