@@ -17,7 +17,7 @@ import hipims_mi as hp  # noqa: E402
 from hipims_mi import strips, synthetic as syn  # noqa: E402
 
 rank, world, where, scheme, precision, rain_on, period = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
-cols, rows, steps = 300, 157, 90
+cols, rows, steps = (int(v) for v in os.environ.get("STRIP_WORKER_GRID", "300,157,90").split(","))
 real = np.float64 if precision == "f64" else np.float32
 g = strips.ghost_rows(scheme) * period
 if rain_on:
