@@ -1006,10 +1006,12 @@ void orc_sim_destroy(orc_sim* s)
 /* prepareSimulation (CSchemeGodunov.cpp:1064-1072): BOTH state buffers receive the same host array */
 void orc_sim_upload(orc_sim* s, const real* state, const real* bed, const real* manning)
 {
-	if (state)   { memcpy(s->primary, state, s->cells * 4 * sizeof(real)); memcpy(s->alt, state, s->cells * 4 * sizeof(real)); }
+	/* the ping-pong phase restarts with the cell states only (prepareSimulation writes both state buffers and clears
+	 * bUseAlternateKernel, CSchemeGodunov.cpp:1064-1075); a write of the bed or Manning buffer alone is a plain
+	 * COCLBuffer::queueWriteAll and leaves it where it is */
+	if (state)   { memcpy(s->primary, state, s->cells * 4 * sizeof(real)); memcpy(s->alt, state, s->cells * 4 * sizeof(real)); s->use_alt = 0; }
 	if (bed)     memcpy(s->bed, bed, s->cells * sizeof(real));
 	if (manning) memcpy(s->manning, manning, s->cells * sizeof(real));
-	s->use_alt = 0;
 }
 
 static orc_bdy* new_bdy(orc_sim* s)
