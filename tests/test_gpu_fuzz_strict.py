@@ -167,20 +167,25 @@ def test_strict_engine_equals_the_oracle_on_a_random_configuration(seed):
 @pytest.mark.parametrize("seed", range(0, N_CASES, 4))
 def test_fast_engine_does_not_depend_on_how_the_iterations_are_batched(seed):
     """The FAST flavour has no oracle to be bit-identical to, but it owes the same bits to itself however the run is cut:
-    one batch (area boundaries fused into the flux kernel wherever they qualify), the random cuts, and single-iteration
-    batches (never fused)."""
+    one batch (area boundaries fused into the flux kernel wherever they qualify), the random cuts, single-iteration
+    batches (never fused), and the host-driven split iteration."""
     c = make_case(seed)
     total = sum(c["cuts"])
     outs = []
-    for plan in ([total], c["cuts"], [1] * total):
+    for plan in ([total], c["cuts"], [1] * total, "split"):
         dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3,
                         friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"],
                         dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=hp.MATH_FAST, kernel=c["kernel"])
         dom.upload(c["st"], c["bed"], c["man"])
         attach(dom, c["bdy"])
         dom.set_target_time(c["target"])
-        for n in plan:
-            dom.step_batch(n)
+        if plan == "split":                                    # the host-driven iteration (hp_step_begin / hp_step_end), with and
+            dom.set_halo_overlap(seed % 8 == 0)                # without the halo part on its own stream
+            for _ in range(total):
+                dom.step_begin(); dom.step_end()
+        else:
+            for n in plan:
+                dom.step_batch(n)
         outs.append((dom.download(), dom.read_scalars()))
         dom.close()
     for out, sc in outs[1:]:
