@@ -1830,6 +1830,10 @@ int hp_strip_update_timestep(hp_domain_t* d)
 	// tst_Reduce over the owned rows of the primary buffer, the maximum over all strips, then tst_UpdateTimestep on every
 	// rank redundantly (CSchemeGodunov.cpp:1189-1195, :1254-1260 with CMPIManager's reduction in between)
 	const ncclDataType_t type = d->desc.precision == 8 ? ncclDouble : ncclFloat;
+	// with the mailboxes the advance kernel WAITS for the other strips' kernels (for a bounded time): launch it only once every
+	// rank's host has arrived here -- the library's all-reduce of the handshake waits without a limit, a strip still busy with
+	// a long upload is no error
+	if (d->peer_agreed && d->comm_world > 1 && (rc = strip_handshake(d)) != HP_OK) return rc;
 	const void* priced = d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK ? d->state[d->use_alt] : d->state[0];     // (as hp_update_timestep)
 	if (d->desc.precision == 8) {
 		if (d->desc.dynamic_dt && (rc = launch_reduce<double>(d, priced, d->own_lo, d->own_hi)) != HP_OK) return rc;
