@@ -154,11 +154,25 @@ struct hp_domain {
 	unsigned*        push_arrived = nullptr;          // device counter of the push blocks
 	bool             peer_direct = false;             // every rank reached its neighbours' buffers: no transfer library inside an iteration
 	bool             push_now = false;                // this iteration's advance kernel carries the ghost rows
+	// the flux launch's own tail block instead of a separate advance launch (LaunchTail, hp_kernels.hpp): small launches only
+	unsigned long long* tail_words = nullptr;         // one word per flux block (EMPTY between launches)
+	bool             tail_allowed = false;            // inside hp_step_batch / hp_strip_step_batch (the host-driven split step has work in between)
+	bool             tail_want = false;               // step_begin_impl: this iteration qualifies, if the launch is small enough
+	int              tail_fresh = 0;                  // ... and this is what its advance would be told
+	bool             tail_done = false;               // launch_march: the launch carried it -- hp_step_end launches nothing
 };
 
 namespace {
 
 void peer_release(hp_domain* d);      // (mailboxes of the peer-written maximum, further down)
+PeerBox peer_box(hp_domain* d, bool use, long timeout_ms = 0);
+PeerPush make_push(const hp_domain* d);
+constexpr unsigned TAIL_MAX_BLOCKS = 65536;    // words allocated per domain
+static unsigned tail_limit()
+{
+	static const unsigned v = std::getenv("HP_TAIL_MAX_BLOCKS") ? (unsigned)std::atoi(std::getenv("HP_TAIL_MAX_BLOCKS")) : TAIL_MAX_BLOCKS;   // (a knob for A/B runs; 768 = one round of blocks)
+	return v < TAIL_MAX_BLOCKS ? v : TAIL_MAX_BLOCKS;
+}
 
 // stencil reach of the scheme = ghost rows one iteration consumes
 inline long strip_ghosts(const hp_domain* d) { return d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK ? 2 : 1; }
@@ -377,16 +391,38 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	                   d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
 	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
-	if (d->fusable)
-		hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, true, T>), dim3(blocks), dim3(256), 0, stream, p,
-		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm,
-		                   (const AreaBdyList<T>*)d->fused_list, d->fuse_next, truncated);
-	else
-		hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, false, T>), dim3(blocks), dim3(256), 0, stream, p,
-		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm,
-		                   (const AreaBdyList<T>*)nullptr, 0, truncated);
+	// a launch that fits the chip in one round carries its own tail block instead of a separate advance launch (LaunchTail)
+	LaunchTail<T> tail{};
+	if (d->tail_want && part == PART_ALL && stream == d->stream && blocks <= tail_limit()) {
+		tail.done = d->tail_words;
+		tail.flux_blocks = blocks;
+		tail.fresh = d->tail_fresh;
+		tail.sc = (Scalars<T>*)d->scalars;
+		tail.slot = (T*)d->cfl_slot;
+		tail.box = peer_box(d, (d->tail_fresh & 4) != 0);
+		tail.edge_rows[0] = tail.edge_rows[1] = tail.edge_rows[2] = tail.edge_rows[3] = 0;
+		if (d->push_now) {
+			tail.push = make_push(d);
+			const int G = (int)d->ghost_rows, rows = (int)d->desc.rows;
+			if (tail.push.to[0]) { tail.edge_rows[0] = G; tail.edge_rows[1] = 2 * G; }
+			if (tail.push.to[1]) { tail.edge_rows[2] = rows - 2 * G; tail.edge_rows[3] = rows - G; }
+		}
+		blocks += 1;
+		d->tail_done = true;
+	}
+#define HP_LAUNCH_K1(FUSED_, TAIL_, LIST_, NEXT_)                                                                                   \
+	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, FUSED_, TAIL_, T>), dim3(blocks), dim3(256), 0, stream, p,                   \
+	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, LIST_, NEXT_,   \
+	                   truncated, tail)
+	if (d->fusable) {
+		if (tail.done) HP_LAUNCH_K1(true, true, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
+		else           HP_LAUNCH_K1(true, false, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
+	} else {
+		if (tail.done) HP_LAUNCH_K1(false, true, (const AreaBdyList<T>*)nullptr, 0);
+		else           HP_LAUNCH_K1(false, false, (const AreaBdyList<T>*)nullptr, 0);
+	}
+#undef HP_LAUNCH_K1
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -485,6 +521,22 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		e1 = d->timing_events[d->timing_used].second;
 		HIP_TRY(hipEventRecord(e0, d->stream));
 	}
+	// The launch's own tail block instead of a separate advance launch (LaunchTail): inside a batch call, the tuned Godunov
+	// kernel, one launch over all rows, nothing between the flux launch and the advance (no stand-alone reduction), and
+	// either no reduction over strips at all or the strips' own transport in its plain shape (no rank with boundaries or a
+	// stale maximum: those iterations pass remembered maxima around, which stays with the advance launch).
+	{
+		static const bool enabled = !(std::getenv("HP_LAUNCH_TAIL") && std::atoi(std::getenv("HP_LAUNCH_TAIL")) == 0);
+		static const bool lonely_too = std::getenv("HP_STRIP_REDUCE_ALWAYS") && std::atoi(std::getenv("HP_STRIP_REDUCE_ALWAYS")) != 0;
+		const bool reduce_after = d->desc.dynamic_dt && cfl_mode == 0 && (basic || d->need_full_reduce);
+		const bool strips_ok = d->comm_world <= 1 ? !(d->comm && lonely_too)
+		                                          : (d->peer_direct && !d->strip_any_bdy && !d->strip_any_full);
+		d->tail_want = enabled && d->tail_allowed && d->desc.scheme == HP_SCHEME_GODUNOV && !basic && !reduce_after && strips_ok &&
+		               !(d->halo_overlap && d->split_now) && d->tail_words != nullptr;
+		const int priced = (d->desc.dynamic_dt && cfl_mode != 0) ? 1 : 0;
+		d->tail_fresh = d->comm_world > 1 ? (priced ? 7 : 4) : priced;
+		d->tail_done = false;
+	}
 	if (d->halo_overlap && d->split_now) {
 		// fork: everything queued so far (previous advance, boundaries, ring pricing) happens-before the halo
 		// segments; they run on their own stream, next to the interior segments on the domain's stream
@@ -499,6 +551,7 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		// join: the CFL maximum (and anything after it on the domain's stream) needs both launches
 		HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_halo, 0));
 	} else if ((rc = launch_flux<T, STRICT>(d, src, dst, cfl_mode, PART_ALL, d->stream)) != HP_OK) return rc;
+	d->tail_want = false;
 	if (sample) {
 		HIP_TRY(hipEventRecord(e1, d->stream));
 		d->timing_used++;
@@ -519,13 +572,35 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	return HP_OK;
 }
 
+// the ghost rows an advance kernel (or a launch's tail block) carries to the strip neighbours: the first / last `ghost_rows`
+// owned rows of the state this iteration wrote go into the neighbours' ghost rows of the same ping-pong buffer
+PeerPush make_push(const hp_domain* d)
+{
+	const long G = d->ghost_rows, rows = d->desc.rows;
+	const size_t row_bytes = (size_t)d->desc.cols * 4 * d->esize;
+	const int b = d->use_alt ^ 1;
+	const char* mine = (const char*)d->state[b];
+	PeerPush push{};
+	push.count = (unsigned)((size_t)G * row_bytes / 16);
+	push.arrived = d->push_arrived;
+	if (d->peer_state[0][b]) {
+		push.from[0] = (const uint4*)(mine + (size_t)G * row_bytes);
+		push.to[0] = (uint4*)((char*)d->peer_state[0][b] + (size_t)(d->peer_rows[0] - G) * row_bytes);
+	}
+	if (d->peer_state[1][b]) {
+		push.from[1] = (const uint4*)(mine + (size_t)(rows - 2 * G) * row_bytes);
+		push.to[1] = (uint4*)d->peer_state[1][b];
+	}
+	return push;
+}
+
 // kernel argument of a reduction through the mailboxes (one per reduction: its parity picks the mailbox set)
 static long peer_timeout_ms()
 {
 	static const long ms = std::getenv("HP_PEER_TIMEOUT_MS") ? std::atol(std::getenv("HP_PEER_TIMEOUT_MS")) : 10000;
 	return ms > 0 ? ms : 10000;
 }
-PeerBox peer_box(hp_domain* d, bool use, long timeout_ms = 0)
+PeerBox peer_box(hp_domain* d, bool use, long timeout_ms)
 {
 	PeerBox box{};
 	if (!use) return box;
@@ -539,25 +614,15 @@ PeerBox peer_box(hp_domain* d, bool use, long timeout_ms = 0)
 template <typename T> int step_end_impl(hp_domain* d)
 {
 	const Params<T> p = make_params<T>(d);
-	const PeerBox box = peer_box(d, (d->adv_fresh & 4) != 0);
-	if (d->push_now) {
-		// the ghost rows travel inside the advance kernel (PeerPush): the first / last `ghost_rows` owned rows of the state
-		// this iteration wrote go into the neighbours' ghost rows of the same ping-pong buffer
-		const long G = d->ghost_rows, rows = d->desc.rows;
-		const size_t row_bytes = (size_t)d->desc.cols * 4 * d->esize;
-		const int b = d->use_alt ^ 1;
-		const char* mine = (const char*)d->state[b];
-		PeerPush push{};
-		push.count = (unsigned)((size_t)G * row_bytes / 16);
-		push.arrived = d->push_arrived;
-		if (d->peer_state[0][b]) {
-			push.from[0] = (const uint4*)(mine + (size_t)G * row_bytes);
-			push.to[0] = (uint4*)((char*)d->peer_state[0][b] + (size_t)(d->peer_rows[0] - G) * row_bytes);
-		}
-		if (d->peer_state[1][b]) {
-			push.from[1] = (const uint4*)(mine + (size_t)(rows - 2 * G) * row_bytes);
-			push.to[1] = (uint4*)d->peer_state[1][b];
-		}
+	const PeerBox box = d->tail_done ? PeerBox{} : peer_box(d, (d->adv_fresh & 4) != 0);   // (the tail block took its own: one per round)
+	if (d->tail_done) {
+		// the flux launch's tail block has done it all (LaunchTail): nothing to launch
+		d->tail_done = false;
+		d->push_now = false;
+		d->fork_is_advance = false;
+	} else if (d->push_now) {
+		// the ghost rows travel inside the advance kernel (PeerPush)
+		const PeerPush push = make_push(d);
 		static const unsigned per_block = std::getenv("HP_PUSH_PER_BLOCK") ? (unsigned)std::atoi(std::getenv("HP_PUSH_PER_BLOCK")) : 1024u;
 		const unsigned blocks = (push.to[0] || push.to[1]) ? std::min(32u, (push.count + per_block - 1u) / per_block) : 1u;
 		hipLaunchKernelGGL((advance_time<false, T>), dim3(blocks), dim3(256), 0, d->stream, p, (Scalars<T>*)d->scalars,
@@ -854,6 +919,8 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	HIP_TRY_C(hipMalloc(&d->scalars, 256));
 	HIP_TRY_C(hipMalloc(&d->cfl_slot, CFL_SLOT_BYTES));
 
+	HIP_TRY_C(hipMalloc((void**)&d->tail_words, (TAIL_MAX_BLOCKS + 8) * sizeof(unsigned long long)));
+	HIP_TRY_C(hipMemset(d->tail_words, 0xff, (TAIL_MAX_BLOCKS + 8) * sizeof(unsigned long long)));      // every word EMPTY
 	HIP_TRY_C(hipHostMalloc(&d->host_scalars, 512, hipHostMallocDefault));
 	HIP_TRY_C(hipMemset(d->state[0], 0, d->cells * 4 * d->esize));
 	HIP_TRY_C(hipMemset(d->state[1], 0, d->cells * 4 * d->esize));
@@ -888,7 +955,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	for (auto& ev : d->timing_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
 	hipFree(d->scalars); hipFree(d->cfl_slot);
-	hipFree(d->saved_state); hipFree(d->saved_scalars); hipFree(d->fused_list);
+	hipFree(d->saved_state); hipFree(d->saved_scalars); hipFree(d->fused_list); hipFree(d->tail_words);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
 	if (d->ev_stop) hipEventDestroy(d->ev_stop);
@@ -1231,7 +1298,10 @@ int hp_step_batch(hp_domain_t* d, uint32_t n_iterations)
 		// (K1 FUSED) every iteration but the last carries its successor's rain / loss: between batches the buffers are
 		// what the reference's are -- a download never sees rain of an iteration that has not begun
 		d->fuse_next = i + 1 < n_iterations;
-		if ((rc = dispatch_begin(d)) != HP_OK) return rc;
+		d->tail_allowed = true;                        // nothing is queued between the flux launch and the advance in this loop
+		rc = dispatch_begin(d);
+		d->tail_allowed = false;
+		if (rc != HP_OK) return rc;
 		if ((rc = dispatch_end(d)) != HP_OK) return rc;
 	}
 	d->fuse_next = 0;
@@ -1801,10 +1871,13 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 		// halo and an interior launch)
 		const bool exchange = d->ghost_valid - g < g;
 		d->split_now = exchange && !d->peer_direct;   // (rows that travel inside the advance kernel need no launch of their own)
-		if ((rc = dispatch_begin(d)) != HP_OK) return rc;
+		d->push_now = exchange && d->peer_direct;     // ... and leave with the advance kernel, or with the flux launch's tail block
+		d->tail_allowed = true;
+		rc = dispatch_begin(d);
+		d->tail_allowed = false;
+		if (rc != HP_OK) return rc;
 		if (exchange) {
-			if (d->peer_direct) d->push_now = true;
-			else if ((rc = strip_halo_exchange(d)) != HP_OK) return rc;
+			if (!d->peer_direct && (rc = strip_halo_exchange(d)) != HP_OK) return rc;
 			d->ghost_valid = d->ghost_rows;
 		} else {
 			d->ghost_valid -= g;

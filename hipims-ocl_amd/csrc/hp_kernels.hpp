@@ -251,6 +251,89 @@ __global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const i
 	advance_body<UPDATE_ONLY>(p, sc, slot, fresh & 3);
 }
 
+// -------------------------------------------------------------------------------------------------
+// The launch's own tail (small launches only: a strip of a strong-scaling run, the example's 342 x 195 grid -- launches that
+// fit the chip in one round and are bound by the hand-over between dependent kernels, not by bytes: 11.6 us per iteration
+// for 3 us of arithmetic on the example).  Instead of a separate advance launch behind the flux launch, the
+// flux launch carries ONE more block.  Every flux block ends by storing its maximum into its own word of `done`
+// (a plain 8-byte store: the word doubles as the block's "I am through" flag, so there is no atomic to wait for and no
+// ordering between two memory operations to arrange); the tail block polls all the words, folds them, empties them for the
+// next launch, and then does what advance_time does (ghost rows to the neighbours, mailbox round, advance_body).  The tail
+// block has the launch's highest index: when it is dispatched every flux block of its XCD has been, and the other XCDs'
+// blocks never wait for it -- it cannot starve what it waits for.  It needs nothing of the flux blocks but their maxima: the
+// new state is the NEXT launch's business, which the stream orders behind this whole launch.
+// -------------------------------------------------------------------------------------------------
+template <typename T> struct LaunchTail {
+	unsigned long long* done;      // nullptr: no tail (the classic two launches)
+	unsigned            flux_blocks;
+	int                 fresh;     // advance_time's `fresh`
+	Scalars<T>*         sc;
+	T*                  slot;
+	PeerBox             box;
+	PeerPush            push;
+	int                 edge_rows[4];   // [lo, hi) of the rows the tail block sends south, [lo, hi) of those it sends north (empty: lo >= hi)
+};
+
+// every wavefront of every flux block, at its very end; `m` = the wavefront's maximum (0 when this launch prices nothing).
+// The tail block needs nothing else of a flux block -- except the rows it sends on to the strip neighbours: a block whose
+// tile holds such rows makes its stores visible (release at agent scope: the tail block runs on some other CU, maybe another
+// XCD) before it reports; all the others report without waiting for theirs.
+template <typename T>
+__device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const T m, const int wave, const int lane, const long y0, const long y1)
+{
+	__shared__ T part[4];
+	const bool sends = (y0 < tail.edge_rows[1] && y1 > tail.edge_rows[0]) || (y0 < tail.edge_rows[3] && y1 > tail.edge_rows[2]);   // wave-uniform
+	if (sends) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	if (lane == 0) part[wave] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		T b = part[0];
+		for (int w = 1; w < 4; ++w) if (part[w] > b) b = part[w];
+		__hip_atomic_store(tail.done + blockIdx.x, peer_bits(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
+template <typename T>
+__device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail<T>& tail)
+{
+	__shared__ T part[4];
+	T m = T(0);
+	for (unsigned i = threadIdx.x; i < tail.flux_blocks; i += blockDim.x) {
+		unsigned long long w;
+		while ((w = __hip_atomic_load(tail.done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == PEER_EMPTY) __builtin_amdgcn_s_sleep(1);
+		__hip_atomic_store(tail.done + i, PEER_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		T v;
+		peer_value(w, v);
+		if (v > m) m = v;
+	}
+	m = wave_max(m);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 4; ++w) if (part[w] > m) m = part[w];
+		if (tail.fresh & 1) tail.slot[0] = m;                   // where the atomic maxima of a classic launch would have gathered
+		part[0] = m;
+	}
+	// ghost rows to the neighbours (PeerPush), by this one block
+	if (tail.push.to[0] || tail.push.to[1]) {
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (pairs with the release of the flux blocks that wrote those rows)
+		for (int side = 0; side < 2; ++side) {
+			if (!tail.push.to[side]) continue;
+			for (unsigned i = threadIdx.x; i < tail.push.count; i += blockDim.x) tail.push.to[side][i] = tail.push.from[side][i];
+		}
+		__threadfence_system();
+	}
+	__syncthreads();                                            // slot[0] and the rows are out before wave 0 goes on
+	if (threadIdx.x >= 64) return;
+	if (tail.fresh & 4) {
+		const T local = (tail.fresh & 1) ? part[0] : atomic_peek(tail.slot);
+		const T all = peer_reduce_max(tail.box, local);
+		if (threadIdx.x == 0 && (tail.fresh & 2)) tail.slot[SLOT_GLOBAL] = all;
+	}
+	if (threadIdx.x != 0) return;
+	advance_body<false>(p, tail.sc, tail.slot, tail.fresh & 3);
+}
+
 // diagnostic / connection test: one reduction of a caller-given word (hp_strip_peer_round)
 __global__ void peer_round(const PeerBox box, const double value)
 {
@@ -491,18 +574,23 @@ template <typename T> struct FusedBdy {
 // is the reference's buffer, without the next iteration's rain -- and the kernel declines when dt's sign is not certain
 // (within VERY_SMALL of the sync point, at the end time): the word at cfl_slot[SLOT_BDY] tells the stand-alone pass of
 // the next iteration whether there is anything left for it to do.
-template <bool STRICT, int CFL_MODE, bool FUSED, typename T>
+template <bool STRICT, int CFL_MODE, bool FUSED, bool TAIL, typename T>
 __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
                                                      const TileMap tm, const AreaBdyList<T>* __restrict__ fused_list,
-                                                     const int fuse_next, const int truncated)
+                                                     const int fuse_next, const int truncated, const LaunchTail<T> tail)
 {
+	if (TAIL && blockIdx.x >= tail.flux_blocks) {                                  // the launch's own tail (LaunchTail above)
+		launch_tail(p, tail);
+		return;
+	}
 	// the wave index is made a scalar explicitly: everything derived from it (tile rows, buffer descriptors, row
 	// offsets) then lives in SGPRs and the buffer accesses need no waterfall loop
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	long strip, y0, y1;                                                            // rows [y0, y1) are updated
+	T wave_vmax = T(0);                                                            // (for the tail block, when there is one)
 	if (tile_rows(tm, wave, strip, y0, y1)) {                                      // wave-uniform
 
 	const long x = strip * MARCH_COLS + lane;
@@ -791,12 +879,14 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		// the edge ring (never written, priced at upload) joins the maximum before any cross-rank all-reduce
 		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
-		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
+		if (TAIL) wave_vmax = vmax;
+		else if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
 	// (FUSED) tell the next iteration's stand-alone boundary pass whether anything is left for it to do.  Every wavefront
 	// reaches the same decision from the same scalars; one of them writes it down.
 	if (FUSED && blockIdx.x == 0 && wave == 0 && lane == 0) cfl_slot[SLOT_BDY] = fuse_flag ? T(1) : T(0);
 	}   // tile / strip guard
+	if (TAIL) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
 
 // -------------------------------------------------------------------------------------------------
