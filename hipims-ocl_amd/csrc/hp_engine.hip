@@ -393,6 +393,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
 	// a launch that fits the chip in one round carries its own tail block instead of a separate advance launch (LaunchTail)
 	LaunchTail<T> tail{};
+	bool pushing = false;
 	if (d->tail_want && part == PART_ALL && stream == d->stream && blocks <= tail_limit()) {
 		tail.done = d->tail_words;
 		tail.flux_blocks = blocks;
@@ -401,11 +402,21 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 		tail.slot = (T*)d->cfl_slot;
 		tail.box = peer_box(d, (d->tail_fresh & 4) != 0);
 		tail.edge_rows[0] = tail.edge_rows[1] = tail.edge_rows[2] = tail.edge_rows[3] = 0;
+		tail.peer_rows[0] = tail.peer_rows[1] = nullptr;
 		if (d->push_now) {
-			tail.push = make_push(d);
-			const int G = (int)d->ghost_rows, rows = (int)d->desc.rows;
-			if (tail.push.to[0]) { tail.edge_rows[0] = G; tail.edge_rows[1] = 2 * G; }
-			if (tail.push.to[1]) { tail.edge_rows[2] = rows - 2 * G; tail.edge_rows[3] = rows - G; }
+			// the tiles that compute this strip's first / last `ghost_rows` owned rows store them into the neighbours as well: the
+			// neighbour's pointer is shifted so that this strip's cell index lands on the neighbour's copy of the cell
+			const long G = d->ghost_rows, rows = d->desc.rows, cols = d->desc.cols;
+			const int b = d->use_alt ^ 1;
+			if (d->peer_state[0][b]) {
+				tail.peer_rows[0] = (State4<T>*)d->peer_state[0][b] + (d->peer_rows[0] - 2 * G) * cols;     // my row G -> its row rows_s - G
+				tail.edge_rows[0] = (int)G; tail.edge_rows[1] = (int)(2 * G);
+			}
+			if (d->peer_state[1][b]) {
+				tail.peer_rows[1] = (State4<T>*)d->peer_state[1][b] - (rows - 2 * G) * cols;                // my row rows - 2G -> its row 0
+				tail.edge_rows[2] = (int)(rows - 2 * G); tail.edge_rows[3] = (int)(rows - G);
+			}
+			pushing = true;
 		}
 		blocks += 1;
 		d->tail_done = true;
@@ -415,12 +426,15 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, LIST_, NEXT_,   \
 	                   truncated, tail)
+	const int tail_kind = !tail.done ? 0 : pushing ? 2 : 1;
 	if (d->fusable) {
-		if (tail.done) HP_LAUNCH_K1(true, true, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
-		else           HP_LAUNCH_K1(true, false, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
+		if (tail_kind == 2)      HP_LAUNCH_K1(true, 2, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
+		else if (tail_kind == 1) HP_LAUNCH_K1(true, 1, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
+		else                     HP_LAUNCH_K1(true, 0, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
 	} else {
-		if (tail.done) HP_LAUNCH_K1(false, true, (const AreaBdyList<T>*)nullptr, 0);
-		else           HP_LAUNCH_K1(false, false, (const AreaBdyList<T>*)nullptr, 0);
+		if (tail_kind == 2)      HP_LAUNCH_K1(false, 2, (const AreaBdyList<T>*)nullptr, 0);
+		else if (tail_kind == 1) HP_LAUNCH_K1(false, 1, (const AreaBdyList<T>*)nullptr, 0);
+		else                     HP_LAUNCH_K1(false, 0, (const AreaBdyList<T>*)nullptr, 0);
 	}
 #undef HP_LAUNCH_K1
 	HIP_TRY(hipGetLastError());

@@ -258,7 +258,7 @@ __global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const i
 // flux launch carries ONE more block.  Every flux block ends by storing its maximum into its own word of `done`
 // (a plain 8-byte store: the word doubles as the block's "I am through" flag, so there is no atomic to wait for and no
 // ordering between two memory operations to arrange); the tail block polls all the words, folds them, empties them for the
-// next launch, and then does what advance_time does (ghost rows to the neighbours, mailbox round, advance_body).  The tail
+// next launch, and then does what advance_time does (mailbox round, advance_body; the ghost rows have left with the tiles).  The tail
 // block has the launch's highest index: when it is dispatched every flux block of its XCD has been, and the other XCDs'
 // blocks never wait for it -- it cannot starve what it waits for.  It needs nothing of the flux blocks but their maxima: the
 // new state is the NEXT launch's business, which the stream orders behind this whole launch.
@@ -270,8 +270,13 @@ template <typename T> struct LaunchTail {
 	Scalars<T>*         sc;
 	T*                  slot;
 	PeerBox             box;
-	PeerPush            push;
-	int                 edge_rows[4];   // [lo, hi) of the rows the tail block sends south, [lo, hi) of those it sends north (empty: lo >= hi)
+	// ghost rows (PUSH instantiations of the flux kernels): the strip's first / last owned rows are stored TWICE by the tile that
+	// computes them -- into this strip's new state and, through peer_rows[side], into the neighbour's ghost rows of the same
+	// ping-pong buffer.  peer_rows[side] is shifted so that THIS strip's cell index addresses the neighbour's copy of the cell.
+	// Cells the kernel leaves untouched (quirk Q3) are left untouched there too: both copies started equal (the host uploads
+	// strips with their ghost rows) and receive the same stores ever after.
+	State4<T>*          peer_rows[2];   // [0] south neighbour, [1] north; nullptr: no neighbour / nothing to send this iteration
+	int                 edge_rows[4];   // [lo, hi) of the rows that go south, [lo, hi) of those that go north (empty: lo >= hi)
 };
 
 // every wavefront of every flux block, at its very end; `m` = the wavefront's maximum (0 when this launch prices nothing).
@@ -282,8 +287,10 @@ template <typename T>
 __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const T m, const int wave, const int lane, const long y0, const long y1)
 {
 	__shared__ T part[4];
+	// a tile that stored rows into a neighbour reports only once those stores have been acknowledged (its own state's stores
+	// need no such wait: nobody reads them before the next launch); all the other tiles report at once
 	const bool sends = (y0 < tail.edge_rows[1] && y1 > tail.edge_rows[0]) || (y0 < tail.edge_rows[3] && y1 > tail.edge_rows[2]);   // wave-uniform
-	if (sends) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	if (sends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	if (lane == 0) part[wave] = m;
 	__syncthreads();
 	if (threadIdx.x == 0) {
@@ -314,16 +321,7 @@ __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail
 		if (tail.fresh & 1) tail.slot[0] = m;                   // where the atomic maxima of a classic launch would have gathered
 		part[0] = m;
 	}
-	// ghost rows to the neighbours (PeerPush), by this one block
-	if (tail.push.to[0] || tail.push.to[1]) {
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (pairs with the release of the flux blocks that wrote those rows)
-		for (int side = 0; side < 2; ++side) {
-			if (!tail.push.to[side]) continue;
-			for (unsigned i = threadIdx.x; i < tail.push.count; i += blockDim.x) tail.push.to[side][i] = tail.push.from[side][i];
-		}
-		__threadfence_system();
-	}
-	__syncthreads();                                            // slot[0] and the rows are out before wave 0 goes on
+	__syncthreads();                                            // (part[0] for wave 0)
 	if (threadIdx.x >= 64) return;
 	if (tail.fresh & 4) {
 		const T local = (tail.fresh & 1) ? part[0] : atomic_peek(tail.slot);
@@ -425,6 +423,11 @@ __device__ __forceinline__ void store_fence(const hp_u32x4& a, const unsigned vo
 // `voff` selects per lane between the cell's offset and HP_OOB (dropped by the range check); it is pinned in a VGPR so
 // that the compiler cannot turn the select into two exec-masked stores (memory instructions under divergent control
 // flow make the s_waitcnt vmcnt bookkeeping conservative).
+// AUX: the store's cache policy.  HP_AUX_THROUGH (sc0 sc1: written through to memory at system scope) is for rows stored into a
+// strip neighbour's buffer: they must not linger in this XCD's L2 -- the reader is another GPU, or another launch that
+// starts as soon as this strip's tail block has spoken, before THIS launch ends and writes its L2 back.
+constexpr int HP_AUX_THROUGH = 1 | 16;
+template <int AUX = HP_AUX_STATE_ST>
 __device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgpu_buffer_rsrc_t r, unsigned voff, const unsigned soff)
 {
 	asm volatile("" : "+v"(voff));
@@ -433,17 +436,18 @@ __device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgp
 	a.z = (unsigned)__double2loint(s.zmax); a.w = (unsigned)__double2hiint(s.zmax);
 	b.x = (unsigned)__double2loint(s.qx); b.y = (unsigned)__double2hiint(s.qx);
 	b.z = (unsigned)__double2loint(s.qy); b.w = (unsigned)__double2hiint(s.qy);
-	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, HP_AUX_STATE_ST);
-	__builtin_amdgcn_raw_buffer_store_b128(b, r, (int)voff + 16, (int)soff, HP_AUX_STATE_ST);
+	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, AUX);
+	__builtin_amdgcn_raw_buffer_store_b128(b, r, (int)voff + 16, (int)soff, AUX);
 	store_fence(a, voff, soff);
 	store_fence(b, voff, soff);
 }
+template <int AUX = HP_AUX_STATE_ST>
 __device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu_buffer_rsrc_t r, unsigned voff, const unsigned soff)
 {
 	asm volatile("" : "+v"(voff));
 	hp_u32x4 a;
 	a.x = __float_as_uint(s.z); a.y = __float_as_uint(s.zmax); a.z = __float_as_uint(s.qx); a.w = __float_as_uint(s.qy);
-	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, HP_AUX_STATE_ST);
+	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, AUX);
 	store_fence(a, voff, soff);
 }
 
@@ -574,7 +578,7 @@ template <typename T> struct FusedBdy {
 // is the reference's buffer, without the next iteration's rain -- and the kernel declines when dt's sign is not certain
 // (within VERY_SMALL of the sync point, at the end time): the word at cfl_slot[SLOT_BDY] tells the stand-alone pass of
 // the next iteration whether there is anything left for it to do.
-template <bool STRICT, int CFL_MODE, bool FUSED, bool TAIL, typename T>
+template <bool STRICT, int CFL_MODE, bool FUSED, int TAIL, typename T>          // TAIL: 0 none, 1 tail block, 2 tail block + ghost rows stored into the neighbours
 __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
                                                      const TileMap tm, const AreaBdyList<T>* __restrict__ fused_list,
                                                      const int fuse_next, const int truncated, const LaunchTail<T> tail)
 {
-	if (TAIL && blockIdx.x >= tail.flux_blocks) {                                  // the launch's own tail (LaunchTail above)
+	if (TAIL != 0 && blockIdx.x >= tail.flux_blocks) {                             // the launch's own tail (LaunchTail above)
 		launch_tail(p, tail);
 		return;
 	}
@@ -704,9 +708,18 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	const __amdgpu_buffer_rsrc_t srd_dst = make_srd(dst + cell0, cells_left * sizeof(State4<T>));
 	const __amdgpu_buffer_rsrc_t srd_bed = make_srd(bed + cell0, cells_left * sizeof(T));
 	const __amdgpu_buffer_rsrc_t srd_man = make_srd(manning + cell0, cells_left * sizeof(T));
+	// (TAIL == 2) the same window of the neighbours' buffers: a row of the edge ranges is stored there as well, every other
+	// row presents the out-of-range offset -- one more store instruction per row, no branch around it (see the store below)
+	const __amdgpu_buffer_rsrc_t srd_peer0 = make_srd((TAIL == 2 && tail.peer_rows[0] ? tail.peer_rows[0] : dst) + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_peer1 = make_srd((TAIL == 2 && tail.peer_rows[1] ? tail.peer_rows[1] : dst) + cell0, cells_left * sizeof(State4<T>));
 	const unsigned lane_col = (unsigned)(xc - strip * MARCH_COLS);                // clamped column within the window
 	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
 	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
+	auto store_peer = [&](const State4<T>& v, const long y, const bool write_lane) {
+		const bool e0 = (int)y >= tail.edge_rows[0] && (int)y < tail.edge_rows[1];   // wave-uniform
+		const bool e1 = (int)y >= tail.edge_rows[2] && (int)y < tail.edge_rows[3];
+		buf_store_state<HP_AUX_THROUGH>(v, e1 ? srd_peer1 : srd_peer0, (write_lane && (e0 || e1)) ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+	};
 
 	// `live` = false: a prefetch slot that no row step will read (the row beyond the tile's north halo row).  The lanes
 	// then present an out-of-range offset: the range check answers with zeros and NO memory request is made -- the slot
@@ -797,6 +810,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		State4<T> stored = out;
 		if (FUSED && fuse) stored = apply_fused(out, rc.zb, y);
 		buf_store_state(stored, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+		if (TAIL == 2) store_peer(stored, y, write);
 		const bool priced = (int)y >= tm.price_lo && (int)y < tm.price_hi;       // wave-uniform
 		if (!priced) {
 		} else if (CFL_MODE == 1) {
@@ -835,6 +849,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			fS = face_dry_for_right<AXIS_Y, STRICT>(sC, sN, vs);
 			// (FUSED: the only cells this loop stores are nulls, which no boundary kernel touches)
 			buf_store_state(rc.c, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+			if (TAIL == 2) store_peer(rc.c, y, write);
 			if (!((int)y >= tm.price_lo && (int)y < tm.price_hi)) {
 			} else if (CFL_MODE == 1) {
 				if (write) {
@@ -870,7 +885,11 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 					const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, zb, p.qs);
 					if (s > vmax) vmax = s;
 				}
-				if (FUSED && fuse) dst[id] = apply_fused(c, zb, y);
+				if (FUSED && fuse) {
+					const State4<T> rained = apply_fused(c, zb, y);
+					dst[id] = rained;
+					if (TAIL == 2) store_peer(rained, y, true);                          // (the neighbour's copy of the cell gets the same store)
+				}
 			}
 		}
 	}
@@ -879,14 +898,14 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		// the edge ring (never written, priced at upload) joins the maximum before any cross-rank all-reduce
 		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
-		if (TAIL) wave_vmax = vmax;
+		if (TAIL != 0) wave_vmax = vmax;
 		else if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
 	// (FUSED) tell the next iteration's stand-alone boundary pass whether anything is left for it to do.  Every wavefront
 	// reaches the same decision from the same scalars; one of them writes it down.
 	if (FUSED && blockIdx.x == 0 && wave == 0 && lane == 0) cfl_slot[SLOT_BDY] = fuse_flag ? T(1) : T(0);
 	}   // tile / strip guard
-	if (TAIL) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
+	if (TAIL != 0) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
 
 // -------------------------------------------------------------------------------------------------
