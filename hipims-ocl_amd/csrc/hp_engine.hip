@@ -356,6 +356,27 @@ inline void launch_rows(const hp_domain* d, long g, long& lo, long& hi)
 	hi = d->desc.rows - (north ? keep : g);
 }
 
+// the launch's own tail block for the kernels that do not carry ghost rows themselves (K2, K6): none while rows have to
+// leave with this iteration (those iterations keep the advance launch, which copies them)
+template <typename T> LaunchTail<T> plain_tail(hp_domain* d, unsigned& blocks, int part, hipStream_t stream)
+{
+	LaunchTail<T> tail{};
+	// (measured, tools/small_launch_probe2.py: K2 and K6 gain 7-40 % up to a few rounds of blocks and LOSE 0.5 / 1.7 % at the
+	// 4608 blocks of 4096^2, where K1 still gains 1.1 %: two rounds of blocks are the limit here)
+	if (!(d->tail_want && !d->push_now && part == PART_ALL && stream == d->stream && blocks <= std::min(tail_limit(), 1536u))) return tail;
+	tail.done = d->tail_words;
+	tail.flux_blocks = blocks;
+	tail.fresh = d->tail_fresh;
+	tail.sc = (Scalars<T>*)d->scalars;
+	tail.slot = (T*)d->cfl_slot;
+	tail.box = peer_box(d, (d->tail_fresh & 4) != 0);
+	tail.edge_rows[0] = tail.edge_rows[1] = tail.edge_rows[2] = tail.edge_rows[3] = 0;
+	tail.peer_rows[0] = tail.peer_rows[1] = nullptr;
+	blocks += 1;
+	d->tail_done = true;
+	return tail;
+}
+
 template <typename T, bool STRICT, int CFL_MODE>
 int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
 {
@@ -367,14 +388,14 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	if (!make_tile_map(lo, hi, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks,
 	                   16, d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
-	if (d->manning_uniform)
-		hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, true, T>), dim3(blocks), dim3(256), 0, stream, p,
-		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
-	else
-		hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, false, T>), dim3(blocks), dim3(256), 0, stream, p,
-		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
+	const LaunchTail<T> tail = plain_tail<T>(d, blocks, part, stream);
+#define HP_LAUNCH_K2(UNIFORM_, TAIL_)                                                                                               \
+	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, UNIFORM_, TAIL_, T>), dim3(blocks), dim3(256), 0, stream, p,                   \
+	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, tail)
+	if (d->manning_uniform) { if (tail.done) HP_LAUNCH_K2(true, true); else HP_LAUNCH_K2(true, false); }
+	else                    { if (tail.done) HP_LAUNCH_K2(false, true); else HP_LAUNCH_K2(false, false); }
+#undef HP_LAUNCH_K2
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -452,9 +473,15 @@ int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, i
 	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
 	                   d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
-	hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, T>), dim3(blocks), dim3(256), 0, stream, p,
-	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm);
+	const LaunchTail<T> tail = plain_tail<T>(d, blocks, part, stream);
+	if (tail.done)
+		hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, true, T>), dim3(blocks), dim3(256), 0, stream, p,
+		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, tail);
+	else
+		hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, false, T>), dim3(blocks), dim3(256), 0, stream, p,
+		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
+		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, tail);
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -545,7 +572,7 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		const bool reduce_after = d->desc.dynamic_dt && cfl_mode == 0 && (basic || d->need_full_reduce);
 		const bool strips_ok = d->comm_world <= 1 ? !(d->comm && lonely_too)
 		                                          : (d->peer_direct && !d->strip_any_bdy && !d->strip_any_full);
-		d->tail_want = enabled && d->tail_allowed && d->desc.scheme == HP_SCHEME_GODUNOV && !basic && !reduce_after && strips_ok &&
+		d->tail_want = enabled && d->tail_allowed && !basic && !reduce_after && strips_ok &&
 		               !(d->halo_overlap && d->split_now) && d->tail_words != nullptr;
 		const int priced = (d->desc.dynamic_dt && cfl_mode != 0) ? 1 : 0;
 		d->tail_fresh = d->comm_world > 1 ? (priced ? 7 : 4) : priced;

@@ -940,15 +940,20 @@ __device__ __forceinline__ Raw<T> raw_from_west(const Raw<T>& r)
 // would spill there and keeps two; fp32 has room for four
 template <bool STRICT, typename T> constexpr int muscl_waves() { return sizeof(T) == 4 ? 4 : (STRICT ? 2 : 3); }
 
-template <bool STRICT, int CFL_MODE, bool UNIFORM_N, typename T>
+template <bool STRICT, int CFL_MODE, bool UNIFORM_N, bool TAIL, typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves<STRICT, T>()))) void muscl_march(const Params<T> p, const Scalars<T>* sc,
                                                    const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                    State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                    T* cfl_slot, const T* __restrict__ edge_max,
-                                                   const TileMap tm)
+                                                   const TileMap tm, const LaunchTail<T> tail)
 {
+	if (TAIL && blockIdx.x >= tail.flux_blocks) {                                  // the launch's own tail block (LaunchTail, K4)
+		launch_tail(p, tail);
+		return;
+	}
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: see K1
 	long strip, y0, y1;                                                            // corrector domain 2..n-3 (:569-573)
+	T wave_vmax = T(0);
 	if (tile_rows(tm, wave, strip, y0, y1)) {
 
 	// Register diet for a third wave per SIMD: what a row does not need while its two faces are being solved -- the
@@ -1177,9 +1182,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	if (CFL_MODE != 0) {
 		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
-		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
+		if (TAIL) wave_vmax = vmax;
+		else if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
 	}   // tile / strip guard
+	if (TAIL) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1194,15 +1201,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 //  dt <= 0 returns WITHOUT writing dst (:61-62, unlike the Godunov kernel), all-dry cells likewise (:103, Q3):
 //  both leave dst stale, and the fused CFL epilogue prices what dst really holds.
 // -------------------------------------------------------------------------------------------------
-template <bool STRICT, int CFL_MODE, typename T>
+template <bool STRICT, int CFL_MODE, bool TAIL, typename T>
 __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const Scalars<T>* sc,
                                                       const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                       State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                       T* cfl_slot, const T* __restrict__ edge_max,
-                                                      const TileMap tm)
+                                                      const TileMap tm, const LaunchTail<T> tail)
 {
+	if (TAIL && blockIdx.x >= tail.flux_blocks) {                                  // the launch's own tail block (LaunchTail, K4)
+		launch_tail(p, tail);
+		return;
+	}
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: see K1
 	long strip, y0, y1;
+	T wave_vmax = T(0);
 	if (tile_rows(tm, wave, strip, y0, y1)) {
 
 	const long x = strip * MARCH_COLS + lane;
@@ -1314,9 +1326,11 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 	if (CFL_MODE != 0) {
 		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
-		if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
+		if (TAIL) wave_vmax = vmax;
+		else if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
 	}   // tile / strip guard
+	if (TAIL) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
 
 // max wave speed over the edge ring (cells no kernel ever writes): the `w` outermost columns on rows
