@@ -356,14 +356,14 @@ inline void launch_rows(const hp_domain* d, long g, long& lo, long& hi)
 	hi = d->desc.rows - (north ? keep : g);
 }
 
-// the launch's own tail block for the kernels that do not carry ghost rows themselves (K2, K6): none while rows have to
-// leave with this iteration (those iterations keep the advance launch, which copies them)
-template <typename T> LaunchTail<T> plain_tail(hp_domain* d, unsigned& blocks, int part, hipStream_t stream)
+// The launch's own tail block (LaunchTail, hp_kernels.hpp), and with it the rows that leave with this iteration: the tiles that
+// compute the strip's first / last `ghost_rows` owned rows store them into the neighbours as well -- the neighbour's pointer
+// is shifted so that this strip's cell index lands on the neighbour's copy of the cell.  `limit`: launches of more blocks keep
+// the advance launch.  Returns 0 (no tail), 1 (tail block) or 2 (tail block + rows stored into the neighbours).
+template <typename T> int make_tail(hp_domain* d, unsigned& blocks, int part, hipStream_t stream, unsigned limit, LaunchTail<T>& tail)
 {
-	LaunchTail<T> tail{};
-	// (measured, tools/small_launch_probe2.py: K2 and K6 gain 7-40 % up to a few rounds of blocks and LOSE 0.5 / 1.7 % at the
-	// 4608 blocks of 4096^2, where K1 still gains 1.1 %: two rounds of blocks are the limit here)
-	if (!(d->tail_want && !d->push_now && part == PART_ALL && stream == d->stream && blocks <= std::min(tail_limit(), 1536u))) return tail;
+	tail = LaunchTail<T>{};
+	if (!(d->tail_want && part == PART_ALL && stream == d->stream && blocks <= limit)) return 0;
 	tail.done = d->tail_words;
 	tail.flux_blocks = blocks;
 	tail.fresh = d->tail_fresh;
@@ -372,10 +372,27 @@ template <typename T> LaunchTail<T> plain_tail(hp_domain* d, unsigned& blocks, i
 	tail.box = peer_box(d, (d->tail_fresh & 4) != 0);
 	tail.edge_rows[0] = tail.edge_rows[1] = tail.edge_rows[2] = tail.edge_rows[3] = 0;
 	tail.peer_rows[0] = tail.peer_rows[1] = nullptr;
+	int kind = 1;
+	if (d->push_now) {
+		const long G = d->ghost_rows, rows = d->desc.rows, cols = d->desc.cols;
+		const int b = d->use_alt ^ 1;
+		if (d->peer_state[0][b]) {
+			tail.peer_rows[0] = (State4<T>*)d->peer_state[0][b] + (d->peer_rows[0] - 2 * G) * cols;     // my row G -> its row rows_s - G
+			tail.edge_rows[0] = (int)G; tail.edge_rows[1] = (int)(2 * G);
+		}
+		if (d->peer_state[1][b]) {
+			tail.peer_rows[1] = (State4<T>*)d->peer_state[1][b] - (rows - 2 * G) * cols;                // my row rows - 2G -> its row 0
+			tail.edge_rows[2] = (int)(rows - 2 * G); tail.edge_rows[3] = (int)(rows - G);
+		}
+		kind = 2;
+	}
 	blocks += 1;
 	d->tail_done = true;
-	return tail;
+	return kind;
 }
+// (measured, tools/small_launch_probe2.py: K2 and K6 gain 7-40 % up to a few rounds of blocks and LOSE 0.5 / 1.7 % at the 4608
+// blocks of 4096^2, where K1 still gains 1.1 %: two rounds of blocks are the limit for them)
+static unsigned tail_limit_k2k6() { return std::min(tail_limit(), 1536u); }
 
 template <typename T, bool STRICT, int CFL_MODE>
 int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
@@ -388,13 +405,14 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	if (!make_tile_map(lo, hi, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks,
 	                   16, d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
-	const LaunchTail<T> tail = plain_tail<T>(d, blocks, part, stream);
+	LaunchTail<T> tail;
+	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit_k2k6(), tail);
 #define HP_LAUNCH_K2(UNIFORM_, TAIL_)                                                                                               \
 	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, UNIFORM_, TAIL_, T>), dim3(blocks), dim3(256), 0, stream, p,                   \
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, tail)
-	if (d->manning_uniform) { if (tail.done) HP_LAUNCH_K2(true, true); else HP_LAUNCH_K2(true, false); }
-	else                    { if (tail.done) HP_LAUNCH_K2(false, true); else HP_LAUNCH_K2(false, false); }
+	if (d->manning_uniform) { if (tail_kind == 2) HP_LAUNCH_K2(true, 2); else if (tail_kind == 1) HP_LAUNCH_K2(true, 1); else HP_LAUNCH_K2(true, 0); }
+	else                    { if (tail_kind == 2) HP_LAUNCH_K2(false, 2); else if (tail_kind == 1) HP_LAUNCH_K2(false, 1); else HP_LAUNCH_K2(false, 0); }
 #undef HP_LAUNCH_K2
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
@@ -412,42 +430,13 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	                   d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
 	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
-	// a launch that fits the chip in one round carries its own tail block instead of a separate advance launch (LaunchTail)
-	LaunchTail<T> tail{};
-	bool pushing = false;
-	if (d->tail_want && part == PART_ALL && stream == d->stream && blocks <= tail_limit()) {
-		tail.done = d->tail_words;
-		tail.flux_blocks = blocks;
-		tail.fresh = d->tail_fresh;
-		tail.sc = (Scalars<T>*)d->scalars;
-		tail.slot = (T*)d->cfl_slot;
-		tail.box = peer_box(d, (d->tail_fresh & 4) != 0);
-		tail.edge_rows[0] = tail.edge_rows[1] = tail.edge_rows[2] = tail.edge_rows[3] = 0;
-		tail.peer_rows[0] = tail.peer_rows[1] = nullptr;
-		if (d->push_now) {
-			// the tiles that compute this strip's first / last `ghost_rows` owned rows store them into the neighbours as well: the
-			// neighbour's pointer is shifted so that this strip's cell index lands on the neighbour's copy of the cell
-			const long G = d->ghost_rows, rows = d->desc.rows, cols = d->desc.cols;
-			const int b = d->use_alt ^ 1;
-			if (d->peer_state[0][b]) {
-				tail.peer_rows[0] = (State4<T>*)d->peer_state[0][b] + (d->peer_rows[0] - 2 * G) * cols;     // my row G -> its row rows_s - G
-				tail.edge_rows[0] = (int)G; tail.edge_rows[1] = (int)(2 * G);
-			}
-			if (d->peer_state[1][b]) {
-				tail.peer_rows[1] = (State4<T>*)d->peer_state[1][b] - (rows - 2 * G) * cols;                // my row rows - 2G -> its row 0
-				tail.edge_rows[2] = (int)(rows - 2 * G); tail.edge_rows[3] = (int)(rows - G);
-			}
-			pushing = true;
-		}
-		blocks += 1;
-		d->tail_done = true;
-	}
+	LaunchTail<T> tail;
+	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit(), tail);
 #define HP_LAUNCH_K1(FUSED_, TAIL_, LIST_, NEXT_)                                                                                   \
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, FUSED_, TAIL_, T>), dim3(blocks), dim3(256), 0, stream, p,                   \
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, LIST_, NEXT_,   \
 	                   truncated, tail)
-	const int tail_kind = !tail.done ? 0 : pushing ? 2 : 1;
 	if (d->fusable) {
 		if (tail_kind == 2)      HP_LAUNCH_K1(true, 2, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
 		else if (tail_kind == 1) HP_LAUNCH_K1(true, 1, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
@@ -473,15 +462,14 @@ int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, i
 	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
 	                   d->ghost_rows, d->own_lo, d->own_hi))
 		return HP_OK;
-	const LaunchTail<T> tail = plain_tail<T>(d, blocks, part, stream);
-	if (tail.done)
-		hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, true, T>), dim3(blocks), dim3(256), 0, stream, p,
-		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, tail);
-	else
-		hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, false, T>), dim3(blocks), dim3(256), 0, stream, p,
-		                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,
-		                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, tail);
+	LaunchTail<T> tail;
+	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit_k2k6(), tail);
+#define HP_LAUNCH_K6(TAIL_)                                                                                                         \
+	hipLaunchKernelGGL((inertial_march<STRICT, CFL_MODE, TAIL_, T>), dim3(blocks), dim3(256), 0, stream, p,                          \
+	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
+	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, tail)
+	if (tail_kind == 2) HP_LAUNCH_K6(2); else if (tail_kind == 1) HP_LAUNCH_K6(1); else HP_LAUNCH_K6(0);
+#undef HP_LAUNCH_K6
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }

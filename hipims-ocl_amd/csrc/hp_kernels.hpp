@@ -940,14 +940,14 @@ __device__ __forceinline__ Raw<T> raw_from_west(const Raw<T>& r)
 // would spill there and keeps two; fp32 has room for four
 template <bool STRICT, typename T> constexpr int muscl_waves() { return sizeof(T) == 4 ? 4 : (STRICT ? 2 : 3); }
 
-template <bool STRICT, int CFL_MODE, bool UNIFORM_N, bool TAIL, typename T>
+template <bool STRICT, int CFL_MODE, bool UNIFORM_N, int TAIL, typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves<STRICT, T>()))) void muscl_march(const Params<T> p, const Scalars<T>* sc,
                                                    const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                    State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                    T* cfl_slot, const T* __restrict__ edge_max,
                                                    const TileMap tm, const LaunchTail<T> tail)
 {
-	if (TAIL && blockIdx.x >= tail.flux_blocks) {                                  // the launch's own tail block (LaunchTail, K4)
+	if (TAIL != 0 && blockIdx.x >= tail.flux_blocks) {                                  // the launch's own tail block (LaunchTail, K4)
 		launch_tail(p, tail);
 		return;
 	}
@@ -981,6 +981,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	const unsigned lane_col = (unsigned)(xc - strip * MUSCL_COLS);
 	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
 	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
+	// (TAIL == 2) the rows of the edge ranges are stored into the strip neighbours as well, written through (see K1)
+	const __amdgpu_buffer_rsrc_t srd_peer0 = make_srd((TAIL == 2 && tail.peer_rows[0] ? tail.peer_rows[0] : dst) + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_peer1 = make_srd((TAIL == 2 && tail.peer_rows[1] ? tail.peer_rows[1] : dst) + cell0, cells_left * sizeof(State4<T>));
+	auto store_peer = [&](const State4<T>& v, const long y, const bool write_lane) {
+		const bool e0 = (int)y >= tail.edge_rows[0] && (int)y < tail.edge_rows[1];   // wave-uniform
+		const bool e1 = (int)y >= tail.edge_rows[2] && (int)y < tail.edge_rows[3];
+		buf_store_state<HP_AUX_THROUGH>(v, e1 ? srd_peer1 : srd_peer0, (write_lane && (e0 || e1)) ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);
+	};
 
 	auto load_row = [&](const long y, const bool live = true) {                 // `live`: see K1
 		RowRegs<T> r;
@@ -1159,6 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		}
 
 		buf_store_state(out, srd_dst, out_x ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);
+		if (TAIL == 2) store_peer(out, y, out_x);
 		if (CFL_MODE == 1 && !skip_cfl && out_x && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, zb_c, p.qs);
 			if (s > vmax) vmax = s;
@@ -1182,11 +1191,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	if (CFL_MODE != 0) {
 		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
-		if (TAIL) wave_vmax = vmax;
+		if (TAIL != 0) wave_vmax = vmax;
 		else if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
 	}   // tile / strip guard
-	if (TAIL) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
+	if (TAIL != 0) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1201,14 +1210,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 //  dt <= 0 returns WITHOUT writing dst (:61-62, unlike the Godunov kernel), all-dry cells likewise (:103, Q3):
 //  both leave dst stale, and the fused CFL epilogue prices what dst really holds.
 // -------------------------------------------------------------------------------------------------
-template <bool STRICT, int CFL_MODE, bool TAIL, typename T>
+template <bool STRICT, int CFL_MODE, int TAIL, typename T>
 __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const Scalars<T>* sc,
                                                       const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                       State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                       T* cfl_slot, const T* __restrict__ edge_max,
                                                       const TileMap tm, const LaunchTail<T> tail)
 {
-	if (TAIL && blockIdx.x >= tail.flux_blocks) {                                  // the launch's own tail block (LaunchTail, K4)
+	if (TAIL != 0 && blockIdx.x >= tail.flux_blocks) {                                  // the launch's own tail block (LaunchTail, K4)
 		launch_tail(p, tail);
 		return;
 	}
@@ -1237,6 +1246,14 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 	const unsigned lane_col = (unsigned)(xc - strip * MARCH_COLS);
 	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
 	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
+	// (TAIL == 2) the rows of the edge ranges are stored into the strip neighbours as well, written through (see K1)
+	const __amdgpu_buffer_rsrc_t srd_peer0 = make_srd((TAIL == 2 && tail.peer_rows[0] ? tail.peer_rows[0] : dst) + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_peer1 = make_srd((TAIL == 2 && tail.peer_rows[1] ? tail.peer_rows[1] : dst) + cell0, cells_left * sizeof(State4<T>));
+	auto store_peer = [&](const State4<T>& v, const long y, const bool write_lane) {
+		const bool e0 = (int)y >= tail.edge_rows[0] && (int)y < tail.edge_rows[1];   // wave-uniform
+		const bool e1 = (int)y >= tail.edge_rows[2] && (int)y < tail.edge_rows[3];
+		buf_store_state<HP_AUX_THROUGH>(v, e1 ? srd_peer1 : srd_peer0, (write_lane && (e0 || e1)) ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+	};
 
 	auto load_row = [&](const long y, const bool live = true) {                 // `live`: see K1
 		RowRegs<T> r;
@@ -1289,6 +1306,7 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 			out = upd;
 		}
 		buf_store_state(out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+		if (TAIL == 2) store_peer(out, y, write);
 		if (!((int)y >= tm.price_lo && (int)y < tm.price_hi)) {
 		} else if (CFL_MODE == 1) {
 			if (write) {
@@ -1326,11 +1344,11 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 	if (CFL_MODE != 0) {
 		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
 		vmax = wave_max(vmax);
-		if (TAIL) wave_vmax = vmax;
+		if (TAIL != 0) wave_vmax = vmax;
 		else if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
 	}   // tile / strip guard
-	if (TAIL) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
+	if (TAIL != 0) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
 
 // max wave speed over the edge ring (cells no kernel ever writes): the `w` outermost columns on rows
