@@ -156,6 +156,7 @@ struct hp_domain {
 	bool             push_now = false;                // this iteration's advance kernel carries the ghost rows
 	// the flux launch's own tail block instead of a separate advance launch (LaunchTail, hp_kernels.hpp): small launches only
 	unsigned long long* tail_words = nullptr;         // one word per flux block (EMPTY between launches)
+	bool             strip_first = false;             // hp_strip_step_batch: the batch's first iteration
 	bool             tail_allowed = false;            // inside hp_step_batch / hp_strip_step_batch (the host-driven split step has work in between)
 	bool             tail_want = false;               // step_begin_impl: this iteration qualifies, if the launch is small enough
 	int              tail_fresh = 0;                  // ... and this is what its advance would be told
@@ -558,12 +559,21 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 		static const bool enabled = !(std::getenv("HP_LAUNCH_TAIL") && std::atoi(std::getenv("HP_LAUNCH_TAIL")) == 0);
 		static const bool lonely_too = std::getenv("HP_STRIP_REDUCE_ALWAYS") && std::atoi(std::getenv("HP_STRIP_REDUCE_ALWAYS")) != 0;
 		const bool reduce_after = d->desc.dynamic_dt && cfl_mode == 0 && (basic || d->need_full_reduce);
-		const bool strips_ok = d->comm_world <= 1 ? !(d->comm && lonely_too)
-		                                          : (d->peer_direct && !d->strip_any_bdy && !d->strip_any_full);
+		const int priced = (d->desc.dynamic_dt && cfl_mode != 0) ? 1 : 0;
+		// strips: the ranks reduce on the iterations strip_allreduce_max says (`everyone`); the tail block serves the two plain
+		// shapes -- this rank priced and everyone reduces, or nobody does -- and leaves the rest (a rank that passes its
+		// REMEMBERED maximum around: boundaries or a stale maximum somewhere else) to the advance launch
+		bool strips_ok = d->comm_world <= 1 ? !(d->comm && lonely_too) : d->peer_direct;
+		int fresh = priced;
+		if (d->comm_world > 1 && d->peer_direct) {
+			const bool everyone = d->desc.dynamic_dt && (muscl || !q1 || dst_is_primary || basic || d->strip_any_bdy ||
+			                                             (d->strip_first && d->strip_any_full));
+			strips_ok = (priced != 0) == everyone;
+			fresh = everyone ? 7 : 4;
+		}
 		d->tail_want = enabled && d->tail_allowed && !basic && !reduce_after && strips_ok &&
 		               !(d->halo_overlap && d->split_now) && d->tail_words != nullptr;
-		const int priced = (d->desc.dynamic_dt && cfl_mode != 0) ? 1 : 0;
-		d->tail_fresh = d->comm_world > 1 ? (priced ? 7 : 4) : priced;
+		d->tail_fresh = fresh;
 		d->tail_done = false;
 	}
 	if (d->halo_overlap && d->split_now) {
@@ -1901,6 +1911,7 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 		const bool exchange = d->ghost_valid - g < g;
 		d->split_now = exchange && !d->peer_direct;   // (rows that travel inside the advance kernel need no launch of their own)
 		d->push_now = exchange && d->peer_direct;     // ... and leave with the advance kernel, or with the flux launch's tail block
+		d->strip_first = i == 0;
 		d->tail_allowed = true;
 		rc = dispatch_begin(d);
 		d->tail_allowed = false;
