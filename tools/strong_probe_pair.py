@@ -5,7 +5,7 @@ in-process double, as in tests/strip_threads_worker.py).  The GPU does the same 
 strip does in strong_probe.py's line (a); what comes on top is what the strip protocol costs per iteration with REAL
 neighbours at both ends of a hand-over: level 2 = ghost rows and maxima written by the strips themselves (one flux launch +
 one advance launch per rank and iteration), 1 = mailboxes + the double's send/receive, 0 = everything through the double
-(whose all-reduce blocks the host: not a timing, listed for completeness).   usage: strong_probe_pair.py [cols rows]"""
+(whose all-reduce blocks the host: not a timing, listed for completeness).   usage: strong_probe_pair.py [cols rows [rain]]   (rain: fp32 S-RAIN instead of fp64 S-DAM)"""
 import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hipims-ocl_amd"))
@@ -16,13 +16,22 @@ import hipims_mi as hp
 from hipims_mi import strips, synthetic as syn
 
 cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4096, 514)
+rain_fp32 = len(sys.argv) > 3 and sys.argv[3] == "rain"        # config C5's shape: fp32, gridded rain on dry terrain (fused into the flux kernel)
 world, steps = 2, 1500
-st, bed, man = syn.s_dam(cols, rows)
+precision = "f32" if rain_fp32 else "f64"
+if rain_fp32:
+    st, bed, man, rn = syn.s_rain_rows(cols, rows, 0, rows, dx=2.0, dtype=np.float32)
+else:
+    st, bed, man = syn.s_dam(cols, rows)
+    rn = None
+def with_rain(dom):
+    if rn is not None:
+        dom.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rn["grids"], rn["resolution"], rn["off_x"], rn["off_y"], rn["interval"])
 lib = hp.load_library()
 hp._check(lib, lib.hp_comm_load(os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so").encode()), "hp_comm_load")
 
-single = hp.Domain(cols, rows)
-single.upload(st, bed, man); single.set_target_time(1e9)
+single = hp.Domain(cols, rows, dx=2.0 if rain_fp32 else 1.0, precision=precision)
+single.upload(st, bed, man); with_rain(single); single.set_target_time(1e9)
 single.step_batch(50); single.sync()
 best = 1e9
 for _ in range(3):
@@ -39,8 +48,8 @@ for level in (2, 1):
 
     def rank_main(r):
         own_lo, own_hi, lo, hi = parts[r]
-        dom = hp.Domain(cols, hi - lo, global_rows=rows, row_offset=lo)
-        dom.upload(st[lo:hi], bed[lo:hi], man[lo:hi])
+        dom = hp.Domain(cols, hi - lo, global_rows=rows, row_offset=lo, dx=2.0 if rain_fp32 else 1.0, precision=precision)
+        dom.upload(st[lo:hi], bed[lo:hi], man[lo:hi]); with_rain(dom)
         dom.set_halo_overlap(level != 2)
         dom.strip_comm_init(uid, r, world)
         tickets[r] = dom.strip_peer_ticket(); meet.wait()
