@@ -252,10 +252,9 @@ __global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const i
 }
 
 // -------------------------------------------------------------------------------------------------
-// The launch's own tail (small launches only: a strip of a strong-scaling run, the example's 342 x 195 grid -- launches that
-// fit the chip in one round and are bound by the hand-over between dependent kernels, not by bytes: 11.6 us per iteration
-// for 3 us of arithmetic on the example).  Instead of a separate advance launch behind the flux launch, the
-// flux launch carries ONE more block.  Every flux block ends by storing its maximum into its own word of `done`
+// The launch's own tail.  Two dependent launches per iteration (flux, advance) cost more in hand-over than in work on
+// anything but the largest grids (the example's 342 x 195: 11.7 us per iteration for 3 us of arithmetic).
+// Instead of a separate advance launch behind the flux launch, the flux launch carries ONE more block.  Every flux block ends by storing its maximum into its own word of `done`
 // (a plain 8-byte store: the word doubles as the block's "I am through" flag, so there is no atomic to wait for and no
 // ordering between two memory operations to arrange); the tail block polls all the words, folds them, empties them for the
 // next launch, and then does what advance_time does (mailbox round, advance_body; the ghost rows have left with the tiles).  The tail
@@ -270,7 +269,7 @@ template <typename T> struct LaunchTail {
 	Scalars<T>*         sc;
 	T*                  slot;
 	PeerBox             box;
-	// ghost rows (PUSH instantiations of the flux kernels): the strip's first / last owned rows are stored TWICE by the tile that
+	// ghost rows (TAIL == 2 instantiations of the flux kernels): the strip's first / last owned rows are stored TWICE by the tile that
 	// computes them -- into this strip's new state and, through peer_rows[side], into the neighbour's ghost rows of the same
 	// ping-pong buffer.  peer_rows[side] is shifted so that THIS strip's cell index addresses the neighbour's copy of the cell.
 	// Cells the kernel leaves untouched (quirk Q3) are left untouched there too: both copies started equal (the host uploads
@@ -279,10 +278,7 @@ template <typename T> struct LaunchTail {
 	int                 edge_rows[4];   // [lo, hi) of the rows that go south, [lo, hi) of those that go north (empty: lo >= hi)
 };
 
-// every wavefront of every flux block, at its very end; `m` = the wavefront's maximum (0 when this launch prices nothing).
-// The tail block needs nothing else of a flux block -- except the rows it sends on to the strip neighbours: a block whose
-// tile holds such rows makes its stores visible (release at agent scope: the tail block runs on some other CU, maybe another
-// XCD) before it reports; all the others report without waiting for theirs.
+// every wavefront of every flux block, at its very end; `m` = the wavefront's maximum (0 when this launch prices nothing)
 template <typename T>
 __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const T m, const int wave, const int lane, const long y0, const long y1)
 {
