@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hipims-ocl_amd")]
 os.environ["HIPIMS_MI_NO_TORCH"] = "1"
 # every rank's streams on hardware queues of their own: a rank's advance kernel WAITS for the other ranks' kernels, which
-# must not sit behind it in a shared queue (one process per GPU in production; here up to 4 ranks x 2 streams share one)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# must not sit behind it in a shared queue (one process per GPU in production; here up to 8 ranks x 2 streams share one)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np  # noqa: E402
 
 import hipims_mi as hp  # noqa: E402

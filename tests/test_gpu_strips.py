@@ -259,7 +259,9 @@ def test_bench_line_names_the_collective_library_on_the_cxx_loop():
     (2, hp.SCHEME_GODUNOV, "f64", 1, 0, 2, -2), (3, hp.SCHEME_GODUNOV, "f64", 0, 0, 2, -2), (4, hp.SCHEME_GODUNOV, "f32", 1, 1, 2, -2),
     (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 1, 0, 2, -2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 2, -2), (3, hp.SCHEME_GODUNOV, "f64", 1, 1, 2, -2),
     # a cell boundary that only the strip holding its cells is told about: the other ranks must still enter every collective
-    (3, hp.SCHEME_GODUNOV, "f64", 1, 0, 1, 1), (3, hp.SCHEME_GODUNOV, "f64", 1, 0, 2, 2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 2, 0)])
+    (3, hp.SCHEME_GODUNOV, "f64", 1, 0, 1, 1), (3, hp.SCHEME_GODUNOV, "f64", 1, 0, 2, 2), (2, hp.SCHEME_INERTIAL, "f64", 1, 0, 2, 0),
+    # eight ranks, as on the 8-GPU node the scaling runs are made on (every rank's mailbox has seven writers)
+    (8, hp.SCHEME_GODUNOV, "f32", 1, 1, 1, -2)])
 def test_cxx_strip_loop_with_several_ranks(world, scheme, precision, overlap, rain, period, cell_rank, peer_max):
     """hp_strip_step_batch / hp_strip_update_timestep with 2-4 REAL ranks: the ranks are threads of one process sharing
     the GPU, the collective library is the in-process test double tests/fake_rccl (RCCL itself refuses two ranks on
