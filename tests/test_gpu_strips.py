@@ -360,7 +360,8 @@ def test_peer_mailboxes_report_a_missing_rank_instead_of_hanging():
 
 
 @pytest.mark.parametrize("world,scheme,precision,rain,period", [
-    (2, hp.SCHEME_GODUNOV, "f64", 0, 1), (3, hp.SCHEME_GODUNOV, "f32", 1, 1), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 0, 1), (2, hp.SCHEME_GODUNOV, "f64", 1, 2)])
+    (2, hp.SCHEME_GODUNOV, "f64", 0, 1), (3, hp.SCHEME_GODUNOV, "f32", 1, 1), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 0, 1), (2, hp.SCHEME_GODUNOV, "f64", 1, 2),
+    (8, hp.SCHEME_GODUNOV, "f64", 1, 1)])
 def test_cxx_strip_loop_with_ranks_that_are_processes(world, scheme, precision, rain, period, tmp_path):
     """The strip loop as it runs in production -- one PROCESS per rank -- on the one GPU of the box: every rank maps its
     neighbours' state buffers and all ranks' mailboxes through IPC handles, the advance kernels write ghost rows and maxima
