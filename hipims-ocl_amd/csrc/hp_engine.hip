@@ -391,9 +391,14 @@ template <typename T> int make_tail(hp_domain* d, unsigned& blocks, int part, hi
 	d->tail_done = true;
 	return kind;
 }
-// (measured, tools/small_launch_probe2.py: K2 and K6 gain 7-40 % up to a few rounds of blocks and LOSE 0.5 / 1.7 % at the 4608
-// blocks of 4096^2, where K1 still gains 1.1 %: two rounds of blocks are the limit for them)
-static unsigned tail_limit_k2k6() { return std::min(tail_limit(), 1536u); }
+// (K2 / K6 have their own knob for A/B runs.  A first probe had them lose 0.5 / 1.7 % at the 4608 blocks of 4096^2 and a limit of
+// two rounds of blocks was set; bench.py's interleaved repeats on one box then showed the opposite -- MUSCL-Hancock 4096^2
+// 0.311 -> 0.302 ms, fp32 0.215 -> 0.192, inertial 0.268 -> 0.249-0.263 -- so there is no limit of their own any more)
+static unsigned tail_limit_k2k6()
+{
+	static const unsigned v = std::getenv("HP_TAIL_MAX_BLOCKS_K2K6") ? (unsigned)std::atoi(std::getenv("HP_TAIL_MAX_BLOCKS_K2K6")) : TAIL_MAX_BLOCKS;
+	return std::min(tail_limit(), v);
+}
 
 template <typename T, bool STRICT, int CFL_MODE>
 int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)

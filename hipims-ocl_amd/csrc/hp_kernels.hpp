@@ -296,6 +296,9 @@ __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const
 	}
 }
 
+#ifndef HP_TAIL_POLL_SLEEP
+#define HP_TAIL_POLL_SLEEP 1
+#endif
 template <typename T>
 __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail<T>& tail)
 {
@@ -303,7 +306,7 @@ __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail
 	T m = T(0);
 	for (unsigned i = threadIdx.x; i < tail.flux_blocks; i += blockDim.x) {
 		unsigned long long w;
-		while ((w = __hip_atomic_load(tail.done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == PEER_EMPTY) __builtin_amdgcn_s_sleep(1);
+		while ((w = __hip_atomic_load(tail.done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == PEER_EMPTY) __builtin_amdgcn_s_sleep(HP_TAIL_POLL_SLEEP);
 		__hip_atomic_store(tail.done + i, PEER_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		T v;
 		peer_value(w, v);
