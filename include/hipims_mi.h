@@ -294,11 +294,11 @@ int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out);
  *                          neighbours' state buffers and runs a connection test (two reductions with known answers,
  *                          bounded wait).  COLLECTIVE.  With a communicator the ranks then agree (one all-reduce) on what
  *                          ALL of them can do:
- *                            *active = 2  mailboxes and ghost rows: hp_strip_step_batch runs ONE flux launch and one
- *                                         advance launch per iteration and calls nothing of the collective library inside
- *                                         an iteration -- the advance kernel's blocks copy the strip's edge rows into the
- *                                         neighbours' ghost rows (CDomainLink's push / pull, Domain/Links/CDomainLink.cpp:
- *                                         168-270) and its mailbox round, held on every iteration, is the hand-over;
+ *                            *active = 2  mailboxes and ghost rows: hp_strip_step_batch runs ONE launch per iteration and calls
+ *                                         nothing of the collective library inside an iteration -- the tiles that compute the
+ *                                         strip's edge rows store them into the neighbours' ghost rows as well (CDomainLink's
+ *                                         push / pull, Domain/Links/CDomainLink.cpp:168-270), and the launch's tail block
+ *                                         holds the mailbox round, on every iteration, which is the hand-over;
  *                            *active = 1  mailboxes only (a rank could not map a neighbour's buffers, or HP_PEER_DIRECT=0
  *                                         in some rank's environment): the rows keep going through ncclSend / ncclRecv;
  *                            *active = 0  nothing: everything stays with the library (the reason goes to the log sink as
