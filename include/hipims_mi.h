@@ -285,7 +285,7 @@ int hp_strip_info(hp_domain_t* d, hp_strip_info_t* out);
 /* ---- the maximum over all strips without a collective ("one-shot all-gather-to-all over direct links, then a
  * local max"; stands where MPI_Allreduce(MIN dt) is, MPI/CMPIManager.cpp:852-861) ----
  * Every strip owns a small mailbox in uncached device memory which the other strips' GPUs write directly over xGMI; the
- * advance kernel that runs after every flux launch anyway stores its maximum into every peer's mailbox, waits for theirs
+ * advance kernel that runs after every flux launch anyway (or the flux launch's own tail block) stores its maximum into every peer's mailbox, waits for theirs
  * and folds them -- no collective kernel on the critical path of an iteration.
  *   hp_strip_peer_ticket   allocates the mailbox and describes it and the domain's two state buffers (addresses for ranks
  *                          of the same process, IPC handles for other processes) in HP_PEER_TICKET_BYTES that the host
