@@ -323,7 +323,7 @@ def main():
                                    f"{cols}x{rows}{'' if levels[0] == 10.0 else ' (levels %g|%g m)' % levels}, "
                                    f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
                                    f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
-                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + (f", per-iteration loop: {getattr(runner, 'loop', 'batch call')}" if world > 1 else "") + (f", collective library {strip_info['library']} reporting {strip_info['comm_ranks']} ranks, halo overlap {'on' if strip_info['halo_overlap'] else 'off'}, maximum over the strips by {'peer-written mailboxes' if strip_info['peer_max'] else 'all-reduce'}, ghost rows {'written into the neighbours by the advance kernel' if strip_info['peer_halo'] else 'sent and received through the library'}" if strip_info else "") + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
+                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + (f", per-iteration loop: {getattr(runner, 'loop', 'batch call')}" if world > 1 else "") + (f", collective library {strip_info['library']} reporting {strip_info['comm_ranks']} ranks, halo overlap {'on' if strip_info['halo_overlap'] else 'off'}, maximum over the strips by {'peer-written mailboxes' if strip_info['peer_max'] else 'all-reduce'}, ghost rows {'stored into the neighbours by the strips themselves' if strip_info['peer_halo'] else 'sent and received through the library'}" if strip_info else "") + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
                                                                 else " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"),
                        "area_boundaries": ("none" if args.workload != "s-rain" else
                                            "fused into the flux kernel's store epilogue" if runner.domain.boundaries_fused() else "separate pass"),
