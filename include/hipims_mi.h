@@ -319,7 +319,8 @@ int hp_strip_peer_disconnect(hp_domain_t* d);
 int hp_timer_start(hp_domain_t* d);
 int hp_timer_stop(hp_domain_t* d, float* elapsed_ms);  /* BLOCKS until the stop event completes */
 /* Average device time of the dominant (flux) kernel: every `stride`-th launch is bracketed with events from a pool of
- * 16 pairs created by this call (so nothing is created inside a timed region); sampling stops when the pool is used up. */
+ * 16 pairs created by this call (so nothing is created inside a timed region); sampling stops when the pool is used up.
+ * The time an EMPTY event pair takes (measured by this call on the idle stream) is taken off every sample. */
 int hp_kernel_timing(hp_domain_t* d, int enable_stride);
 int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples);   /* BLOCKS */
 
