@@ -196,6 +196,7 @@ template <typename T> Params<T> make_params(const hp_domain* d)
 	p.manning_uniform = d->manning_uniform ? 1 : 0;
 	p.manning_value = (T)d->manning_value;
 	p.simplified_cfl = d->desc.scheme == HP_SCHEME_INERTIAL ? 1 : 0;       // CLSchemeInertial.clh:25
+	p.muscl_nb_bed = (d->desc.quirks & HP_QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED) ? 1 : 0;
 	return p;
 }
 

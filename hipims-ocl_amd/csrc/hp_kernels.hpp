@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		const Raw<T> e = raw_from_east(c), w = raw_from_west(c);
 		dry_e = e.zmax < vs;                                                       // :633 tests Zmax, not depth (Q6)
 		dry_w = w.zmax < vs;
-		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs, quiet, same);
+		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs, p.muscl_nb_bed != 0, quiet, same);
 	};
 	// A "quiet" row (muscl_predict's wave-uniform fast path: all four face states of every lane equal the cell state)
 	// needs neither the LDS round trip of its face values nor three separate sides: one side built from the cell state

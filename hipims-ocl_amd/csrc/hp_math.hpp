@@ -29,6 +29,7 @@ template <typename T> struct Params {
 	int  manning_uniform;        // every cell has the same Manning n (the usual "constant" data source): not re-read per step
 	T    manning_value;
 	int  simplified_cfl;         // TIMESTEP_SIMPLIFIED (CLSchemeInertial.clh:25): wave speed = sqrt(g h) only
+	int  muscl_nb_bed;           // HP_QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED: the predictor's first-order test reads the neighbours' bed
 };
 
 // device-resident time-control block ("Time", "Timestep", ... buffers, CSchemeGodunov.cpp:852-872)
@@ -545,13 +546,17 @@ __device__ __forceinline__ Face4<T> face_extrapolate(const T zb, const Face4<T>&
 template <bool STRICT, typename T>
 __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>& n, const Raw<T>& e, const Raw<T>& s,
                                                   const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs,
-                                                  bool& quiet_row, bool& same_row)
+                                                  const bool nb_y_is_bed, bool& quiet_row, bool& same_row)
 {
 	const T g = gravity<T>();
 	Face4<T> cc; cc.z = c.z; cc.h = c.z - c.zb; cc.qx = c.qx; cc.qy = c.qy;           // :333
 	Faces<T> f; f.n = cc; f.e = cc; f.s = cc; f.w = cc;
-	const bool first = (c.z - c.zb < T(1E-5)) || n.zmax <= T(-9998.0) || e.zmax <= T(-9998.0) ||
-	                   s.zmax <= T(-9998.0) || w.zmax <= T(-9998.0);                    // :325-330
+	// :325-330.  `pNeigData*.y` is the neighbour's BED in the reference's default configuration (kCachePrediction: the LDS tile
+	// of mch_1st_cachePrediction holds {Z, bed, Qx, Qy}, :201, :232-239) and its Zmax in mch_1st_cacheNone (:109-125);
+	// nb_y_is_bed is wave-uniform (HP_QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED)
+	const bool nb_null = nb_y_is_bed ? (n.zb <= T(-9998.0) || e.zb <= T(-9998.0) || s.zb <= T(-9998.0) || w.zb <= T(-9998.0))
+	                                 : (n.zmax <= T(-9998.0) || e.zmax <= T(-9998.0) || s.zmax <= T(-9998.0) || w.zmax <= T(-9998.0));
+	const bool first = (c.z - c.zb < T(1E-5)) || nb_null;
 
 	// Cheapest sufficient test for a quiet row (see below): a cell whose four neighbours carry exactly its own level, bed
 	// and discharges has all differences zero, hence all limited slopes zero -- sixteen compares instead of the eight

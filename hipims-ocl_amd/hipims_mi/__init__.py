@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(PKG_ROOT, "lib", "libhipims_mi.so")
 # enums of include/hipims_mi.h
 SCHEME_GODUNOV, SCHEME_MUSCL_HANCOCK, SCHEME_INERTIAL = 0, 1, 2
 ARRAY_STATE, ARRAY_BED, ARRAY_MANNING = 0, 1, 2
-QUIRK_CFL_READS_PRIMARY, QUIRK_BDY_TRUNCATED, QUIRKS_REFERENCE = 1, 2, 3
+QUIRK_CFL_READS_PRIMARY, QUIRK_BDY_TRUNCATED, QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED, QUIRKS_REFERENCE = 1, 2, 4, 7
 MATH_FAST, MATH_STRICT = 0, 1
 KERNEL_AUTO, KERNEL_BASIC = 0, 1
 UNIFORM_RAIN_INTENSITY, UNIFORM_LOSS_RATE = 0, 1

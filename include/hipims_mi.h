@@ -59,12 +59,23 @@ enum {
 	                                          (CSchemeGodunov.cpp:1629/:1634 set a non-existent arg) */
 	HP_QUIRK_BDY_TRUNCATED     = 1u << 1,  /* Q9: boundary kernels cover floor(n/8)*8 cells per axis
 	                                          (Boundaries/CBoundaryUniform.cpp:294-295) */
-	HP_QUIRKS_REFERENCE        = 3u
+	HP_QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED = 1u << 2,
+	                                       /* Q11: the reference's DEFAULT MUSCL-Hancock configuration is kCachePrediction
+	                                          (Schemes/CSchemeMUSCLHancock.cpp:46): mch_1st_cachePrediction keeps {Z, BED, Qx, Qy}
+	                                          in LDS (CLSchemeMUSCLHancock.clc:201) and hands the four neighbours to mch_1st with
+	                                          their bed in .y (:232-239), so the predictor's first-order fallback
+	                                          `pNeigData*.y <= -9998.0` (:325-330) tests the neighbour's BED -- a cell next to a
+	                                          disabled (Zmax = -9999) cell with an ordinary bed stays second order.  Off = the
+	                                          non-default mch_1st_cacheNone variant, which tests the neighbour's Zmax (:109-125). */
+	HP_QUIRKS_REFERENCE        = 7u
 };
 
 /* Arithmetic flavour of the device kernels.
  *  STRICT: the reference's expression order, IEEE division/sqrt, no FMA contraction -- bit-identical to
- *          the oracle except for pow() in the friction term;
+ *          the oracle and to the reference's own kernels as built by oracle/ref_build, friction included: pow(), the one
+ *          built-in whose result is implementation defined, is in all three the correctly rounded cube root of
+ *          csrc/hp_crmath.h (i.e. the identity holds against the reference run on a platform with THAT pow; a
+ *          platform with another conforming pow differs in the last bit of the friction term, fixture f10_*_libm);
  *  FAST  : algebraically identical, fewer divisions, explicit FMAs (the reference itself ships with
  *          -cl-mad-enable, OpenCL/Executors/COCLProgram.cpp:73, so its own results are compiler
  *          dependent at this level).  Default. */

@@ -25,7 +25,10 @@ REFERENCE_SRC = "/root/reference/src"
 
 GODUNOV, MUSCL, INERTIAL = 0, 1, 2
 Q1_CFL_READS_PRIMARY, Q9_BDY_TRUNCATED, Q6_MUSCL_SERIAL = 1, 2, 4
-QUIRKS_REFERENCE = 7
+# the reference's DEFAULT MUSCL predictor (kCachePrediction, CSchemeMUSCLHancock.cpp:46): neighbours reach mch_1st with their
+# BED in .y (CLSchemeMUSCLHancock.clc:201, :232-248, :325-330); off = the mch_1st_cacheNone variant (neighbours' Zmax)
+Q11_MUSCL_NB_Y_IS_BED = 8
+QUIRKS_REFERENCE = 15
 UNIFORM_RAIN_INTENSITY, UNIFORM_LOSS_RATE = 0, 1
 GRIDDED_RAIN_INTENSITY, GRIDDED_RAIN_ACCUMUL, GRIDDED_MASS_FLUX = 0, 1, 2
 DEPTH_IGNORE, DEPTH_IS_FSL, DEPTH_IS_DEPTH, DEPTH_IS_CRITICAL = 0, 1, 2, 3
@@ -73,7 +76,8 @@ def _params_struct(creal):
     class Params(C.Structure):
         _fields_ = [("cols", C.c_long), ("rows", C.c_long), ("dx", creal), ("very_small", creal),
                     ("quite_small", creal), ("courant", creal), ("end_time", creal), ("fixed_dt", creal),
-                    ("dynamic_dt", C.c_int), ("friction", C.c_int), ("threads", C.c_int), ("simplified_cfl", C.c_int)]
+                    ("dynamic_dt", C.c_int), ("friction", C.c_int), ("threads", C.c_int), ("simplified_cfl", C.c_int),
+                    ("muscl_nb_y_is_bed", C.c_int)]
     return Params
 
 
@@ -107,7 +111,7 @@ def _load_oracle(precision: str):
 class OracleFunctions:
     """Function-level entry points of the C restatement (registers in, registers out)."""
 
-    def __init__(self, precision="f64", very_small=1e-10, dx=1.0, friction=True):
+    def __init__(self, precision="f64", very_small=1e-10, dx=1.0, friction=True, muscl_nb_y_is_bed=False):
         self.precision = precision
         self.lib = _load_oracle(precision)
         self.creal = _c_real(precision)
@@ -115,7 +119,7 @@ class OracleFunctions:
         self.Params = _params_struct(self.creal)
         self.p = self.Params(cols=0, rows=0, dx=dx, very_small=very_small, quite_small=very_small * 10,
                              courant=0.5, end_time=1e30, fixed_dt=0.0, dynamic_dt=1, friction=int(friction),
-                             threads=1)
+                             threads=1, muscl_nb_y_is_bed=int(muscl_nb_y_is_bed))
 
     def _a(self, x, n):
         a = np.ascontiguousarray(x, dtype=self.real)
@@ -508,7 +512,9 @@ class RefSim(_SimBase):
                 self.use_alt = not self.use_alt
             else:
                 f = self.faces
-                self.lib.ref_mch_1st(_ptr(self.dt), _ptr(self.bed), _ptr(self.primary), _ptr(f[0]), _ptr(f[1]),
+                # the default configuration's predictor kernel, run as real 16 x 16 work-groups (shim.cpp), or the cacheNone twin
+                first = self.lib.ref_mch_1st_cached if (self.quirks & Q11_MUSCL_NB_Y_IS_BED) else self.lib.ref_mch_1st
+                first(_ptr(self.dt), _ptr(self.bed), _ptr(self.primary), _ptr(f[0]), _ptr(f[1]),
                                      _ptr(f[2]), _ptr(f[3]))
                 self.lib.ref_mch_2nd(_ptr(self.dt), _ptr(self.primary), _ptr(self.bed), _ptr(self.manning),
                                      _ptr(f[0]), _ptr(f[1]), _ptr(f[2]), _ptr(f[3]))

@@ -22,6 +22,9 @@
 #include "../../hipims-ocl_amd/csrc/hp_crmath.h"   // shared with the oracle and the STRICT HIP kernels (see there)
 #include <cstddef>
 #include <cstdint>
+#include <pthread.h>
+#include <thread>
+#include <vector>
 
 #ifdef REF_FP32
 typedef float real;
@@ -39,7 +42,10 @@ size_t get_local_id(unsigned d)    { return t_lid[d]; }
 size_t get_group_id(unsigned d)    { return t_grp[d]; }
 size_t get_local_size(unsigned d)  { return t_lsz[d]; }
 size_t get_global_size(unsigned d) { return t_gsz[d]; }
-void   barrier(unsigned)           {}
+// barrier(): a no-op for the kernels driven one work-item at a time (groups of 1 x 1 x 1); the one kernel driven as a real
+// work-group -- mch_1st_cachePrediction, ref_mch_1st_cached below -- gives every work-item thread this group's barrier
+static thread_local pthread_barrier_t* t_barrier = nullptr;
+void   barrier(unsigned)           { if (t_barrier) pthread_barrier_wait(t_barrier); }
 
 long   max(long a, long b)         { return a > b ? a : b; }
 long   min(long a, long b)         { return a < b ? a : b; }
@@ -119,6 +125,7 @@ void ine_cacheDisabled(const real* dt, const real* bed, real* src, real* dst, co
 void mch_1st_cacheNone(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW);
 void mch_2nd_cacheNone(const real* dt, real* state, const real* bed, const real* manning,
                        real* fN, real* fE, real* fS, real* fW);
+void mch_1st_cachePrediction(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW);
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -186,6 +193,44 @@ void ref_mch_1st(const real* dt, const real* bed, real* state, real* fN, real* f
 			set_item_2d((size_t)x, (size_t)y, (size_t)REFP_COLS, (size_t)REFP_ROWS);
 			mch_1st_cacheNone(dt, bed, state, fN, fE, fS, fW);
 		}
+}
+/* The reference's DEFAULT predictor (ucConfiguration = kCachePrediction, CSchemeMUSCLHancock.cpp:46, kernels :523-531):
+ * mch_1st_cachePrediction, work-groups of MCH_STG1_DIM1 x MCH_STG1_DIM2 = 16 x 16 work-items (floor(sqrt(256)),
+ * CSchemeMUSCLHancock.cpp:361-373) that overlap by two cells, one __local tile per group and a barrier between filling and
+ * reading it (CLSchemeMUSCLHancock.clc:176-296).  Run here as a REAL work-group: 256 host threads, one per work-item, with
+ * a pthread barrier behind barrier(); the kernel's __local array is one static object of the compiled text, i.e. shared by the
+ * threads exactly as LDS is shared by a group.  Groups run one after the other (a second barrier keeps a fast thread from
+ * refilling the tile while a slow one still reads it).  Global size = ceil(n * 16/14) rounded up to the group size
+ * (CSchemeMUSCLHancock.cpp:375-380, COCLKernel.cpp:343-344). */
+void ref_mch_1st_cached(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW)
+{
+	const size_t L = 16;                                  /* == MCH_STG1_DIM1/2 of prelude.cl */
+	auto gsize = [&](long n) {
+		size_t g = (size_t)__builtin_ceil((double)n * ((double)L / (double)(L - 2)));
+		return (size_t)(__builtin_ceil((double)g / (double)L) * (double)L);
+	};
+	const size_t gsx = gsize(REFP_COLS), gsy = gsize(REFP_ROWS), ngx = gsx / L, ngy = gsy / L;
+	pthread_barrier_t bar;
+	pthread_barrier_init(&bar, nullptr, (unsigned)(L * L));
+	std::vector<std::thread> items;
+	for (size_t lid = 0; lid < L * L; ++lid)
+		items.emplace_back([&, lid] {
+			t_barrier = &bar;
+			const size_t lx = lid % L, ly = lid / L;
+			for (size_t gy = 0; gy < ngy; ++gy)
+				for (size_t gx = 0; gx < ngx; ++gx) {
+					t_gid[0] = gx * L + lx; t_gid[1] = gy * L + ly; t_gid[2] = 0;
+					t_grp[0] = gx; t_grp[1] = gy; t_grp[2] = 0;
+					t_lid[0] = lx; t_lid[1] = ly; t_lid[2] = 0;
+					t_lsz[0] = L; t_lsz[1] = L; t_lsz[2] = 1;
+					t_gsz[0] = gsx; t_gsz[1] = gsy; t_gsz[2] = 1;
+					mch_1st_cachePrediction(dt, bed, state, fN, fE, fS, fW);
+					pthread_barrier_wait(&bar);           /* the tile is free for the next group */
+				}
+			t_barrier = nullptr;
+		});
+	for (auto& t : items) t.join();
+	pthread_barrier_destroy(&bar);
 }
 /* In-place corrector: result depends on work-item order (quirk Q6).  Driven row-major, x fastest. */
 void ref_mch_2nd(const real* dt, real* state, const real* bed, const real* manning,

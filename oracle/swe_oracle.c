@@ -347,8 +347,12 @@ int orc_mch_1st(const orc_params* p, real dt, const real states[20], const real 
 	real *fN = faces, *fE = faces + 4, *fS = faces + 8, *fW = faces + 12;
 	int first = 0;
 
+	/* pNeigData*.y: the neighbour's Zmax as mch_1st_cacheNone passes it (:109-125), its BED as the default
+	 * mch_1st_cachePrediction does (the LDS tile is {Z, bed, Qx, Qy}, :201, :232-239, :251-266) */
+	const real yN = p->muscl_nb_y_is_bed ? bN : sN[1], yE = p->muscl_nb_y_is_bed ? bE : sE[1];
+	const real yS = p->muscl_nb_y_is_bed ? bS : sS[1], yW = p->muscl_nb_y_is_bed ? bW : sW[1];
 	if (sC[0] - bC < RC(1E-5) ||                                      /* :325-330 (hard-coded 1E-5) */
-	    sN[1] <= RC(-9998.0) || sE[1] <= RC(-9998.0) || sS[1] <= RC(-9998.0) || sW[1] <= RC(-9998.0))
+	    yN <= RC(-9998.0) || yE <= RC(-9998.0) || yS <= RC(-9998.0) || yW <= RC(-9998.0))
 		first = 1;
 
 	real c[4] = { sC[0], sC[0] - bC, sC[2], sC[3] };                  /* :333 second element becomes depth */
@@ -598,7 +602,9 @@ void orc_inertial_step(const orc_params* p, real dt, const real* bed, const real
 			inertial_cell(p, dt, x, y, bed, src, dst, manning);
 }
 
-/* mch_1st_cacheNone -- Schemes/CLSchemeMUSCLHancock.clc:28-152 */
+/* mch_1st_cacheNone -- Schemes/CLSchemeMUSCLHancock.clc:28-152; with p->muscl_nb_y_is_bed the reference's default,
+ * mch_1st_cachePrediction -- :157-296: same cells (the overlapping 16 x 16 groups cover 1..n-2 once), the cell's own state
+ * from global memory, the four neighbours from the LDS tile {Z, bed, Qx, Qy} */
 void orc_muscl_predict(const orc_params* p, real dt, const real* bed, const real* state,
                        real* fN, real* fE, real* fS, real* fW)
 {
@@ -617,6 +623,11 @@ void orc_muscl_predict(const orc_params* p, real dt, const real* bed, const real
 			memcpy(st + 12, state + 4 * iS, 4 * sizeof(real));
 			memcpy(st + 16, state + 4 * iW, 4 * sizeof(real));
 			bd[0] = bed[id]; bd[1] = bed[iN]; bd[2] = bed[iE]; bd[3] = bed[iS]; bd[4] = bed[iW];
+			if (p->muscl_nb_y_is_bed) {                               /* :243-248: own Zmax, neighbours' BED, and `==` */
+				if (st[1] == RC(-9999.0) && bd[1] == RC(-9999.0) && bd[2] == RC(-9999.0) &&
+				    bd[3] == RC(-9999.0) && bd[4] == RC(-9999.0))
+					continue;
+			} else
 			if (st[1] <= RC(-9999.0) && st[5] <= RC(-9999.0) && st[9] <= RC(-9999.0) &&   /* :95-100 */
 			    st[13] <= RC(-9999.0) && st[17] <= RC(-9999.0))
 				continue;
@@ -980,6 +991,7 @@ orc_sim* orc_sim_create(const orc_params* p, int scheme, unsigned quirks, real d
 	s->scheme = scheme;
 	if (scheme == ORC_SCHEME_INERTIAL) s->p.simplified_cfl = 1;       /* CLSchemeInertial.clh:25, always defined */
 	s->quirks = quirks;
+	s->p.muscl_nb_y_is_bed = (quirks & ORC_Q11_MUSCL_NB_Y_IS_BED) ? 1 : 0;
 	s->cells = (size_t)p->cols * (size_t)p->rows;
 	s->primary = (real*)calloc(s->cells * 4, sizeof(real));
 	s->alt     = (real*)calloc(s->cells * 4, sizeof(real));

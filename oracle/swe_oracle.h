@@ -41,7 +41,12 @@ enum {
 	ORC_Q1_CFL_READS_PRIMARY = 1,   /* CSchemeGodunov.cpp:1629/:1634: tst_Reduce always reads the primary buffer */
 	ORC_Q9_BDY_TRUNCATED     = 2,   /* CBoundaryUniform.cpp:294: boundary NDRange = floor(n/8)*8 */
 	ORC_Q6_MUSCL_SERIAL      = 4,   /* in-place corrector driven row-major (what oracle/_ref does); off = snapshot */
-	ORC_QUIRKS_REFERENCE     = 1 | 2 | 4
+	ORC_Q11_MUSCL_NB_Y_IS_BED = 8,  /* the reference's DEFAULT MUSCL configuration (kCachePrediction, CSchemeMUSCLHancock.cpp:46)
+	                                 * runs mch_1st_cachePrediction, whose LDS tile holds {Z, BED, Qx, Qy}
+	                                 * (CLSchemeMUSCLHancock.clc:201): the neighbours it hands to mch_1st carry their bed in .y,
+	                                 * so the first-order fallback (:325-330) and the all-disabled skip (:243-248) test the
+	                                 * neighbours' BED; off = mch_1st_cacheNone (neighbours' Zmax, :95-100) */
+	ORC_QUIRKS_REFERENCE     = 1 | 2 | 4 | 8
 };
 
 /* uniform-boundary definitions: src/Boundaries/CLBoundaries.clh:44-50 */
@@ -63,6 +68,7 @@ typedef struct {
 	int   friction;      /* FRICTION_ENABLED (fused: FRICTION_IN_FLUX_KERNEL) */
 	int   threads;       /* worker threads for the grid loops (1 = scalar) */
 	int   simplified_cfl;/* TIMESTEP_SIMPLIFIED (CLSchemeInertial.clh:25): wave speed = sqrt(g h) only */
+	int   muscl_nb_y_is_bed; /* ORC_Q11 (orc_sim_create sets it from the quirk mask): predictor = mch_1st_cachePrediction */
 } orc_params;
 
 typedef struct {

@@ -401,8 +401,14 @@ def no_friction(tag="f64"):
 
 
 def disabled_cells(tag="f64"):
-    """F15: disabled cells -- the domain's nulls (CDomain.cpp:351-360: Zmax = -9999; the kernels also test Z == -9999):
-    a block and a sprinkle of them in a wet/dry rough grid, all three schemes, through a sync point."""
+    """F15: disabled cells -- the domain's nulls.  Three kinds in a wet/dry rough grid, all three schemes, through a sync point:
+    mask-style nulls (a disabledCells raster: Zmax = -9999, the bed keeps its DEM value, CDomain.cpp:351-360; a block and a
+    sprinkle), one cell with Z == -9999 (the kernels test that too), DEM-nodata nulls (bed = Z = Zmax = -9999) and one LIVE dry
+    cell on a bed of -9998.5.  MUSCL-Hancock is stored for BOTH predictor variants of the reference: `mch` = its default
+    configuration (kCachePrediction, CSchemeMUSCLHancock.cpp:46: mch_1st_cachePrediction run as real 16 x 16 work-groups,
+    oracle/ref_build/shim.cpp; the neighbours' .y is their BED) and `mchnone` = mch_1st_cacheNone (their Zmax).  Next to the
+    mask-style nulls the default stays second order where cacheNone drops to first; next to the -9998.5 bed it is the other way
+    round."""
     out = {}
     st, bed, man = syn.s_rough(64, 48, manning=None)
     rng = np.random.default_rng(15)
@@ -412,14 +418,23 @@ def disabled_cells(tag="f64"):
     dis[0] = dis[-1] = False; dis[:, 0] = dis[:, -1] = False
     st[dis, 1] = -9999.0
     st[5, 5, 0] = -9999.0
+    nod = np.zeros_like(dis)
+    nod[30:34, 40:44] = True
+    bed[nod] = -9999.0; st[nod, 0] = -9999.0; st[nod, 1] = -9999.0
+    dis |= nod
+    bed[40, 12] = -9998.5; st[40, 12, 0] = -9998.5; st[40, 12, 1] = -9998.5
     out.update(state=st, bed=bed, manning=man, disabled=dis)
-    for scheme, name in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch"), (oracle.INERTIAL, "ine")):
-        sim = oracle.RefSim(64, 48, scheme=scheme)
+    runs = ((oracle.GODUNOV, "god", oracle.QUIRKS_REFERENCE), (oracle.MUSCL, "mch", oracle.QUIRKS_REFERENCE),
+            (oracle.MUSCL, "mchnone", oracle.QUIRKS_REFERENCE & ~oracle.Q11_MUSCL_NB_Y_IS_BED),
+            (oracle.INERTIAL, "ine", oracle.QUIRKS_REFERENCE))
+    for scheme, name, quirks in runs:
+        sim = oracle.RefSim(64, 48, scheme=scheme, quirks=quirks)
         sim.upload(st, bed, man)
         sim.set_target(2.5)
         out[f"{name}_dt"] = sim.run(150)
         out[f"{name}_state"] = sim.download()
         out[f"{name}_t"] = np.array(sim.scalars()["t"])
+    assert not np.array_equal(out["mch_state"], out["mchnone_state"])
     save(f"f15_disabled_cells_{tag}", **out)
 
 

@@ -516,22 +516,46 @@ def test_strict_bit_identity_at_scale(scheme):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("scheme,name", [(hp.SCHEME_GODUNOV, "god"), (hp.SCHEME_MUSCL_HANCOCK, "mch"), (hp.SCHEME_INERTIAL, "ine")])
-def test_disabled_cells_fixture(scheme, name, mode):
-    """Disabled cells (Zmax = -9999 / Z == -9999) against the fixture from the reference's kernels: carried unchanged bit
-    for bit, the wet cells around them within the stated tolerance, same time."""
+@pytest.mark.parametrize("scheme,name,quirks", [
+    (hp.SCHEME_GODUNOV, "god", hp.QUIRKS_REFERENCE), (hp.SCHEME_MUSCL_HANCOCK, "mch", hp.QUIRKS_REFERENCE),
+    (hp.SCHEME_MUSCL_HANCOCK, "mchnone", hp.QUIRKS_REFERENCE & ~hp.QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED),
+    (hp.SCHEME_INERTIAL, "ine", hp.QUIRKS_REFERENCE)])
+def test_disabled_cells_fixture(scheme, name, quirks, mode):
+    """Disabled cells (mask-style nulls: Zmax = -9999 over an ordinary bed; Z == -9999; DEM-nodata nulls; a live cell on a
+    -9998.5 bed) against the fixture from the reference's kernels: STRICT bit for bit -- every cell, every timestep --, FAST
+    within the stated tolerance with the nulls carried unchanged.  `mch` is the reference's DEFAULT MUSCL-Hancock
+    configuration (kCachePrediction, CSchemeMUSCLHancock.cpp:46; fixture from mch_1st_cachePrediction run as real
+    work-groups): the predictor's first-order test reads the neighbours' BED (CLSchemeMUSCLHancock.clc:201, :232-239,
+    :325-330), so cells next to mask-style nulls stay second order; `mchnone` is mch_1st_cacheNone (neighbours' Zmax),
+    HP_QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED off."""
     g = load_golden("f15_disabled_cells_f64")
-    dom = hp.Domain(64, 48, scheme=scheme, math_mode=mode)
+    dom = hp.Domain(64, 48, scheme=scheme, math_mode=mode, quirks=quirks)
     dom.upload(g["state"], g["bed"], g["manning"])
     dom.set_target_time(2.5)
     dom.step_batch(150)
     out, ref, dis = dom.download(), g[f"{name}_state"], g["disabled"]
     assert np.array_equal(out[dis], g["state"][dis])
+    if mode == hp.MATH_STRICT:
+        assert np.array_equal(out, ref)
+        assert dom.read_scalars()["time"] == float(g[f"{name}_t"])
     live = ~dis & (g["state"][..., 0] != -9999.0)
     dg = np.maximum(0, out[..., 0] - g["bed"])[live]; dr = np.maximum(0, ref[..., 0] - g["bed"])[live]
     assert np.sqrt(np.mean((dg - dr) ** 2)) < 1e-9 and np.abs(dg - dr).max() < 1e-7
     assert abs(dom.read_scalars()["time"] - float(g[f"{name}_t"])) <= 1e-12 * float(g[f"{name}_t"])
     dom.close()
+
+
+def test_muscl_variants_differ_next_to_masked_cells():
+    """The two predictor variants are different schemes next to nulls: the engine's two settings reproduce the fixture's two
+    runs and not each other's (guards against the quirk flag being ignored)."""
+    g = load_golden("f15_disabled_cells_f64")
+    outs = {}
+    for name, quirks in (("mch", hp.QUIRKS_REFERENCE), ("mchnone", hp.QUIRKS_REFERENCE & ~hp.QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED)):
+        dom = hp.Domain(64, 48, scheme=hp.SCHEME_MUSCL_HANCOCK, math_mode=hp.MATH_STRICT, quirks=quirks)
+        dom.upload(g["state"], g["bed"], g["manning"]); dom.set_target_time(2.5); dom.step_batch(150)
+        outs[name] = dom.download(); dom.close()
+    assert np.array_equal(outs["mch"], g["mch_state"]) and np.array_equal(outs["mchnone"], g["mchnone_state"])
+    assert not np.array_equal(outs["mch"], outs["mchnone"])
 
 
 @pytest.mark.parametrize("definition", [hp.GRIDDED_MASS_FLUX, hp.GRIDDED_RAIN_INTENSITY])

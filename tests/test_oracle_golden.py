@@ -312,11 +312,16 @@ def test_no_friction_program():
 def test_disabled_cells():
     """The domain's nulls: cells with Zmax = -9999 (or Z == -9999) are carried unchanged, neighbours see their level."""
     g = load_golden("f15_disabled_cells_f64")
-    for scheme, name in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch"), (oracle.INERTIAL, "ine")):
-        sim = oracle.OracleSim(64, 48, scheme=scheme)
+    # `mch`: the reference's default predictor (mch_1st_cachePrediction as real work-groups: neighbours' .y = bed);
+    # `mchnone`: mch_1st_cacheNone (neighbours' .y = Zmax) -- quirk Q11 on / off
+    for scheme, name, quirks in ((oracle.GODUNOV, "god", oracle.QUIRKS_REFERENCE), (oracle.MUSCL, "mch", oracle.QUIRKS_REFERENCE),
+                                 (oracle.MUSCL, "mchnone", oracle.QUIRKS_REFERENCE & ~oracle.Q11_MUSCL_NB_Y_IS_BED),
+                                 (oracle.INERTIAL, "ine", oracle.QUIRKS_REFERENCE)):
+        sim = oracle.OracleSim(64, 48, scheme=scheme, quirks=quirks)
         sim.upload(g["state"], g["bed"], g["manning"])
         sim.set_target(2.5)
         assert same(sim.run(150), g[f"{name}_dt"])
         out = sim.download()
         assert same(out, g[f"{name}_state"]) and sim.scalars()["t"] == g[f"{name}_t"]
         assert same(out[g["disabled"]], g["state"][g["disabled"]]) and g["disabled"].sum() > 100
+    assert not same(g["mch_state"], g["mchnone_state"])

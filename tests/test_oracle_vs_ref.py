@@ -30,6 +30,31 @@ def test_random_terrain_trajectory(precision, scheme, seed):
     assert sa["batch_skipped"] > 0
 
 
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("default_variant", [True, False])
+def test_muscl_predictor_variants_next_to_nulls(precision, default_variant):
+    """The reference's two MUSCL-Hancock predictors, live: its DEFAULT mch_1st_cachePrediction (kCachePrediction,
+    CSchemeMUSCLHancock.cpp:46) run as real 16 x 16 work-groups with LDS tile and barrier (oracle/ref_build/shim.cpp) -- the
+    neighbours' .y is their BED --, and mch_1st_cacheNone -- their Zmax.  Mask-style nulls (Zmax = -9999 over an ordinary
+    bed), DEM-nodata nulls and a live cell on a bed below -9998: the restatement follows each variant bit for bit."""
+    real = np.float64 if precision == "f64" else np.float32
+    st, bed, man = syn.s_rough(40, 33, dtype=real, seed=4, manning=None)
+    rng = np.random.default_rng(41)
+    mask = rng.random((33, 40)) < 0.06
+    mask[0] = mask[-1] = False; mask[:, 0] = mask[:, -1] = False
+    st[mask, 1] = -9999.0
+    bed[20:23, 8:11] = -9999.0; st[20:23, 8:11, 0] = -9999.0; st[20:23, 8:11, 1] = -9999.0
+    bed[12, 30] = -9998.25; st[12, 30, 0] = -9998.25; st[12, 30, 1] = -9998.25
+    quirks = oracle.QUIRKS_REFERENCE if default_variant else oracle.QUIRKS_REFERENCE & ~oracle.Q11_MUSCL_NB_Y_IS_BED
+    a = oracle.OracleSim(40, 33, scheme=oracle.MUSCL, precision=precision, quirks=quirks)
+    b = oracle.RefSim(40, 33, scheme=oracle.MUSCL, precision=precision, quirks=quirks)
+    for s in (a, b):
+        s.upload(st, bed, man)
+        s.set_target(1e9)
+    assert np.array_equal(a.run(60), b.run(60))
+    assert np.array_equal(a.download(), b.download(), equal_nan=True)
+
+
 def test_threads_do_not_change_results():
     st, bed, man = syn.s_rough(64, 48, manning=None)
     outs = []

@@ -8,7 +8,7 @@ __global__ void phase_predict(const T* in, T* out)
 {
 	Raw<T> c{LD(0), LD(1), LD(2), LD(3), LD(4)}, n{LD(5), LD(6), LD(7), LD(8), LD(9)}, e{LD(10), LD(11), LD(12), LD(13), LD(14)},
 	       s{LD(15), LD(16), LD(17), LD(18), LD(19)}, w{LD(20), LD(21), LD(22), LD(23), LD(24)};
-	bool quiet, same; const Faces<T> f = muscl_predict<false>(c, n, e, s, w, LD(25), LD(26), LD(27), LD(28), quiet, same);
+	bool quiet, same; const Faces<T> f = muscl_predict<false>(c, n, e, s, w, LD(25), LD(26), LD(27), LD(28), true, quiet, same);
 	T* o = out + threadIdx.x;
 	o[0] = f.n.z; o[64] = f.n.h; o[128] = f.n.qx; o[192] = f.n.qy; o[256] = f.e.z; o[320] = f.e.h; o[384] = f.e.qx; o[448] = f.e.qy;
 	o[512] = f.s.z; o[576] = f.s.h; o[640] = f.s.qx; o[704] = f.s.qy; o[768] = f.w.z; o[832] = f.w.h; o[896] = f.w.qx; o[960] = f.w.qy;

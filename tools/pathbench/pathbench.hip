@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_piece(const Snap s, const int iters, do
 	Raw<double> rc{c.z, c.zmax, c.qx, c.qy, zb}, rn{cn.z, cn.zmax, cn.qx, cn.qy, zbn}, re{ce.z, ce.zmax, ce.qx, ce.qy, zbe},
 	            rs{cs_.z, cs_.zmax, cs_.qx, cs_.qy, zbs}, rw{cw.z, cw.zmax, cw.qx, cw.qy, zbw};
 	bool q0, q1;
-	Faces<double> pc = muscl_predict<false>(rc, rn, re, rs, rw, dt, dx, inv_dx, vs, q0, q1);
+	Faces<double> pc = muscl_predict<false>(rc, rn, re, rs, rw, dt, dx, inv_dx, vs, true, q0, q1);
 	Side<double> mE = side_from_face<false>(pc.e, c.qx, c.qy, vs), mN = side_from_face<false>(pc.n, c.qx, c.qy, vs);
 	Side<double> mEnb, mNnb;
 	{
@@ -79,13 +79,13 @@ __global__ __launch_bounds__(256) void k_piece(const Snap s, const int iters, do
 			cell(s, x + 1 + ox, y + oy, t, tz); r2[k] = Raw<double>{t.z, t.zmax, t.qx, t.qy, tz};
 		}
 		bool a, b;
-		Faces<double> pe = muscl_predict<false>(r2[0], r2[1], r2[2], r2[3], r2[4], dt, dx, inv_dx, vs, a, b);
+		Faces<double> pe = muscl_predict<false>(r2[0], r2[1], r2[2], r2[3], r2[4], dt, dx, inv_dx, vs, true, a, b);
 		mEnb = side_from_face<false>(pe.w, ce.qx, ce.qy, vs);
 		for (int k = 0; k < 5; ++k) {
 			const long ox = (k == 2) - (k == 4), oy = (k == 1) - (k == 3);
 			cell(s, x + ox, y + 1 + oy, t, tz); r2[k] = Raw<double>{t.z, t.zmax, t.qx, t.qy, tz};
 		}
-		Faces<double> pn = muscl_predict<false>(r2[0], r2[1], r2[2], r2[3], r2[4], dt, dx, inv_dx, vs, a, b);
+		Faces<double> pn = muscl_predict<false>(r2[0], r2[1], r2[2], r2[3], r2[4], dt, dx, inv_dx, vs, true, a, b);
 		mNnb = side_from_face<false>(pn.s, cn.qx, cn.qy, vs);
 	}
 
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_piece(const Snap s, const int iters, do
 			Raw<double> a = rc; opaque(a.z); opaque(a.qx); opaque(a.qy);
 			Raw<double> b = rn; opaque(b.z); opaque(b.qx);
 			bool qa, qb;
-			const Faces<double> p = muscl_predict<false>(a, b, re, rs, rw, dt, dx, inv_dx, vs, qa, qb);
+			const Faces<double> p = muscl_predict<false>(a, b, re, rs, rw, dt, dx, inv_dx, vs, true, qa, qb);
 			acc += p.n.z + p.n.h + p.n.qx + p.n.qy + p.e.z + p.e.h + p.e.qx + p.e.qy + p.s.z + p.s.h + p.s.qx + p.s.qy + p.w.z + p.w.h + p.w.qx + p.w.qy;
 		} else if (PIECE == P_SIDE_FROM_FACE) {
 			Faces<double> p = pc; opaque(p.n.z); opaque(p.n.h); opaque(p.e.z); opaque(p.e.h); opaque(p.s.z); opaque(p.s.h); opaque(p.w.z); opaque(p.w.h);
