@@ -2,20 +2,28 @@
 """bench.py -- Mcell-steps/s of the Godunov + HLLC fp64 step on the synthetic flat-DEM dam-break (S-DAM).
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-N = 1 : BASELINE.json configs[1], 4096 x 4096, one MI355X.
-N > 1 : one process per GPU (torch.distributed.run), 1-D row strips with per-step ghost-row exchange and an 8-byte
-        MAX all-reduce over RCCL, the per-iteration loop run by the library itself (hp_strip_step_batch); weak scaling
-        along the configs' ladder 4096^2 -> 8192x4096 -> 8192^2 -> 16384x8192 (configs[3] at N = 8), i.e. 16,777,216
-        cells per GPU at every N.  `--scaling strong` cuts the 4096^2 grid into N strips instead.
+N = 1 : BASELINE.json configs[1], 4096 x 4096, one MI355X.  The line also carries a `strict` leg (the exact mode: the
+        reference's bits, the only mode that meets 1e-9 m on every config) and the Manning-array leg.
+N > 1 : one process per GPU (torch.distributed.run), 1-D row strips with per-iteration ghost rows and an 8-byte MAX, the
+        per-iteration loop run by the library itself (hp_strip_step_batch).  BASELINE.json's metric is quoted on the 4096^2
+        grid at 1/2/4/8 GPUs and north_star's target is STRONG scaling, so `value` is the strong-scaling leg -- the 4096^2
+        grid cut into N strips, `scaling: "strong"` -- with `speedup_vs_1gpu_same_run` from a single-domain leg that rank 0
+        runs on its own GPU in the same invocation; the object `weak` is the second leg, the configs' ladder 4096^2 ->
+        8192x4096 -> 8192^2 -> 16384x8192 (configs[3] at N = 8; 16,777,216 cells per GPU at every N) with its own
+        roofline.  `--scaling weak|strong` runs one leg only (then `value` is that leg's).
 
 The timed region starts with all inputs resident in HBM.  An untimed, time-based pre-warm (--prewarm-s) settles clocks
 and caches; the state is then put back from a device-side checkpoint (hp_state_restore), W untimed warm-up steps run,
 and EXACTLY K steps are timed (barrier + device sync on both sides).  That is done `--repeats` times -- every repeat
 times the same steps [W, W+K) of the workload from t = 0 -- and the MEDIAN repeat is reported.  `--evolve-steps E`
-moves the timed window to [W+E, W+E+K): a developed flood instead of the first moments after the dam has gone.  `roofline` prices the flux kernel from HIP events recorded on
-the domain's own stream (sparse samples, events created before the timed region); `roofline_manning_array` is the
-same kernel with a spatially varying Manning array; `cpu_baseline` times the reference's kernel sources compiled for
-the host (oracle/_ref) / the plain-C oracle on the host cores.
+moves the timed window to [W+E, W+E+K): a developed flood instead of the first moments after the dam has gone.
+`roofline`: when an iteration is ONE launch (the flux launch carries its own tail block; no separate boundary pass) the
+kernel cannot take longer than the step, and `frac` is priced from `ms_per_step` -- reproducible from the line itself and
+from the driver's clock; the flux kernel is also sampled with HIP events on the domain's own stream (sparse samples, events
+created before the timed region): `frac_event_sampled`, with the raw average and the cost of an empty event pair that was
+taken off (`avg_launch_ms_raw`, `event_pair_overhead_ms`).  `roofline_manning_array` is the same kernel with a spatially
+varying Manning array; `cpu_baseline` times the reference's kernel sources compiled for the host (oracle/_ref) / the plain-C
+oracle on the host cores.
 """
 import argparse
 import json
@@ -33,16 +41,6 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/
 BYTES_PER_CELL_STEP = {"f64": 80.0, "f32": 40.0}      # read state+bed+Manning, write state
 
 LADDER = {1: (4096, 4096), 2: (8192, 4096), 4: (8192, 8192), 8: (16384, 8192)}
-
-
-def grid_for(n_gpus, cols, rows, scaling="weak"):
-    if cols and rows:
-        return cols, rows
-    if scaling == "strong":
-        return LADDER[1]                 # configs[1]'s 4096 x 4096 cut into N strips (north_star's strong-scaling target)
-    if n_gpus in LADDER:
-        return LADDER[n_gpus]
-    return 4096, 4096 * n_gpus
 
 
 def pmc_traffic(kernel_substr, scheme):
@@ -127,10 +125,24 @@ def cpu_baseline(cols, precision, scheme, levels=(10.0, 1.0), budget_s=8.0):
 
 
 def visible_gpus():
-    """GPUs this process could use, WITHOUT initialising the HIP runtime (the launcher must stay GPU-free: it starts
-    the rank processes and a process that has touched the GPU must not spawn-and-replace itself on this pool)."""
-    import torch
-    return int(torch.cuda.device_count())
+    """GPUs this process could use, counted WITHOUT the HIP runtime (the launcher must stay GPU-free: it starts the rank
+    processes, and torch.cuda.device_count() falls through to hipGetDeviceCount -- which opens /dev/kfd -- when amdsmi is
+    not importable).  The KFD topology lists every node; GPUs are the nodes with SIMDs.  HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES narrow the set the ranks will see."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def self_launch(args):
@@ -165,12 +177,159 @@ def self_launch(args):
     print(lines[0], flush=True)
 
 
+
+WORKLOAD_NAMES = {"s-rain": "S-RAIN gridded-rainfall on dry terrain", "s-rough": "S-ROUGH wet/dry rough terrain",
+                  "s-dam": "S-DAM flat-DEM dam-break"}
+
+
+def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=False, repeats=None, last=True):
+    """One timed leg: build this rank's runner for a `cols x rows` grid cut into `world` strips, load the workload, pre-warm,
+    then `repeats` x (restore, W warm-up steps, EXACTLY K timed steps between barrier + device sync); median repeat.
+    Returns what rank 0 needs for the line (every rank gets the same timing numbers: max over ranks)."""
+    from hipims_mi import synthetic as syn
+    scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
+    levels = (2.0, 1.6) if args.scheme == "inertial" else (10.0, 1.0)     # the partial-inertial scheme wants a gentle step
+    math_mode = hp.MATH_FAST if math == "fast" else hp.MATH_STRICT
+    kernel = hp.KERNEL_AUTO if args.kernel == "auto" else hp.KERNEL_BASIC
+    real = np.float64 if args.precision == "f64" else np.float32
+    dx = 2.0 if args.workload == "s-rain" else 1.0
+    if world == 1:
+        from hipims_mi.strips import SingleRunner
+        runner = SingleRunner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
+                              device=local_rank)
+    else:
+        from hipims_mi.strips import StripRunner
+        # HIPIMS_MI_BACKEND=gloo: rehearsal of this branch with several processes on one GPU (host-staged exchange)
+        backend = os.environ.get("HIPIMS_MI_BACKEND", "nccl")
+        device = local_rank if backend == "nccl" else local_rank % max(1, hp.device_count())
+        runner = StripRunner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
+                             device=device, rank=rank, world=world, backend=backend)
+    if args.workload == "s-rain":
+        st, bed, man, rain = syn.s_rain_rows(cols, rows, runner.local_lo, runner.local_hi, dx=dx, dtype=real)
+        runner.upload(st, bed, man)
+        runner.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"],
+                                  rain["off_y"], rain["interval"])
+    elif args.workload == "s-rough":
+        if world != 1:
+            raise SystemExit("--workload s-rough is a single-GPU diagnostic")
+        st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
+        runner.upload(st, bed, man)
+    else:
+        st, bed, man = (syn.s_dam(cols, runner.local_rows_total, dtype=real, levels=levels) if world == 1
+                        else runner.make_s_dam(real, levels=levels))
+        if manning_array:     # all 80 B/cell streamed: the uniform n of S-DAM is otherwise passed as a scalar
+            man = (0.03 + np.random.default_rng(11).uniform(-0.005, 0.005, man.shape)).astype(real)
+        runner.upload(st, bed, man)
+    del st, bed, man
+    runner.set_target_time(1e9)
+
+    # ---- untimed: a time-based pre-warm so that a short run (the driver's 20 steps are 5 ms of GPU time) is not
+    #      measured on clocks and caches that have not settled.  The pre-warm advances the flood by however many steps
+    #      fit into its time -- a faster kernel would hand the timed region a more developed (more expensive) flood --
+    #      so the state is then put back from a device-side checkpoint: what is timed is always steps [W, W+K) of the
+    #      workload from t = 0, whatever the hardware did before ----
+    runner.save()
+    runner.barrier()
+    t_warm = time.perf_counter()
+    # every rank must run the same number of passes (each is 25 collective iterations): the decision is taken on the
+    # maximum over ranks of the elapsed time, which is one value everywhere
+    while runner.max_over_ranks(time.perf_counter() - t_warm) < args.prewarm_s:
+        runner.step(25)
+        runner.barrier()
+
+    stride = max(1, args.steps // 12) | 1              # odd: both CFL flavours of the kernel get sampled
+    runs = []
+    for _ in range(max(1, repeats if repeats is not None else args.repeats)):
+        runner.restore()
+        runner.step(args.warmup + args.evolve_steps)
+        runner.domain.kernel_timing(stride)
+        runner.barrier()
+        t0 = time.perf_counter()
+        runner.step(args.steps)
+        runner.barrier()
+        el = runner.max_over_ranks(time.perf_counter() - t0)
+        k_ms, k_n = runner.domain.kernel_timing_read()
+        runs.append((el, k_ms, k_n))
+    overhead_ms = runner.domain.kernel_timing_overhead()
+    runs.sort()
+    elapsed = runs[len(runs) // 2][0]
+    k_n = runs[len(runs) // 2][2]
+    k_ms = sorted(r[1] for r in runs)[len(runs) // 2]
+    sc = runner.domain.read_scalars()
+    # ---- N > 1: a number is only a measurement if the strips really saw each other's rows.  After the timed batch every
+    #      rank's ghost rows must equal, bit for bit, the rows their owners hold -- checked over torch.distributed's own
+    #      channel, whatever transport the strip loop used (RCCL send/receive, or the strips' direct writes over xGMI) ----
+    if world > 1:
+        bad = runner.verify_ghost_rows()
+        if bad:
+            raise SystemExit(f"bench.py --gpus {world}: {bad} ghost-row cells differ from their owners' values after the timed "
+                             f"batch of the {cols}x{rows} leg -- the strips did not exchange correctly; no line is printed for a broken run")
+    strip_info = runner.domain.strip_info() if world > 1 and getattr(runner, "loop", "") == "cxx" else None
+    leg = dict(cols=cols, rows=rows, world=world, math=math, elapsed=elapsed, runs=runs, k_ms=k_ms, k_n=k_n, sc=sc,
+               overhead_ms=overhead_ms, strip_info=strip_info, loop=getattr(runner, "loop", "batch call"),
+               cells_per_launch=cols * runner.local_rows_total, flux_kernel=runner.flux_kernel_name, levels=levels,
+               fused=(runner.domain.boundaries_fused() if args.workload == "s-rain" else None),
+               one_launch=(args.kernel == "auto" and os.environ.get("HP_LAUNCH_TAIL", "1") != "0"
+                           and (args.workload != "s-rain")
+                           and (world == 1 or bool(strip_info and strip_info["peer_halo"]))))
+    if world > 1 and not last:
+        runner.close(destroy_group=False)
+    else:
+        runner.close()
+    return leg
+
+
+def roofline_of(args, leg):
+    """algorithmic bytes per launch / the flux kernel's launch duration, against the 8 TB/s HBM line."""
+    bpc = BYTES_PER_CELL_STEP[args.precision]
+    ms_step = leg["elapsed"] / args.steps * 1e3
+    raw = leg["k_ms"] + leg["overhead_ms"] if leg["k_ms"] > 0 else 0.0
+    bytes_launch = bpc * leg["cells_per_launch"]
+    frac_of = lambda ms: (bytes_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0
+    ev_ms = min(leg["k_ms"], ms_step) if (leg["one_launch"] and leg["k_ms"] > 0) else leg["k_ms"]   # a kernel is never longer than the step it is all of
+    launch_ms = ms_step if leg["one_launch"] else ev_ms
+    r = {"bound": "hbm", "achieved": frac_of(launch_ms) * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": frac_of(launch_ms), "traffic": None, "kernel": leg["flux_kernel"],
+         "frac_basis": ("ms_per_step: an iteration is one launch (the flux launch carries the time advance), so the kernel's "
+                        "duration is at most the step's" if leg["one_launch"] else "HIP-event samples of the flux kernel"),
+         "avg_launch_ms": launch_ms, "frac_event_sampled": frac_of(ev_ms), "avg_launch_ms_event_sampled": ev_ms,
+         "avg_launch_ms_raw": raw, "event_pair_overhead_ms": leg["overhead_ms"], "launches_sampled": leg["k_n"],
+         "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": leg["cells_per_launch"]}
+    if args.workload in ("s-dam", "s-rain", "s-rough") and leg.get("manning_uniform", True):
+        # the synthetic workloads have ONE Manning value, which the engine passes as a scalar: the bytes such a launch
+        # really has to move are 72 (fp64) / 36 (fp32) per cell; SURVEY 8(d)'s contract figure stays above
+        r["uniform_manning_bytes_per_cell_step"] = bpc * 0.9
+        r["frac_at_uniform_manning_bytes"] = 0.9 * r["frac"]
+    return r
+
+
+def parallelism_of(leg):
+    world, si = leg["world"], leg["strip_info"]
+    s = f"row-strips x{world}"
+    if world > 1:
+        s += f", per-iteration loop: {leg['loop']}"
+    if si:
+        s += (f", collective library {si['library']} reporting {si['comm_ranks']} ranks, halo overlap {'on' if si['halo_overlap'] else 'off'}, "
+              f"maximum over the strips by {'peer-written mailboxes' if si['peer_max'] else 'all-reduce'}, ghost rows "
+              f"{'stored into the neighbours by the strips themselves' if si['peer_halo'] else 'sent and received through the library'}")
+    if world > 1 and os.environ.get("HIPIMS_MI_BACKEND", "nccl") != "nccl":
+        s += " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"
+    return s
+
+
+def workload_of(args, leg):
+    lv = leg["levels"]
+    return (f"{WORKLOAD_NAMES[args.workload]} {leg['cols']}x{leg['rows']}{'' if lv[0] == 10.0 else ' (levels %g|%g m)' % lv}, "
+            f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
+            f"dynamic CFL dt, quirks=reference, math={leg['math']}, kernel={args.kernel}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cols", type=int, default=0)
+    ap.add_argument("--cols", type=int, default=0, help="with --rows: the grid of the N = 1 / strong-scaling leg (the weak leg has N times the rows)")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--scheme", choices=["godunov", "muscl", "inertial"], default="godunov")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
@@ -179,10 +338,13 @@ def main():
     ap.add_argument("--workload", choices=["s-dam", "s-rain", "s-rough"], default="s-dam",
                     help="s-dam: BASELINE configs[1..3]; s-rain: configs[4] (initially dry terrain + gridded rainfall, dx = 2 m); "
                          "s-rough: SURVEY 8(d)'s wet/dry rough terrain at full size (every tile on the general path; N = 1)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = 16.8 Mcell per GPU along the configs' ladder (default); strong = 4096^2 cut into N strips")
+    ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
+                    help="N > 1: both (default) = `value` from the strong leg (the metric's 4096^2 grid cut into N strips) and the "
+                         "object `weak` from the configs' ladder (16.8 Mcell per GPU); weak / strong = that leg only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-manning-leg", action="store_true")
+    ap.add_argument("--no-strict-leg", action="store_true")
+    ap.add_argument("--no-single-leg", action="store_true", help="N > 1: skip rank 0's single-domain leg (speedup_vs_1gpu_same_run)")
     ap.add_argument("--repeats", type=int, default=3, help="timed repeats of --steps steps; the median is reported")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed time-based pre-warm (the state is restored afterwards)")
     ap.add_argument("--evolve-steps", type=int, default=0, help="untimed steps after the warm-up: time a developed flood")
@@ -201,165 +363,103 @@ def main():
         # single GPU needs no collectives: keep torch (and its bundled, older HIP runtime) out of the process
         os.environ.setdefault("HIPIMS_MI_NO_TORCH", "1")
     import hipims_mi as hp
-    from hipims_mi import synthetic as syn
 
-    cols, rows = grid_for(world, args.cols, args.rows, args.scaling)
-    scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
-    # the partial-inertial scheme is only meaningful for a gentle step (2.0 m | 1.6 m instead of 10 m | 1 m)
-    levels = (2.0, 1.6) if args.scheme == "inertial" else (10.0, 1.0)
-    math_mode = hp.MATH_FAST if args.math == "fast" else hp.MATH_STRICT
-    kernel = hp.KERNEL_AUTO if args.kernel == "auto" else hp.KERNEL_BASIC
-    real = np.float64 if args.precision == "f64" else np.float32
+    custom = bool(args.cols and args.rows)
+    strong_grid = (args.cols, args.rows) if custom else LADDER[1]
+    weak_grid = ((args.cols, args.rows * world) if custom else LADDER.get(world, (4096, 4096 * world)))
+    bpc = BYTES_PER_CELL_STEP[args.precision]
 
-    dx = 2.0 if args.workload == "s-rain" else 1.0
     if world == 1:
-        from hipims_mi.strips import SingleRunner as Runner
-        runner = Runner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
-                        device=local_rank)
+        cols, rows = strong_grid
+        main_leg = run_leg(args, hp, cols, rows, 1, 0, local_rank, args.math)
+        default_cfg = ((cols, rows) == (4096, 4096) and args.precision == "f64" and args.kernel == "auto"
+                       and args.workload == "s-dam" and args.math == "fast")
+        manning_leg = strict_leg = None
+        if args.workload == "s-dam" and not args.no_manning_leg:
+            manning_leg = run_leg(args, hp, cols, rows, 1, 0, local_rank, args.math, manning_array=True, repeats=1)
+            manning_leg["manning_uniform"] = False
+        if args.math == "fast" and not args.no_strict_leg:
+            strict_leg = run_leg(args, hp, cols, rows, 1, 0, local_rank, "strict", repeats=1)
+        scaling, weak_leg, single_leg = "weak", None, None
     else:
-        from hipims_mi.strips import StripRunner as Runner
-        # HIPIMS_MI_BACKEND=gloo: rehearsal of this branch with several processes on one GPU (host-staged exchange)
-        backend = os.environ.get("HIPIMS_MI_BACKEND", "nccl")
-        device = local_rank if backend == "nccl" else local_rank % max(1, hp.device_count())
-        runner = Runner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
-                        device=device, rank=rank, world=world, backend=backend)
+        legs = {"both": ("strong", "weak"), "weak": ("weak",), "strong": ("strong",)}[args.scaling]
+        single = "strong" in legs and not args.no_single_leg
+        results = {}
+        for i, kind in enumerate(legs):
+            cols, rows = strong_grid if kind == "strong" else weak_grid
+            results[kind] = run_leg(args, hp, cols, rows, world, rank, local_rank, args.math,
+                                    last=(i == len(legs) - 1 and not single))
+        main_leg = results[legs[0]]
+        weak_leg = results.get("weak") if legs[0] == "strong" else None
+        scaling = legs[0]
+        single_leg = None
+        if single:
+            # the strong-scaling denominator, measured in the same invocation: rank 0 runs the whole grid as ONE domain on
+            # its own GPU (same protocol, one repeat less) while the other ranks wait at the barrier below
+            import torch.distributed as dist
+            if rank == 0:
+                single_leg = run_leg(args, hp, strong_grid[0], strong_grid[1], 1, 0, local_rank, args.math, repeats=max(1, args.repeats - 1))
+            dist.barrier()
+            dist.destroy_process_group()
+        manning_leg = strict_leg = None
+        default_cfg = False
 
-    if args.workload == "s-rain":
-        st, bed, man, rain = syn.s_rain_rows(cols, rows, runner.local_lo, runner.local_hi, dx=dx, dtype=real)
-        runner.upload(st, bed, man)
-        runner.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"],
-                                  rain["off_y"], rain["interval"])
-    elif args.workload == "s-rough":
-        if world != 1:
-            raise SystemExit("--workload s-rough is a single-GPU diagnostic")
-        st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
-        runner.upload(st, bed, man)
-    else:
-        st, bed, man = (syn.s_dam(cols, runner.local_rows_total, dtype=real, levels=levels) if world == 1
-                        else runner.make_s_dam(real, levels=levels))
-        runner.upload(st, bed, man)
-    del st, bed, man
-    runner.set_target_time(1e9)
-
-    # ---- untimed: a time-based pre-warm so that a short run (the driver's 20 steps are 6 ms of GPU time) is not
-    #      measured on clocks and caches that have not settled.  The pre-warm advances the flood by however many steps
-    #      fit into its time -- a faster kernel would hand the timed region a more developed (more expensive) flood --
-    #      so the state is then put back from a device-side checkpoint: what is timed is always steps [W, W+K) of the
-    #      workload from t = 0, whatever the hardware did before ----
-    runner.save()
-    runner.barrier()
-    t_warm = time.perf_counter()
-    # every rank must run the same number of passes (each is 25 collective iterations): the decision is taken on the
-    # maximum over ranks of the elapsed time, which is one value everywhere
-    while runner.max_over_ranks(time.perf_counter() - t_warm) < args.prewarm_s:
-        runner.step(25)
-        runner.barrier()
-
-    # ---- `repeats` x (restore, W untimed warm-up steps, EXACTLY K timed steps bracketed by barrier + device sync);
-    #      the median repeat is reported.  The flux kernel is sampled sparsely (<= 16 launches per repeat, events
-    #      created beforehand) ----
-    stride = max(1, args.steps // 12) | 1              # odd: both CFL flavours of the kernel get sampled
-    runs = []
-    for _ in range(max(1, args.repeats)):
-        runner.restore()
-        runner.step(args.warmup + args.evolve_steps)
-        runner.domain.kernel_timing(stride)
-        runner.barrier()
-        t0 = time.perf_counter()
-        runner.step(args.steps)
-        runner.barrier()
-        el = runner.max_over_ranks(time.perf_counter() - t0)
-        k_ms, k_n = runner.domain.kernel_timing_read()
-        runs.append((el, k_ms, k_n))
-    runs.sort()
-    elapsed, k_ms, k_n = runs[len(runs) // 2]
-    k_ms = sorted(r[1] for r in runs)[len(runs) // 2]
-    sc = runner.domain.read_scalars()
-    # ---- N > 1: a number is only a measurement if the strips really saw each other's rows.  After the timed batch every
-    #      rank's ghost rows must equal, bit for bit, the rows their owners hold -- checked over torch.distributed's own
-    #      channel, whatever transport the strip loop used (RCCL send/receive, or the strips' direct writes over xGMI) ----
-    ghost_rows_bad = runner.verify_ghost_rows() if world > 1 else 0
-    if ghost_rows_bad:
-        raise SystemExit(f"bench.py --gpus {world}: {ghost_rows_bad} ghost-row cells differ from their owners' values after the "
-                         f"timed batch -- the strips did not exchange correctly; no line is printed for a broken run")
-
-    # ---- the same kernel with a spatially varying Manning array (the uniform n of S-DAM is passed as a scalar and
-    #      its 8 B/cell are not streamed): one more repeat, N = 1 only ----
-    manning_leg = None
-    if world == 1 and args.workload == "s-dam" and not args.no_manning_leg:
-        rng = np.random.default_rng(11)
-        man = (0.03 + rng.uniform(-0.005, 0.005, (rows, cols))).astype(real)
-        runner.domain.upload(manning=man)                  # a 128 MiB host copy: the clocks settle again afterwards
-        del man
-        t_warm = time.perf_counter()
-        while runner.max_over_ranks(time.perf_counter() - t_warm) < args.prewarm_s:
-            runner.step(25)
-            runner.barrier()
-        runner.restore()
-        runner.step(args.warmup + args.evolve_steps)
-        runner.domain.kernel_timing(stride)
-        runner.barrier()
-        t0 = time.perf_counter()
-        runner.step(args.steps)
-        runner.barrier()
-        el_m = time.perf_counter() - t0
-        km_ms, km_n = runner.domain.kernel_timing_read()
-        manning_leg = (el_m, km_ms, km_n)
-
-    strip_info = runner.domain.strip_info() if world > 1 and getattr(runner, "loop", "") == "cxx" else None
     if rank == 0:
-        cells = cols * rows
-        value = cells * args.steps / elapsed / 1e6
-        cells_per_launch = cols * runner.local_rows_total
-        bpc = BYTES_PER_CELL_STEP[args.precision]
-        achieved = bpc * cells_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        cells = main_leg["cols"] * main_leg["rows"]
+        value = cells * args.steps / main_leg["elapsed"] / 1e6
         out = {
             "metric": "Mcell-steps/sec fp64 Godunov+HLLC, 4096^2 grid, 1/2/4/8 MI355X; % HBM roofline",
             "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
-            "repeats_ms_per_step": [r[0] / args.steps * 1e3 for r in runs],
+            "ms_per_step": main_leg["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "repeats_ms_per_step": [r[0] / args.steps * 1e3 for r in main_leg["runs"]],
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{ {'s-rain': 'S-RAIN gridded-rainfall on dry terrain', 's-rough': 'S-ROUGH wet/dry rough terrain', 's-dam': 'S-DAM flat-DEM dam-break'}[args.workload] } "
-                                   f"{cols}x{rows}{'' if levels[0] == 10.0 else ' (levels %g|%g m)' % levels}, "
-                                   f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
-                                   f"dynamic CFL dt, quirks=reference, math={args.math}, kernel={args.kernel}",
-                       "cells_per_gpu": cells // world, "parallelism": f"row-strips x{world}" + (f", per-iteration loop: {getattr(runner, 'loop', 'batch call')}" if world > 1 else "") + (f", collective library {strip_info['library']} reporting {strip_info['comm_ranks']} ranks, halo overlap {'on' if strip_info['halo_overlap'] else 'off'}, maximum over the strips by {'peer-written mailboxes' if strip_info['peer_max'] else 'all-reduce'}, ghost rows {'stored into the neighbours by the strips themselves' if strip_info['peer_halo'] else 'sent and received through the library'}" if strip_info else "") + ("" if world == 1 or os.environ.get("HIPIMS_MI_BACKEND", "nccl") == "nccl"
-                                                                else " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"),
+            "config": {"workload": workload_of(args, main_leg),
+                       "cells_per_gpu": cells // world, "parallelism": parallelism_of(main_leg),
                        "area_boundaries": ("none" if args.workload != "s-rain" else
-                                           "fused into the flux kernel's store epilogue" if runner.domain.boundaries_fused() else "separate pass"),
+                                           "fused into the flux kernel's store epilogue" if main_leg["fused"] else "separate pass"),
                        "timed_steps": [args.warmup + args.evolve_steps, args.warmup + args.evolve_steps + args.steps],
-                       "sim_time_s": sc["time"], "successful_iterations": sc["batch_successful"],
+                       "sim_time_s": main_leg["sc"]["time"], "successful_iterations": main_leg["sc"]["batch_successful"],
                        **({"ghost_rows_verified_after_timed_batch": True} if world > 1 else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": runner.flux_kernel_name, "avg_launch_ms": k_ms, "launches_sampled": k_n,
-                         "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": cells_per_launch},
+            "roofline": roofline_of(args, main_leg),
         }
-        if args.workload in ("s-dam", "s-rain", "s-rough"):
-            # both synthetic workloads have ONE Manning value, which the engine passes as a scalar: the bytes this
-            # launch really has to move are 72 (fp64) / 36 (fp32) per cell; SURVEY 8(d)'s contract figure stays above
-            wb = bpc * 0.9
-            out["roofline"]["uniform_manning_bytes_per_cell_step"] = wb
-            out["roofline"]["frac_at_uniform_manning_bytes"] = wb * cells_per_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else 0.0
+        if single_leg:
+            v1 = single_leg["cols"] * single_leg["rows"] * args.steps / single_leg["elapsed"] / 1e6
+            out["speedup_vs_1gpu_same_run"] = value / v1
+            out["single_gpu_same_run"] = {"what": "the same grid as ONE domain on rank 0's GPU, same invocation, same protocol",
+                                          "value": v1, "ms_per_step": single_leg["elapsed"] / args.steps * 1e3,
+                                          "workload": workload_of(args, single_leg)}
+        if weak_leg:
+            wc = weak_leg["cols"] * weak_leg["rows"]
+            out["weak"] = {"what": "weak-scaling leg: the configs' ladder, fixed cells per GPU" + (" (configs[3])" if (weak_leg["cols"], weak_leg["rows"]) == (16384, 8192) else ""),
+                           "value": wc * args.steps / weak_leg["elapsed"] / 1e6, "unit": "Mcell-steps/s", "scaling": "weak",
+                           "ms_per_step": weak_leg["elapsed"] / args.steps * 1e3,
+                           "repeats_ms_per_step": [r[0] / args.steps * 1e3 for r in weak_leg["runs"]],
+                           "workload": workload_of(args, weak_leg), "cells_per_gpu": wc // world,
+                           "parallelism": parallelism_of(weak_leg), "ghost_rows_verified_after_timed_batch": True,
+                           "roofline": roofline_of(args, weak_leg)}
         if manning_leg:
-            el_m, km_ms, km_n = manning_leg
-            ach_m = bpc * cells_per_launch / (km_ms * 1e-3) / 1e9 if km_ms > 0 else 0.0
+            rm = roofline_of(args, manning_leg)
             out["roofline_manning_array"] = {"what": "same workload with a spatially varying Manning array (all 80 B/cell streamed)",
-                                             "value": cells * args.steps / el_m / 1e6, "achieved": ach_m, "frac": ach_m / HBM_PEAK_GBS,
-                                             "avg_launch_ms": km_ms, "launches_sampled": km_n}
-        default_cfg = (cols, rows) == (4096, 4096) and args.precision == "f64" and args.kernel == "auto" \
-            and args.workload == "s-dam" \
-            and args.math == "fast" and world == 1
+                                             "value": cells * args.steps / manning_leg["elapsed"] / 1e6, "achieved": rm["achieved"],
+                                             "frac": rm["frac"], "avg_launch_ms": rm["avg_launch_ms"],
+                                             "frac_event_sampled": rm["frac_event_sampled"], "launches_sampled": rm["launches_sampled"]}
+        if strict_leg:
+            rs = roofline_of(args, strict_leg)
+            out["strict"] = {"what": "the exact mode (math=strict): bit-identical to the reference's kernels, same workload, same steps",
+                             "value": cells * args.steps / strict_leg["elapsed"] / 1e6, "unit": "Mcell-steps/s",
+                             "ms_per_step": strict_leg["elapsed"] / args.steps * 1e3, "frac": rs["frac"],
+                             "frac_event_sampled": rs["frac_event_sampled"], "kernel": rs["kernel"]}
         if default_cfg:
             tr = pmc_traffic(args.scheme + "_march<false", args.scheme)
+            k_ms = out["roofline"]["avg_launch_ms"]
             if tr:
                 out["roofline"]["traffic"] = tr[0] / 1e9 / (k_ms * 1e-3) if k_ms > 0 else None   # GB/s, same unit as achieved
                 out["roofline"]["traffic_bytes_per_launch"] = tr[0]
                 out["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cols, args.precision, scheme, levels)
+            scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
+            out["cpu_baseline"] = cpu_baseline(main_leg["cols"], args.precision, scheme, main_leg["levels"])
         print(json.dumps(out), flush=True)
-    runner.close()
 
 
 if __name__ == "__main__":

@@ -2051,4 +2051,13 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples)
 	return HP_OK;
 }
 
+int hp_kernel_timing_overhead(hp_domain_t* d, double* overhead_ms)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!overhead_ms) return fail(HP_ERR_INVALID, "null argument");
+	*overhead_ms = d->timing_overhead_ms;
+	return HP_OK;
+}
+
 } // extern "C"

@@ -36,7 +36,7 @@ EXPORTS = [
     "hp_stream_halo", "hp_comm_load", "hp_comm_unique_id", "hp_strip_comm_init", "hp_strip_step_batch", "hp_strip_update_timestep",
     "hp_strip_comm_destroy", "hp_strip_info", "hp_strip_peer_ticket", "hp_strip_peer_connect", "hp_strip_peer_round",
     "hp_strip_peer_disconnect", "hp_timer_start",
-    "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read",
+    "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read", "hp_kernel_timing_overhead",
 ]
 
 
@@ -159,6 +159,7 @@ def load_library(path: str | None = None):
     lib.hp_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.hp_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     lib.hp_kernel_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    lib.hp_kernel_timing_overhead.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.hp_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.hp_device_info.argtypes = [C.c_int, C.POINTER(DeviceInfo)]
     _lib = lib
@@ -482,6 +483,12 @@ class Domain:
         avg, n = C.c_double(0), C.c_uint32(0)
         _check(self.lib, self.lib.hp_kernel_timing_read(self.h, C.byref(avg), C.byref(n)), "hp_kernel_timing_read")
         return avg.value, n.value
+
+    def kernel_timing_overhead(self):
+        """Cost of an empty event pair (ms) that kernel_timing_read() has taken off every sample."""
+        ms = C.c_double(0)
+        _check(self.lib, self.lib.hp_kernel_timing_overhead(self.h, C.byref(ms)), "hp_kernel_timing_overhead")
+        return ms.value
 
     # ---- output derivation (src/Datasets/CRasterDataset.cpp:214-251) ----
     def depth_velocity(self, state=None, bed=None):

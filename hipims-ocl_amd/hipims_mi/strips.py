@@ -388,9 +388,10 @@ class StripRunner:
         self.dist.all_gather_object(out, mine)
         return np.concatenate(out, axis=0)
 
-    def close(self):
+    def close(self, destroy_group=True):
+        """`destroy_group=False` keeps the process group for another StripRunner of this process (bench.py's second leg)."""
         if self.loop == "cxx":
             self.domain.strip_comm_destroy()
         self.engine.close()
-        if self.dist.is_initialized():
+        if destroy_group and self.dist.is_initialized():
             self.dist.destroy_process_group()

@@ -334,6 +334,9 @@ int hp_timer_stop(hp_domain_t* d, float* elapsed_ms);  /* BLOCKS until the stop 
  * The time an EMPTY event pair takes (measured by this call on the idle stream) is taken off every sample. */
 int hp_kernel_timing(hp_domain_t* d, int enable_stride);
 int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples);   /* BLOCKS */
+/* The cost of an empty event pair that the last hp_kernel_timing() measured and hp_kernel_timing_read() takes off every
+ * sample (raw average = avg_ms + this): reported so that lines with and without the correction can be compared. */
+int hp_kernel_timing_overhead(hp_domain_t* d, double* overhead_ms);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,18 @@ Q1_CFL_READS_PRIMARY, Q9_BDY_TRUNCATED, Q6_MUSCL_SERIAL = 1, 2, 4
 # BED in .y (CLSchemeMUSCLHancock.clc:201, :232-248, :325-330); off = the mch_1st_cacheNone variant (neighbours' Zmax)
 Q11_MUSCL_NB_Y_IS_BED = 8
 QUIRKS_REFERENCE = 15
+
+
+def quirks_to_engine(q: int) -> int:
+    """Oracle quirk mask -> the engine's HP_QUIRK_* mask (include/hipims_mi.h): Q1 and Q9 share their bits, Q6 is the oracle's
+    own (the engine is always snapshot order), Q11 is bit 3 here and bit 2 there."""
+    return (q & 3) | (4 if q & Q11_MUSCL_NB_Y_IS_BED else 0)
+
+
+def quirks_from_engine(q: int, muscl_serial: bool = False) -> int:
+    return (q & 3) | (Q11_MUSCL_NB_Y_IS_BED if q & 4 else 0) | (Q6_MUSCL_SERIAL if muscl_serial else 0)
+
+
 UNIFORM_RAIN_INTENSITY, UNIFORM_LOSS_RATE = 0, 1
 GRIDDED_RAIN_INTENSITY, GRIDDED_RAIN_ACCUMUL, GRIDDED_MASS_FLUX = 0, 1, 2
 DEPTH_IGNORE, DEPTH_IS_FSL, DEPTH_IS_DEPTH, DEPTH_IS_CRITICAL = 0, 1, 2, 3

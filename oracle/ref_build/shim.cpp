@@ -22,8 +22,7 @@
 #include "../../hipims-ocl_amd/csrc/hp_crmath.h"   // shared with the oracle and the STRICT HIP kernels (see there)
 #include <cstddef>
 #include <cstdint>
-#include <pthread.h>
-#include <thread>
+#include <ucontext.h>
 #include <vector>
 
 #ifdef REF_FP32
@@ -42,10 +41,19 @@ size_t get_local_id(unsigned d)    { return t_lid[d]; }
 size_t get_group_id(unsigned d)    { return t_grp[d]; }
 size_t get_local_size(unsigned d)  { return t_lsz[d]; }
 size_t get_global_size(unsigned d) { return t_gsz[d]; }
-// barrier(): a no-op for the kernels driven one work-item at a time (groups of 1 x 1 x 1); the one kernel driven as a real
-// work-group -- mch_1st_cachePrediction, ref_mch_1st_cached below -- gives every work-item thread this group's barrier
-static thread_local pthread_barrier_t* t_barrier = nullptr;
-void   barrier(unsigned)           { if (t_barrier) pthread_barrier_wait(t_barrier); }
+// barrier(): a no-op for the kernels driven one work-item at a time (groups of 1 x 1 x 1).  The one kernel driven as a real
+// work-group -- mch_1st_cachePrediction, ref_mch_1st_cached below -- runs its work-items as coroutines (ucontext fibers) of
+// the calling thread: barrier() hands control back to the group's scheduler, which resumes a work-item only after every
+// work-item of the group has arrived -- the semantics of the OpenCL barrier, deterministically and without 256 kernel threads.
+static thread_local ucontext_t* t_fiber = nullptr;      // the running work-item's context (nullptr: not inside a group)
+static thread_local ucontext_t* t_sched = nullptr;      // the group scheduler's context
+static thread_local int         t_at_barrier = 0;
+void   barrier(unsigned)
+{
+	if (!t_fiber) return;
+	t_at_barrier = 1;
+	swapcontext(t_fiber, t_sched);                        // resumed (ids restored by the scheduler) once the whole group is here
+}
 
 long   max(long a, long b)         { return a > b ? a : b; }
 long   min(long a, long b)         { return a < b ? a : b; }
@@ -197,11 +205,18 @@ void ref_mch_1st(const real* dt, const real* bed, real* state, real* fN, real* f
 /* The reference's DEFAULT predictor (ucConfiguration = kCachePrediction, CSchemeMUSCLHancock.cpp:46, kernels :523-531):
  * mch_1st_cachePrediction, work-groups of MCH_STG1_DIM1 x MCH_STG1_DIM2 = 16 x 16 work-items (floor(sqrt(256)),
  * CSchemeMUSCLHancock.cpp:361-373) that overlap by two cells, one __local tile per group and a barrier between filling and
- * reading it (CLSchemeMUSCLHancock.clc:176-296).  Run here as a REAL work-group: 256 host threads, one per work-item, with
- * a pthread barrier behind barrier(); the kernel's __local array is one static object of the compiled text, i.e. shared by the
- * threads exactly as LDS is shared by a group.  Groups run one after the other (a second barrier keeps a fast thread from
- * refilling the tile while a slow one still reads it).  Global size = ceil(n * 16/14) rounded up to the group size
- * (CSchemeMUSCLHancock.cpp:375-380, COCLKernel.cpp:343-344). */
+ * reading it (CLSchemeMUSCLHancock.clc:176-296).  Run here as a REAL work-group: 256 coroutines, one per work-item, that all
+ * run up to the barrier before any of them runs beyond it; the kernel's __local array is one static object of the compiled
+ * text, shared by the work-items exactly as LDS is shared by a group.  Groups run one after the other.  Global size =
+ * ceil(n * 16/14) rounded up to the group size (CSchemeMUSCLHancock.cpp:375-380, COCLKernel.cpp:343-344). */
+struct GroupCall { const real* dt; const real* bed; real* state; real* f[4]; int done; };
+static thread_local GroupCall* t_call = nullptr;
+static void work_item_entry()
+{
+	GroupCall* c = t_call;
+	mch_1st_cachePrediction(c->dt, c->bed, c->state, c->f[0], c->f[1], c->f[2], c->f[3]);
+	c->done = 1;                                          /* returns to the scheduler through uc_link */
+}
 void ref_mch_1st_cached(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW)
 {
 	const size_t L = 16;                                  /* == MCH_STG1_DIM1/2 of prelude.cl */
@@ -209,28 +224,46 @@ void ref_mch_1st_cached(const real* dt, const real* bed, real* state, real* fN, 
 		size_t g = (size_t)__builtin_ceil((double)n * ((double)L / (double)(L - 2)));
 		return (size_t)(__builtin_ceil((double)g / (double)L) * (double)L);
 	};
-	const size_t gsx = gsize(REFP_COLS), gsy = gsize(REFP_ROWS), ngx = gsx / L, ngy = gsy / L;
-	pthread_barrier_t bar;
-	pthread_barrier_init(&bar, nullptr, (unsigned)(L * L));
-	std::vector<std::thread> items;
-	for (size_t lid = 0; lid < L * L; ++lid)
-		items.emplace_back([&, lid] {
-			t_barrier = &bar;
-			const size_t lx = lid % L, ly = lid / L;
-			for (size_t gy = 0; gy < ngy; ++gy)
-				for (size_t gx = 0; gx < ngx; ++gx) {
-					t_gid[0] = gx * L + lx; t_gid[1] = gy * L + ly; t_gid[2] = 0;
-					t_grp[0] = gx; t_grp[1] = gy; t_grp[2] = 0;
-					t_lid[0] = lx; t_lid[1] = ly; t_lid[2] = 0;
-					t_lsz[0] = L; t_lsz[1] = L; t_lsz[2] = 1;
-					t_gsz[0] = gsx; t_gsz[1] = gsy; t_gsz[2] = 1;
-					mch_1st_cachePrediction(dt, bed, state, fN, fE, fS, fW);
-					pthread_barrier_wait(&bar);           /* the tile is free for the next group */
+	const size_t gsx = gsize(REFP_COLS), gsy = gsize(REFP_ROWS), ngx = gsx / L, ngy = gsy / L, items = L * L;
+	const size_t STACK = 128 * 1024;
+	static std::vector<char> stacks;                      /* allocated once: re-zeroing 32 MiB per call would dominate */
+	if (stacks.size() < items * STACK) stacks.resize(items * STACK);
+	std::vector<ucontext_t> ctx(items);
+	std::vector<GroupCall> call(items);
+	ucontext_t sched;
+	auto set_ids = [&](size_t gx, size_t gy, size_t lid) {
+		const size_t lx = lid % L, ly = lid / L;
+		t_gid[0] = gx * L + lx; t_gid[1] = gy * L + ly; t_gid[2] = 0;
+		t_grp[0] = gx; t_grp[1] = gy; t_grp[2] = 0;
+		t_lid[0] = lx; t_lid[1] = ly; t_lid[2] = 0;
+		t_lsz[0] = L; t_lsz[1] = L; t_lsz[2] = 1;
+		t_gsz[0] = gsx; t_gsz[1] = gsy; t_gsz[2] = 1;
+	};
+	t_sched = &sched;
+	for (size_t gy = 0; gy < ngy; ++gy)
+		for (size_t gx = 0; gx < ngx; ++gx) {
+			for (size_t i = 0; i < items; ++i) {
+				call[i] = GroupCall{dt, bed, state, {fN, fE, fS, fW}, 0};
+				getcontext(&ctx[i]);
+				ctx[i].uc_stack.ss_sp = &stacks[i * STACK];
+				ctx[i].uc_stack.ss_size = STACK;
+				ctx[i].uc_link = &sched;
+				makecontext(&ctx[i], work_item_entry, 0);
+			}
+			/* rounds: every unfinished work-item runs to its next barrier (or to its end); the next round starts only when all
+			 * of them have -- nobody passes a barrier before everybody has reached it */
+			for (bool any = true; any;) {
+				any = false;
+				for (size_t i = 0; i < items; ++i) {
+					if (call[i].done) continue;
+					set_ids(gx, gy, i);
+					t_call = &call[i]; t_fiber = &ctx[i]; t_at_barrier = 0;
+					swapcontext(&sched, &ctx[i]);
+					any = any || !call[i].done;
 				}
-			t_barrier = nullptr;
-		});
-	for (auto& t : items) t.join();
-	pthread_barrier_destroy(&bar);
+			}
+		}
+	t_fiber = nullptr; t_sched = nullptr; t_call = nullptr;
 }
 /* In-place corrector: result depends on work-item order (quirk Q6).  Driven row-major, x fastest. */
 void ref_mch_2nd(const real* dt, real* state, const real* bed, const real* manning,

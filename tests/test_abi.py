@@ -113,6 +113,22 @@ def test_peer_transport_entry_points_reject_missing_domains_and_match_the_header
     assert [f[0] for f in hipims_mi.StripInfo._fields_][-2:] == ["peer_max", "peer_halo"]
 
 
+def test_bench_counts_gpus_without_the_hip_runtime(monkeypatch):
+    """the launcher must stay GPU-free; torch.cuda.device_count() may open /dev/kfd.  visible_gpus() reads the KFD
+    topology and the *_VISIBLE_DEVICES variables only (and never imports torch)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    had_torch = "torch" in sys.modules
+    n = bench.visible_gpus()
+    assert isinstance(n, int) and n >= 0 and (("torch" in sys.modules) == had_torch)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.visible_gpus() <= 1
+
+
 def test_bench_never_runs_a_smaller_job_than_asked_for():
     """`python bench.py --gpus 8` without a launcher's environment used to run N = 1 and print
     "n_gpus": 1.  It now starts the ranks itself -- and where the GPUs are not there it must refuse."""

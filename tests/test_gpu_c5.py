@@ -224,7 +224,7 @@ def test_cell_boundary_on_the_edge_ring_drives_the_timestep(q1):
     series = np.array([[0, 3.0, 12.0, -6.0], [5, 4.0, 25.0, -12.0], [10, 4.0, 25.0, -12.0], [15, 2.0, 5.0, 0.0],
                        [20, 2.0, 5.0, 0.0]])
     quirks = hp.QUIRKS_REFERENCE if q1 else hp.QUIRKS_REFERENCE & ~hp.QUIRK_CFL_READS_PRIMARY
-    ref = oracle.OracleSim(cols, rows, quirks=(quirks & 3) | oracle.Q6_MUSCL_SERIAL)
+    ref = oracle.OracleSim(cols, rows, quirks=oracle.quirks_from_engine(quirks, muscl_serial=True))
     dom = hp.Domain(cols, rows, quirks=quirks)
     for s in (ref, dom):
         s.upload(st, bed, man)
@@ -232,7 +232,7 @@ def test_cell_boundary_on_the_edge_ring_drives_the_timestep(q1):
     dom.set_target_time(1e9); ref.set_target(1e9)
     tr_ref, tr_gpu = ref.run(150), dom.run(150)
     # the ring cell really is what limits the timestep: without it the trace differs
-    plain = oracle.OracleSim(cols, rows, quirks=(quirks & 3) | oracle.Q6_MUSCL_SERIAL)
+    plain = oracle.OracleSim(cols, rows, quirks=oracle.quirks_from_engine(quirks, muscl_serial=True))
     plain.upload(st, bed, man); plain.set_target(1e9)
     assert np.abs(plain.run(150) - tr_ref).max() > 1e-3 * tr_ref.max()
     assert np.abs(tr_gpu - tr_ref).max() <= 1e-12 * tr_ref.max(), np.abs(tr_gpu - tr_ref).max()

@@ -39,7 +39,7 @@ def compare(dom, ref, precision="f64", check_t=True):
 
 
 def make_pair(cols, rows, st, bed, man, precision="f64", scheme=0, quirks=hp.QUIRKS_REFERENCE, dx=1.0, **kw):
-    oq = (quirks & 3) | (0 if scheme == hp.SCHEME_MUSCL_HANCOCK else oracle.Q6_MUSCL_SERIAL)
+    oq = oracle.quirks_from_engine(quirks, muscl_serial=scheme != hp.SCHEME_MUSCL_HANCOCK)
     ref = oracle.OracleSim(cols, rows, scheme=scheme, precision=precision, quirks=oq, dx=dx,
                            end_time=kw.get("t_end", 1e30))
     dom = hp.Domain(cols, rows, scheme=scheme, precision=precision, quirks=quirks, dx=dx, **kw)

@@ -218,23 +218,52 @@ def test_bench_multi_rank_branch_rehearsal():
     """bench.py's N > 1 branch end to end THROUGH ITS OWN LAUNCHER (`python bench.py --gpus 2`, no torchrun around it:
     it starts the two rank processes itself), default time-based pre-warm included (its pass count must be the same on
     both ranks), strip inputs, barrier, max-over-ranks timing, rank-0 JSON line; two processes share the GPU over the
-    rehearsal transport; the numbers are meaningless, the line must be well formed."""
+    rehearsal transport; the numbers are meaningless, the line must be well formed.  BASELINE.json's metric is quoted on
+    ONE grid at 1/2/4/8 GPUs (north_star: strong scaling), so the default N > 1 line carries BOTH legs: `value` = the grid cut
+    into N strips (`scaling: "strong"`, with the speed-up over the same grid as one domain measured in the same run), and
+    `weak` = N times the rows (the configs' ladder) with its own roofline."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
-                        "--cols", "512", "--rows", "1024", "--repeats", "1"], capture_output=True, text=True, timeout=900,
+                        "--cols", "512", "--rows", "512", "--repeats", "1"], capture_output=True, text=True, timeout=900,
                        env=dict(env, HIPIMS_MI_BACKEND="gloo"))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                     # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["value"] > 0
     assert "REHEARSAL" in d["config"]["parallelism"] and "cpu_baseline" not in d
-    assert d["config"]["successful_iterations"] == 35 and d["roofline"]["cells_per_launch"] == 512 * (512 + 1)
+    # the strong leg is the line's value: the metric's grid (here 512 x 512) cut into two strips
+    assert d["scaling"] == "strong" and "512x512" in d["config"]["workload"] and d["config"]["cells_per_gpu"] == 512 * 256
+    assert d["config"]["successful_iterations"] == 35 and d["roofline"]["cells_per_launch"] == 512 * (256 + 1)
     assert d["config"]["ghost_rows_verified_after_timed_batch"] is True     # each strip's ghost rows == their owners' rows, bit for bit
+    assert d["speedup_vs_1gpu_same_run"] > 0 and "512x512" in d["single_gpu_same_run"]["workload"]
+    assert abs(d["speedup_vs_1gpu_same_run"] - d["value"] / d["single_gpu_same_run"]["value"]) < 1e-9
+    # the weak leg: the ladder (N times the rows), same cells per GPU as the single domain
+    w = d["weak"]
+    assert w["scaling"] == "weak" and "512x1024" in w["workload"] and w["cells_per_gpu"] == 512 * 512 and w["value"] > 0
+    assert w["roofline"]["cells_per_launch"] == 512 * (512 + 1) and 0 < w["roofline"]["frac"] < 1
+    assert w["ghost_rows_verified_after_timed_batch"] is True
+    for rl in (d["roofline"], w["roofline"]):
+        assert {"frac", "frac_event_sampled", "event_pair_overhead_ms", "avg_launch_ms_raw", "frac_basis"} <= set(rl)
+
+
+def test_bench_single_leg_options():
+    """`--scaling weak` / `--scaling strong` run one leg only and say which."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--cols", "256", "--rows", "256", "--repeats", "1", "--scaling", "weak", "--prewarm-s", "0.05"],
+                       capture_output=True, text=True, timeout=900, env=dict(env, HIPIMS_MI_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "weak" and "256x512" in d["config"]["workload"] and "weak" not in d and "speedup_vs_1gpu_same_run" not in d
 
 
 def test_bench_line_names_the_collective_library_on_the_cxx_loop():

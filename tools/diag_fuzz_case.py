@@ -13,7 +13,7 @@ for batch in (1, 2, 5, 50):
     oq = c["quirks"] & ~(oracle.Q6_MUSCL_SERIAL if c["scheme"] == hp.SCHEME_MUSCL_HANCOCK else 0)
     ref = oracle.OracleSim(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=oq, friction=c["kw"]["friction"],
                            dynamic_dt=c["kw"]["dynamic_dt"], fixed_dt=c["fixed_dt"], dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001)
-    dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3, friction=c["kw"]["friction"],
+    dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=oracle.quirks_to_engine(c["quirks"]), friction=c["kw"]["friction"],
                     dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"], dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=hp.MATH_STRICT)
     for s in (ref, dom):
         s.upload(c["st"], c["bed"], c["man"]); m.attach(s, c["bdy"])

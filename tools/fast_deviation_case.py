@@ -14,7 +14,7 @@ for seed in map(int, sys.argv[1:]):
     print(f"seed {seed}: scheme {c['scheme']} {c['precision']} {c['cols']}x{c['rows']} dx {c['dx']} {c['kw']} fixed_dt {c['fixed_dt']} boundaries {[(b[0], b[1]) for b in c['bdy']]} target {c['target']:.3g} iterations {sum(c['cuts'])}")
     doms = []
     for mode in (hp.MATH_STRICT, hp.MATH_FAST):
-        dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3,
+        dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=fz.oracle.quirks_to_engine(c["quirks"]),
                         friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"],
                         dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=mode)
         dom.upload(c["st"], c["bed"], c["man"]); fz.attach(dom, c["bdy"]); dom.set_target_time(c["target"])

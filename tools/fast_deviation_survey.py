@@ -24,7 +24,7 @@ for seed in range(n):
     pick = (nudged[..., 0] - c["bed"] > 1e-3) & (nudged[..., 1] > -9000) & (prng.random(nudged.shape[:2]) < 0.1)
     nudged[..., 0][pick] = np.nextafter(nudged[..., 0][pick], np.inf).astype(nudged.dtype)
     for mode, start in ((hp.MATH_STRICT, c["st"]), (hp.MATH_FAST, c["st"]), (hp.MATH_STRICT, nudged)):
-        dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=c["quirks"] & 3,
+        dom = hp.Domain(c["cols"], c["rows"], dx=c["dx"], scheme=c["scheme"], precision=c["precision"], quirks=fz.oracle.quirks_to_engine(c["quirks"]),
                         friction=c["kw"]["friction"], dynamic_dt=c["kw"]["dynamic_dt"], dt_fixed=c["fixed_dt"],
                         dt_initial=c["fixed_dt"] if not c["kw"]["dynamic_dt"] else 0.001, math_mode=mode)
         dom.upload(start, c["bed"], c["man"]); fz.attach(dom, c["bdy"]); dom.set_target_time(c["target"])
