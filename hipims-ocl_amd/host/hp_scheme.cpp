@@ -1,9 +1,12 @@
-// hp_scheme.cpp -- see hp_scheme.hpp.  Behaviour follows src/Schemes/CSchemeGodunov.cpp of the reference; the
-// detached worker thread (runBatchThread, :1116-1139) is not reproduced: hp_step_batch is asynchronous on the
-// domain's HIP stream and the blocking read at the end of a batch is hp_read_scalars (clFinish + five reads there).
+// hp_scheme.cpp -- see hp_scheme.hpp.  Behaviour follows src/Schemes/CSchemeGodunov.cpp of the reference, its worker
+// thread included (runBatchThread / Threaded_runBatch, :1116-1139, :1147-1372): runSimulation returns at once with
+// bRunning set, the scheme's own thread queues the batch (hp_step_batch / hp_strip_step_batch), blocks in the read of the
+// key statistics (hp_read_scalars: clFinish + five reads there) and clears bRunning -- so one host thread can drive
+// several strips, as CModel's main loop drives several domains.
 #include "hp_scheme.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <utility>
 #include <cmath>
 #include <cstring>
@@ -118,6 +121,24 @@ int CSchemeMI::connectPeers(const void* tickets)
 	return active;
 }
 
+int CSchemeMI::prepareStripSet(const std::vector<CSchemeMI*>& strips, bool peerMax)
+{
+	const size_t n = strips.size();
+	std::vector<std::thread> th;
+	for (CSchemeMI* s : strips) th.emplace_back([s] { s->prepareAll(); });       // collective: the communicator
+	for (auto& t : th) t.join();
+	for (CSchemeMI* s : strips) if (!s->isReady()) return -1;
+	if (!peerMax || n < 2) return 0;
+	std::vector<char> tickets(n * HP_PEER_TICKET_BYTES, 0);
+	for (size_t r = 0; r < n; ++r) if (!strips[r]->getPeerTicket(&tickets[r * HP_PEER_TICKET_BYTES])) return -1;
+	std::vector<int> level(n, 0);
+	th.clear();
+	for (size_t r = 0; r < n; ++r) th.emplace_back([&, r] { level[r] = strips[r]->connectPeers(tickets.data()); });   // collective: test + agreement
+	for (auto& t : th) t.join();
+	for (CSchemeMI* s : strips) if (!s->isReady()) return -1;
+	return *std::min_element(level.begin(), level.end());
+}
+
 void CSchemeMI::prepareSimulation()
 {
 	if (!bReady) return;
@@ -128,7 +149,7 @@ void CSchemeMI::prepareSimulation()
 	check(hp_sync(hpDomain), "hp_sync");                              // blockUntilFinished (:1071)
 	bOverrideTimestep = false; bUseForcedTimeAdvance = true; bCellStatesSynced = true;
 	dBatchStartedTime = 0.0; ulCurrentCellsCalculated = 0; uiIterationsSinceSync = 0; dLastSyncTime = 0.0;
-	bRunning = false;
+	bRunning.store(false);
 }
 
 void CSchemeMI::setTargetTime(double t)
@@ -147,7 +168,7 @@ void CSchemeMI::forceTimestep(double dt)
 
 void CSchemeMI::runSimulation(double dTarget, double dRealTime)
 {
-	if (!bReady || bRunning) return;
+	if (!bReady || isRunning()) return;
 	int busy = 0;
 	if (hp_is_busy(hpDomain, &busy) != HP_OK || busy) return;         // :1377-1378
 	if (dTargetTime != dTarget) setTargetTime(dTarget);               // :1381-1382
@@ -173,9 +194,48 @@ void CSchemeMI::runSimulation(double dTarget, double dRealTime)
 		if (uiQueueAdditionSize < 1) uiQueueAdditionSize = 1;
 	}
 	dBatchStartedTime = dRealTime;
-	bRunning = true;
+	{
+		std::lock_guard<std::mutex> l(mtxWorker);
+		bRunning.store(true, std::memory_order_release);
+	}
+	runBatchThread();                                                 // :1452; returns at once
+}
 
-	// ---- Threaded_runBatch (:1147-1372), one pass ----
+// runBatchThread (:1116-1139): the worker is created on the first batch and kept ("because of the overhead associated with
+// creating a thread", :1149-1150); later calls only wake it
+void CSchemeMI::runBatchThread()
+{
+	if (!bThreadRunning) {
+		bThreadRunning = true;
+		thWorker = std::thread([this] { Threaded_runBatch(); });
+	}
+	cvWorker.notify_one();
+}
+
+void CSchemeMI::Threaded_runBatch()
+{
+	for (;;) {
+		{
+			std::unique_lock<std::mutex> l(mtxWorker);                // "Are we expected to run?" (:1153-1161), asleep instead of spinning
+			cvWorker.wait(l, [this] { return !bThreadRunning || bRunning.load(std::memory_order_acquire); });
+			if (!bThreadRunning) return;
+		}
+		runBatch();
+		bRunning.store(false, std::memory_order_release);             // "Wait until further work is scheduled" (:1366)
+		cvWorker.notify_all();                                        // (waitUntilIdle)
+	}
+}
+
+void CSchemeMI::waitUntilIdle()
+{
+	std::unique_lock<std::mutex> l(mtxWorker);
+	cvWorker.wait_for(l, std::chrono::milliseconds(1), [this] { return !bRunning.load(std::memory_order_acquire); });
+	while (bRunning.load(std::memory_order_acquire)) cvWorker.wait_for(l, std::chrono::milliseconds(1));
+}
+
+// ---- Threaded_runBatch (:1147-1372), one pass of its loop body; runs on the worker thread ----
+void CSchemeMI::runBatch()
+{
 	if (bUpdateTargetTime) {                                          // :1163-1209
 		bUpdateTargetTime = false;
 		check(hp_set_target_time(hpDomain, dTargetTime), "hp_set_target_time");
@@ -201,7 +261,6 @@ void CSchemeMI::runSimulation(double dTarget, double dRealTime)
 		bCellStatesSynced = false;
 	}
 	readKeyStatistics();                                              // :1309-1313 + blockUntilFinished + :1350
-	bRunning = false;
 }
 
 void CSchemeMI::readKeyStatistics()
@@ -247,7 +306,7 @@ void CSchemeMI::rollbackSimulation(double dTime, double dTarget)
 
 bool CSchemeMI::isSimulationFailure(double dExpected)
 {
-	if (bRunning) return false;
+	if (isRunning()) return false;
 	if (ucSyncMethod == syncMethod::kSyncForecast && uiBatchSuccessful >= uiRollbackLimit && dExpected - dCurrentTime > 1E-5) return true;
 	if (ucSyncMethod == syncMethod::kSyncTimestep && uiBatchSuccessful > uiRollbackLimit) return true;
 	if (dCurrentTime > dExpected + 1E-5) return true;
@@ -256,7 +315,7 @@ bool CSchemeMI::isSimulationFailure(double dExpected)
 
 bool CSchemeMI::isSimulationSyncReady(double dExpected)
 {
-	if (bRunning) return false;
+	if (isRunning()) return false;
 	if (ucSyncMethod != syncMethod::kSyncTimestep && dExpected - dCurrentTime > 1E-5) return false;
 	if (ucSyncMethod == syncMethod::kSyncTimestep && uiIterationsSinceSync < uiRollbackLimit - 1 &&
 	    dExpected - dCurrentTime > 1E-5 && dCurrentTime > 0.0) return false;
@@ -278,8 +337,19 @@ double CSchemeMI::proposeSyncPoint(double dTime)
 
 void CSchemeMI::cleanupSimulation()
 {
+	// "Kill the worker thread ... wait for the thread to terminate before returning" (:1458-1469): a batch in flight finishes first
+	if (thWorker.joinable()) {
+		waitUntilIdle();
+		{
+			std::lock_guard<std::mutex> l(mtxWorker);
+			bThreadRunning = false;
+		}
+		cvWorker.notify_all();
+		thWorker.join();
+	}
+	bThreadRunning = false;
 	if (hpDomain) { hp_domain_destroy(hpDomain); hpDomain = nullptr; }
-	bRunning = false; bReady = false; dBatchStartedTime = 0.0;
+	bRunning.store(false); bReady = false; dBatchStartedTime = 0.0;
 }
 
 } // namespace hipims_mi

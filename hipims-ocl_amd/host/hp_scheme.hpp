@@ -7,9 +7,13 @@
 // TinyXML): host arrays in the reference's layout stand in for CDomain (src/Domain/CDomain.cpp:143-191).
 #pragma once
 
+#include <atomic>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hipims_mi.h"
@@ -81,12 +85,27 @@ public:
 	// library inside an iteration), 1 = the maxima only, 0 = everything stays with the library.
 	bool   getPeerTicket(void* ticketOut);
 	int    connectPeers(const void* tickets);
+	// Several strips driven by ONE host thread of ONE process (the reference's several <domain deviceNumber=...> of one
+	// CDomainManager, CDomainManager.cpp:203-220): the collective parts of the set-up -- prepareAll's communicator
+	// (ncclCommInitRank blocks until every rank has joined) and connectPeers' connection test and agreement -- cannot be
+	// called strip after strip from one thread.  prepareStripSet runs them for all strips of this process at once (one
+	// short-lived thread per strip, as ncclCommInitAll does inside the collective library) and returns the transport level
+	// all strips agreed on (connectPeers' value; `peerMax` = false keeps everything on the collective library), or -1 on failure.
+	static int prepareStripSet(const std::vector<CSchemeMI*>& strips, bool peerMax = true);
 	// model::doError's place (main.cpp:631-652): every failure of the library is also handed to this sink
 	static void setLogSink(hp_log_sink_t sink, void* user) { hp_set_log_sink(sink, user); }
 
 	// ---- the CScheme virtuals CModel drives (CScheme.h:82-129) ----
+	// Threading contract of the reference (CSchemeGodunov.cpp:1116-1139, :1147-1372, :1374-1453): runSimulation
+	// sizes the batch, sets bRunning and returns AT ONCE; the scheme's own worker thread (runBatchThread, kept alive between
+	// batches) queues the batch, blocks until the device has finished and the key statistics are back, and clears bRunning.
+	// The caller -- CModel's single main thread, which schedules every idle domain in turn (CModel.cpp:906-955) -- polls
+	// isRunning(); everything else here (setTargetTime, saveCurrentState, rollbackSimulation, readDomainAll ...) is called
+	// only while the scheme is idle.  In strip mode that is what lets ONE host thread drive several strips: each strip's
+	// batch (handshake, hp_strip_step_batch, hp_read_scalars) blocks its own worker, never the caller.
 	bool   isReady() const                   { return bReady; }
-	bool   isRunning() const                 { return bRunning; }
+	bool   isRunning() const                 { return bRunning.load(std::memory_order_acquire); }
+	void   waitUntilIdle();                                      // a host without a polling loop: COCLDevice::blockUntilFinished + "until !bRunning"
 	void   prepareAll();                                         // CSchemeGodunov::prepareAll (:386-470)
 	void   prepareSimulation();                                  // :1053-1092
 	void   setTargetTime(double t);                              // :1741-1753
@@ -116,6 +135,9 @@ public:
 
 private:
 	bool check(int rc, const char* what);
+	void runBatchThread();                                       // :1116-1139
+	void Threaded_runBatch();                                    // :1147-1372
+	void runBatch();                                             // one pass of Threaded_runBatch's loop body
 
 	DomainArrays* pDomain;
 	hp_domain_t*  hpDomain = nullptr;
@@ -125,7 +147,12 @@ private:
 	std::string   sLastError;
 
 	// CScheme.cpp:46-55 / CSchemeGodunov.cpp:42-75 defaults
-	bool         bReady = false, bRunning = false;
+	bool         bReady = false;
+	std::atomic<bool> bRunning{false};                           // set by runSimulation (caller), cleared by the worker
+	std::thread  thWorker;                                       // the batch thread; bThreadRunning keeps it alive between batches
+	bool         bThreadRunning = false;
+	std::mutex   mtxWorker;
+	std::condition_variable cvWorker;                            // (the reference's worker spins on bRunning; this one sleeps)
 	bool         bAutomaticQueue = true;
 	unsigned int uiQueueAdditionSize = 1;
 	double       dCourantNumber = 0.5;

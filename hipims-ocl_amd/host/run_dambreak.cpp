@@ -53,7 +53,8 @@ int main(int argc, char** argv)
 	double target = freq;
 	while (scheme.getCurrentTime() < duration - 1e-9) {
 		const double real = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-		scheme.runSimulation(target, real);                       // runModelSchedule (:906-961)
+		scheme.runSimulation(target, real);                       // runModelSchedule (:906-961): returns at once, the batch runs on the scheme's worker
+		scheme.waitUntilIdle();                                   // (one domain, nothing else to schedule: block instead of polling isRunning())
 		if (!scheme.isReady()) { std::fprintf(stderr, "step failed: %s\n", scheme.lastError().c_str()); return 3; }
 		if (scheme.isSimulationSyncReady(target)) {               // runModelSync (:775-868) -> outputs, next target
 			scheme.saveCurrentState();

@@ -90,6 +90,7 @@ int main(int argc, char** argv)
 		double pass = 0.0;                                    // stands in for the wall clock: only "has time passed" matters to a strip
 		while (out < outputs) {
 			scheme.runSimulation(target, pass += 1.0);
+			scheme.waitUntilIdle();                                   // this driver has a host thread per strip (run_model_strips.cpp has ONE for all)
 			if (!scheme.isReady()) {                                  // the other ranks are inside a collective: leave as a process
 				std::fprintf(stderr, "rank %d step failed: %s\n", r, scheme.lastError().c_str());
 				std::_Exit(3);

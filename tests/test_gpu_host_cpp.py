@@ -130,6 +130,48 @@ def test_cpp_host_strip_mode_matches_the_single_domain(scheme_name, world, peer_
         assert abs(float(la[3]) - float(lb[4])) <= 1e-12 * abs(float(lb[4]))            # checksum of Z
 
 
+@pytest.mark.parametrize("scheme_name,world,peer_max,batch", [("godunov", 2, 2, 25), ("godunov", 3, 2, 25), ("muscl", 3, 2, 25), ("muscl", 2, 0, 25),
+                                                              ("godunov", 3, 1, 25), ("godunov", 3, 0, 25), ("godunov", 3, 2, 0)])
+def test_cpp_single_threaded_model_loop_drives_the_strips(scheme_name, world, peer_max, batch):
+    """the reference runs each domain's batch on the scheme's own worker (CSchemeGodunov.cpp:1116-1139) so that
+    CModel's ONE main thread can schedule every idle domain in turn and poll isRunning() (CModel.cpp:906-955, :1069-1108).
+    CSchemeMI now has that worker: host/run_model_strips.cpp is that management loop -- assess, sync / outputs, schedule every
+    idle strip, poll -- on a single thread over 2-3 strips of one grid, both transports (the strips' own stores and mailboxes;
+    the collective library's send / receive and all-reduce), fixed batches and the several-domains automatic queue.  A blocking
+    runSimulation would deadlock here (strip 0's batch waits for strip 1's, which the same thread has not scheduled yet).
+    Times, iteration counts, volume and level checksum equal the single domain's."""
+    exe = os.path.join(PKG, "lib", "run_model_strips")
+    fake = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(exe), "run_model_strips not built (make -C hipims-ocl_amd/csrc)"
+    if not os.path.exists(fake):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", fake,
+                               os.path.join(os.path.dirname(fake), "fake_rccl.cpp")])
+    cols, rows, duration, freq = 320, 161, 1.5, 0.5
+    run = subprocess.run([exe, fake, str(world), str(cols), str(rows), str(duration), str(freq), scheme_name, str(batch)],
+                         capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, HIPIMS_MI_PEER_MAX=str(min(peer_max, 1)), HP_PEER_DIRECT=str(int(peer_max == 2)), GPU_MAX_HW_QUEUES="16"))
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert ("maximum over the strips: peer-written mailboxes" in run.stderr) == bool(peer_max), run.stderr
+    assert ("ghost rows: written by the strips" in run.stderr) == (peer_max == 2), run.stderr
+    assert "no strip driven from a thread of its own" in run.stderr
+    a = [l.split() for l in run.stdout.strip().splitlines()]
+    if batch:
+        single = subprocess.run([EXE, str(cols), str(rows), str(duration), str(freq), scheme_name, str(batch)],
+                                capture_output=True, text=True, timeout=300)
+        assert single.returncode == 0, single.stderr
+        b = [[l.split()[0], l.split()[1], l.split()[3], l.split()[4]] for l in single.stdout.strip().splitlines()]
+    else:       # the several-domains queue formula has no single-domain twin: the thread-per-strip driver is the comparison
+        other = subprocess.run([os.path.join(PKG, "lib", "run_strips"), fake, str(world), str(cols), str(rows), str(duration), str(freq), scheme_name, "0"],
+                               capture_output=True, text=True, timeout=300, env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+        assert other.returncode == 0, other.stdout + other.stderr
+        b = [l.split() for l in other.stdout.strip().splitlines()]
+    assert len(a) == len(b) == 3
+    for la, lb in zip(a, b):
+        assert float(la[0]) == float(lb[0]) and int(la[1]) == int(lb[1])              # time, successful iterations
+        assert abs(float(la[2]) - float(lb[2])) <= 1e-11 * float(lb[2])                 # volume (summation order differs)
+        assert abs(float(la[3]) - float(lb[3])) <= 1e-12 * abs(float(lb[3]))            # checksum of Z
+
+
 def test_cpp_host_strip_mode_automatic_queue_is_rank_consistent():
     """The automatic batch size of a strip is the reference's several-domains formula (CSchemeGodunov.cpp:1428-1429: the
     iterations left to the target at the batch's mean timestep) -- simulated quantities only, so every rank queues the same
