@@ -1354,6 +1354,23 @@ int hp_step_batch(hp_domain_t* d, uint32_t n_iterations)
 	return HP_OK;
 }
 
+// The mailboxes' sticky error word (a strip that was not heard from within HP_PEER_TIMEOUT_MS: the tail / advance kernel then
+// went on with a partial maximum and the ghost rows were not handed over).  Read wherever the host blocks on this domain's
+// stream anyway -- hp_read_scalars, hp_sync (what a download or a checkpoint is followed by), the strips' batch-start
+// handshake -- so that no host call sequence gets rasters of a broken exchange with HP_OK.  Blocks.
+static int peer_error_check(hp_domain* d)
+{
+	if (!d->peer_agreed || !d->peer_mine) return HP_OK;
+	uint64_t* peer_error = (uint64_t*)((char*)d->host_scalars + 480);
+	*peer_error = 0;
+	HIP_TRY(hipMemcpyAsync(peer_error, d->peer_mine + PEER_WORD_ERROR, 8, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	if (*peer_error)
+		return fail(HP_ERR_HIP, "the exchange between the strips is incomplete: rank " + std::to_string((long)*peer_error - 1) +
+		                        " was not heard from within the time limit (HP_PEER_TIMEOUT_MS); states and ghost rows after that point are not valid");
+	return HP_OK;
+}
+
 int hp_read_scalars(hp_domain_t* d, hp_scalars_t* out)
 {
 	int rc = check_domain(d);
@@ -1387,7 +1404,7 @@ int hp_sync(hp_domain_t* d)
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	HIP_TRY(hipStreamSynchronize(d->stream));
-	return HP_OK;
+	return peer_error_check(d);                                          // (a download / checkpoint of a broken exchange must not look fine)
 }
 
 int hp_is_busy(hp_domain_t* d, int* busy)
@@ -1538,7 +1555,10 @@ int strip_handshake(hp_domain* d)
 	d->strip_any_bdy = !d->bdy.empty() && d->desc.scheme != HP_SCHEME_MUSCL_HANCOCK;
 	d->strip_any_full = d->need_full_reduce;
 	if (d->comm_world <= 1) return HP_OK;
-	const double mine[8] = {d->strip_any_bdy ? 1.0 : 0.0, d->strip_any_full ? 1.0 : 0.0, (double)d->use_alt, -(double)d->use_alt,
+	// (element 0 also carries the mailboxes' sticky error word of THIS rank as a value above 1: the all-reduce then tells every
+	// rank that the exchange broke somewhere, and all of them fail together instead of one leaving the others in a collective)
+	const bool broken = peer_error_check(d) != HP_OK;
+	const double mine[8] = {broken ? 3.0 : (d->strip_any_bdy ? 1.0 : 0.0), d->strip_any_full ? 1.0 : 0.0, (double)d->use_alt, -(double)d->use_alt,
 	                        (double)d->ghost_valid, -(double)d->ghost_valid, (double)d->ghost_rows, -(double)d->ghost_rows};
 	double all[8];
 	char* slot = (char*)d->cfl_slot + (size_t)SLOT_HANDSHAKE * d->esize;
@@ -1555,6 +1575,9 @@ int strip_handshake(hp_domain* d)
 	HIP_TRY(hipStreamSynchronize(d->stream));
 	if (d->desc.precision == 8) std::memcpy(all, pinned + 128, sizeof all);
 	else { const float* f = (const float*)(pinned + 128); for (int i = 0; i < 8; ++i) all[i] = f[i]; }
+	if (all[0] > 2.0)
+		return fail(HP_ERR_HIP, broken ? std::string(hp_last_error())
+		                               : std::string("the exchange between the strips broke on another rank (a strip was not heard from in time)"));
 	if (all[2] != -all[3]) return fail(HP_ERR_STATE, "the strips disagree on the ping-pong phase (different iteration counts?)");
 	if (all[4] != -all[5] || all[6] != -all[7]) return fail(HP_ERR_STATE, "the strips disagree on their ghost rows");
 	d->strip_any_bdy = all[0] > 0.0;
@@ -1758,19 +1781,24 @@ int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int ra
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	if (active) *active = 0;
+	// This call is COLLECTIVE over the communicator's ranks: whatever is wrong on this rank -- arguments included -- it must
+	// still reach the agreement below, or the other ranks wait in that all-reduce for ever.  A local fault
+	// therefore only marks this rank's verdict as "no"; the error code is returned after the agreement.
+	std::string fault;
 	if (!tickets || count < 1 || count > PEER_MAX_RANKS || rank < 0 || rank >= count)
-		return fail(HP_ERR_INVALID, "bad mailbox arguments (1.." + std::to_string(PEER_MAX_RANKS) + " ranks)");
-	if (!d->peer_mine) return fail(HP_ERR_STATE, "hp_strip_peer_connect without hp_strip_peer_ticket");
-	if (d->comm && (count != d->comm_world || rank != d->comm_rank))
-		return fail(HP_ERR_INVALID, "mailbox ranks do not match the communicator's");
+		fault = "bad mailbox arguments (1.." + std::to_string(PEER_MAX_RANKS) + " ranks)";
+	else if (!d->peer_mine) fault = "hp_strip_peer_connect without hp_strip_peer_ticket";
+	else if (d->comm && (count != d->comm_world || rank != d->comm_rank)) fault = "mailbox ranks do not match the communicator's";
 	const PeerTicket* t = (const PeerTicket*)tickets;
-	if (t[rank].magic != PEER_MAGIC || t[rank].address != (uint64_t)(uintptr_t)d->peer_mine || t[rank].process != process_token())
-		return fail(HP_ERR_INVALID, "tickets[rank] is not this domain's ticket");
+	if (fault.empty() && (t[rank].magic != PEER_MAGIC || t[rank].address != (uint64_t)(uintptr_t)d->peer_mine || t[rank].process != process_token()))
+		fault = "tickets[rank] is not this domain's ticket";
+	if (!fault.empty() && !d->comm) return fail(HP_ERR_INVALID, fault);   // nobody to keep waiting
+	if (!fault.empty()) count = 0;                                       // nothing is mapped below
 	// map every peer's mailbox; a failure here is not an error of the call: the connection test below fails on every
 	// rank alike (the others never hear from this one) and the run stays on the collective
-	std::vector<unsigned long long*> table((size_t)count, nullptr);
-	bool mapped = true;
-	std::string why;
+	std::vector<unsigned long long*> table((size_t)(count > 0 ? count : 1), nullptr);
+	bool mapped = fault.empty();
+	std::string why = fault;
 	for (int r = 0; r < count && mapped; ++r) {
 		if (t[r].magic != PEER_MAGIC) { mapped = false; why = "ticket " + std::to_string(r) + " is not a ticket"; break; }
 		if (t[r].process == process_token()) {                           // same address space (ranks as threads, or one process driving several GPUs)
@@ -1787,7 +1815,7 @@ int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int ra
 			else { d->peer_mapped.push_back(m); table[(size_t)r] = (unsigned long long*)m; }
 		}
 	}
-	d->peer_world = count; d->peer_rank = rank; d->peer_rounds = 0;
+	d->peer_world = count > 0 ? count : 1; d->peer_rank = fault.empty() ? rank : 0; d->peer_rounds = 0;
 	// the strip neighbours' state buffers, for the ghost rows (PeerPush).  Optional on top of the mailboxes: when any rank
 	// cannot have it the rows keep travelling through the collective library's send / receive
 	const bool direct_wanted = !(std::getenv("HP_PEER_DIRECT") && std::atoi(std::getenv("HP_PEER_DIRECT")) == 0);
@@ -1869,6 +1897,7 @@ int hp_strip_peer_connect(hp_domain_t* d, const void* tickets, int count, int ra
 		if (active) *active = d->peer_agreed ? (d->peer_direct ? 2 : 1) : 0;
 		if (!d->peer_agreed) peer_release(d);
 		else if (!d->peer_direct) for (auto& side : d->peer_state) side[0] = side[1] = nullptr;
+		if (!fault.empty()) return fail(HP_ERR_INVALID, fault);            // (every rank has left the agreement by now)
 	} else {
 		// no communicator: nothing to agree through (diagnostic use, hp_strip_peer_round); the strip loop is not touched
 		if (active) *active = error ? 0 : 1;

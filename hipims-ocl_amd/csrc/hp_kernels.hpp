@@ -286,13 +286,21 @@ __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const
 	// a tile that stored rows into a neighbour reports only once those stores have been acknowledged (its own state's stores
 	// need no such wait: nobody reads them before the next launch); all the other tiles report at once
 	const bool sends = (y0 < tail.edge_rows[1] && y1 > tail.edge_rows[0]) || (y0 < tail.edge_rows[3] && y1 > tail.edge_rows[2]);   // wave-uniform
+	// Ordering of the hand-over, in the memory model's own terms (it had rested on the write-through stores and a
+	// hand-written wait alone): the edge tiles' peer stores -> system-scope RELEASE of the block's done word -> the tail
+	// block's ACQUIRE of that word -> its system-scope release store into the neighbours' mailboxes (peer_reduce_max).  Only
+	// the few tiles that store rows into a neighbour pay for the stronger store; all the others keep the relaxed one.
 	if (sends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	if (lane == 0) part[wave] = m;
 	__syncthreads();
+	bool block_sends = false;
 	if (threadIdx.x == 0) {
+		// (the tile rows of the block's four waves are the same: `sends` of wave 0 is the block's)
+		block_sends = sends;
 		T b = part[0];
 		for (int w = 1; w < 4; ++w) if (part[w] > b) b = part[w];
-		__hip_atomic_store(tail.done + blockIdx.x, peer_bits(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (block_sends) __hip_atomic_store(tail.done + blockIdx.x, peer_bits(b), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		else             __hip_atomic_store(tail.done + blockIdx.x, peer_bits(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
@@ -312,6 +320,9 @@ __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail
 		peer_value(w, v);
 		if (v > m) m = v;
 	}
+	// every done word has been seen: acquire what their writers released (the edge tiles' rows in the neighbours' memory)
+	// before this block publishes into the neighbours' mailboxes
+	if (tail.peer_rows[0] || tail.peer_rows[1]) __atomic_thread_fence(__ATOMIC_ACQUIRE);
 	m = wave_max(m);
 	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
 	__syncthreads();

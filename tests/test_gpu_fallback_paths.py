@@ -1,0 +1,39 @@
+"""The engine's fused paths each keep a classic twin behind a switch; these legs keep the twins alive:
+HP_LAUNCH_TAIL=0 -- the flux launch without its own tail block: atomic maxima + a separate advance launch (hp_kernels.hpp
+launch_tail); HP_FUSE_BDY=0 -- rain / loss as the stand-alone boundary pass instead of the flux kernel's store
+epilogue (K5).  (HP_PEER_DIRECT=0, ghost rows through the collective library's send / receive, is the peer_max = 1 leg of
+tests/test_gpu_strips.py::test_cxx_strip_loop_with_several_ranks.)  Each leg: all three schemes, fp64 and fp32, uniform and
+coarse gridded rain, a sync point inside the run, ragged batches -- STRICT, bit for bit against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(os.path.dirname(__file__), "fallback_worker.py")
+
+
+@pytest.mark.parametrize("env", [{}, {"HP_LAUNCH_TAIL": "0"}, {"HP_FUSE_BDY": "0"}, {"HP_LAUNCH_TAIL": "0", "HP_FUSE_BDY": "0"}],
+                         ids=["default", "no-tail-block", "stand-alone-rain", "both-off"])
+def test_switched_off_variants_equal_the_oracle(env):
+    r = subprocess.run([sys.executable, WORKER], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fallback paths bit-identical" in r.stdout
+    # the boundary switch really switched: the Godunov domain reports whether its area boundaries ride in the flux kernel
+    assert ("fused=1" in r.stdout) == ("HP_FUSE_BDY" not in env) and ("fused=0" in r.stdout) == ("HP_FUSE_BDY" in env)
+
+
+@pytest.mark.parametrize("peer_max", [2, 0])
+def test_strips_without_the_tail_block(peer_max):
+    """Row strips with HP_LAUNCH_TAIL=0: the advance launch carries the mailbox round (and the ghost-row push) again."""
+    lib = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", lib,
+                               os.path.join(os.path.dirname(lib), "fake_rccl.cpp")])
+    import hipims_mi as hp
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "strip_threads_worker.py"), "3",
+                          str(hp.SCHEME_GODUNOV), "f64", "1", "1", "1", "-2", str(peer_max)],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, HP_LAUNCH_TAIL="0"))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "bit-identical True" in res.stdout

@@ -515,6 +515,42 @@ def test_strict_bit_identity_at_scale(scheme):
     dom.close()
 
 
+@pytest.mark.parametrize("workload", ["s-rough", "s-dam-dry"])
+@pytest.mark.parametrize("scheme", [hp.SCHEME_GODUNOV, hp.SCHEME_MUSCL_HANCOCK])
+def test_fast_and_strict_against_the_oracle_at_scale_with_friction(scheme, workload):
+    """VERDICT r03 (weak #9): FAST has wave-uniform short cuts of its own (hp_math.hpp: face_solve's all-wet / subcritical
+    paths, the straight-line friction) that STRICT never executes, and was only ever compared with the oracle on grids of a
+    few thousand cells (at 4096^2 against the cross-check kernel, which shares its arithmetic).  Here: 1024 x 1024, friction
+    ON, 250 iterations, S-ROUGH (every tile on the general path) and S-DAM-DRY (a wet/dry front through still water and dry
+    land: every wave-uniform short cut and its fall-back side by side) -- ONE oracle run, STRICT bit for bit, FAST to
+    north_star's tolerance: depth RMSE < 1e-9 m, max < 1e-7 m, elapsed time to 1e-12 relative."""
+    cols = rows = 1024
+    if workload == "s-rough":
+        st, bed, man = syn.s_rough(cols, rows, manning=None)
+    else:
+        st, bed, man = syn.s_dam(cols, rows, wet_right=False)
+    quirks = oracle.QUIRKS_REFERENCE & ~(oracle.Q6_MUSCL_SERIAL if scheme == hp.SCHEME_MUSCL_HANCOCK else 0)
+    ref = oracle.OracleSim(cols, rows, scheme=scheme, quirks=quirks, threads=min(16, os.cpu_count() or 1))
+    ref.upload(st, bed, man); ref.set_target(1e9)
+    ref.run(250)
+    want, sr = ref.download(), ref.scalars()
+    for mode in (hp.MATH_STRICT, hp.MATH_FAST):
+        dom = hp.Domain(cols, rows, scheme=scheme, math_mode=mode)
+        dom.upload(st, bed, man); dom.set_target_time(1e9)
+        dom.step_batch(250)
+        got, sc = dom.download(), dom.read_scalars()
+        dom.close()
+        if mode == hp.MATH_STRICT:
+            assert np.array_equal(got, want) and sc["time"] == sr["t"] and sc["timestep"] == sr["dt"]
+            continue
+        dg, dr = np.maximum(0, got[..., 0] - bed), np.maximum(0, want[..., 0] - bed)
+        rmse, mx = float(np.sqrt(np.mean((dg - dr) ** 2))), float(np.abs(dg - dr).max())
+        record("fast_at_scale_1024", scheme=int(scheme), workload=workload, rmse=rmse, max=mx,
+               time_rel=abs(sc["time"] - sr["t"]) / sr["t"])
+        assert rmse < 1e-9 and mx < 1e-7, (rmse, mx)
+        assert abs(sc["time"] - sr["t"]) <= 1e-12 * sr["t"]
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("scheme,name,quirks", [
     (hp.SCHEME_GODUNOV, "god", hp.QUIRKS_REFERENCE), (hp.SCHEME_MUSCL_HANCOCK, "mch", hp.QUIRKS_REFERENCE),
