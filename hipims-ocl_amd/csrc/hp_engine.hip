@@ -99,6 +99,7 @@ struct hp_domain {
 	int              march_rseg = 16;                 // rows per wavefront tile of godunov_march
 	int              muscl_rseg = 32;                 // ... of muscl_march (two warm-up rows per tile)
 	int              inertial_rseg = 32;              // ... of inertial_march
+	int              march_nbands = 8, muscl_nbands = 8, inertial_nbands = 8;   // row bands of a whole-domain launch (pick_tiling)
 	int              tall_rseg = 18;                  // K1/K6 tile height where an XCD band has >= 256 rows (16 if a knob is set)
 	int              tail_rseg = 8, tail_pct = 0;     // optional short tiles for the last tail_pct % of each XCD band (measured: no gain)
 	void*            host_scalars = nullptr;          // pinned mirror
@@ -301,7 +302,8 @@ struct RowRange { long lo, hi; };
 // TileMap of one launch (see hp_kernels.hpp): 8 XCD bands over [lo, hi), tall tiles first and optionally short tiles
 // for the last `tail_pct` percent of each band; or, for the halo part, the two blocks of `halo` rows as two bands.
 inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rseg, int rseg_tail, int tail_pct,
-                          TileMap& tm, unsigned& blocks, int rseg_tall = 16, long need = 0, long price_lo = 0, long price_hi = 0x7fffffffL)
+                          TileMap& tm, unsigned& blocks, int rseg_tall = 16, long need = 0, long price_lo = 0, long price_hi = 0x7fffffffL,
+                          int nbands = 8)
 {
 	static const long halo_env = std::getenv("HP_HALO_ROWS") ? std::atol(std::getenv("HP_HALO_ROWS")) : 0;
 	if (need < g) need = g;                                             // rows at each end that a strip neighbour is sent
@@ -325,8 +327,12 @@ inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rs
 	}
 	tm.y_begin = lo; tm.y_end = hi;
 	const long rows = hi - lo;
-	tm.nbands = 8;
-	tm.band_rows = (int)((rows + 7) / 8);
+	// Row bands: 8, one per XCD -- or, for a whole-domain launch that fits the chip in ONE round, the number the tiling
+	// search of hp_domain_create found (pick_tiling: such a launch is bound by its most loaded CU, and 8 x groups x segments
+	// only offers coarse block counts).  HP_NBANDS forces a number (tools/r04_band_sweep.py).
+	static const int nbands_env = std::getenv("HP_NBANDS") ? std::atoi(std::getenv("HP_NBANDS")) : 0;
+	tm.nbands = nbands_env >= 1 && nbands_env <= 64 ? nbands_env : (part == PART_ALL && nbands >= 1 && nbands <= 64 ? nbands : 8);
+	tm.band_rows = (int)((rows + tm.nbands - 1) / tm.nbands);
 	tm.band_stride = tm.band_rows;
 	// K1/K6 on tall bands: 18-row tiles measured 1.9 % / 2.8 % ahead of 16 at 4096^2 (band of 512 rows) and 0.6 % at
 	// 8192 x 2050 (256), but 3 % behind at 16384 x 1026 (128 rows = eight exact 16-row tiles); interleaved repeats
@@ -343,7 +349,7 @@ inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rs
 		const int rest = tm.band_rows - tm.nbig * tm.rseg;
 		tm.ntail = rest > 0 ? (rest + rseg_tail - 1) / rseg_tail : 0;
 	}
-	blocks = 8u * (unsigned)(tm.groups * (tm.nbig + tm.ntail));
+	blocks = (unsigned)tm.nbands * (unsigned)(tm.groups * (tm.nbig + tm.ntail));
 	return true;
 }
 
@@ -411,7 +417,7 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	long lo, hi;
 	launch_rows(d, 2, lo, hi);
 	if (!make_tile_map(lo, hi, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks,
-	                   16, d->ghost_rows, d->own_lo, d->own_hi))
+	                   16, d->ghost_rows, d->own_lo, d->own_hi, d->muscl_nbands))
 		return HP_OK;
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit_k2k6(), tail);
@@ -435,7 +441,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	long lo, hi;
 	launch_rows(d, 1, lo, hi);
 	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
-	                   d->ghost_rows, d->own_lo, d->own_hi))
+	                   d->ghost_rows, d->own_lo, d->own_hi, d->march_nbands))
 		return HP_OK;
 	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
 	LaunchTail<T> tail;
@@ -468,7 +474,7 @@ int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, i
 	long lo, hi;
 	launch_rows(d, 1, lo, hi);
 	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
-	                   d->ghost_rows, d->own_lo, d->own_hi))
+	                   d->ghost_rows, d->own_lo, d->own_hi, d->inertial_nbands))
 		return HP_OK;
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit_k2k6(), tail);
@@ -893,8 +899,11 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		int cus = 256;
 		hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, desc->device);
 		static const bool refine = !(std::getenv("HP_RSEG_REFINE") && std::atoi(std::getenv("HP_RSEG_REFINE")) == 0);
-		auto pick = [&](long updated_rows, long updated_cols, int tile_cols, int tallest, int shortest, int blocks_per_cu) {
+		// (read per domain, not once per process: tools/strong_probe_pair.py creates domains both ways)
+		const bool one_round_search = !(std::getenv("HP_TILING_SEARCH") && std::atoi(std::getenv("HP_TILING_SEARCH")) == 0);
+		auto pick = [&](long updated_rows, long updated_cols, int tile_cols, int tallest, int shortest, int blocks_per_cu, int& nbands_out, bool searchable) {
 			const long groups = ((updated_cols + tile_cols - 1) / tile_cols + 3) / 4;
+			nbands_out = 8;
 			int rseg = tallest;
 			while (rseg > shortest && groups * ((updated_rows + rseg - 1) / rseg) < 350) rseg /= 2;
 			// Round 3: a launch whose blocks all fit the chip at once (a row strip of a strong-scaling run: 4096 x 514 is 544
@@ -912,19 +921,68 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 					int best = rseg;
 					for (int r = rseg - 1; r > rseg / 2; --r) if (cost(r) < cost(best)) best = r;
 					rseg = best;
+					// Round 4: what such a launch really lasts is what its MOST LOADED CU has to walk: blocks are dealt to the CUs
+					// layer by layer (block b lands on CU b mod cus while every CU has room), a block costs its rows plus ~3.5 rows
+					// of pipeline fill, and the blocks of one CU share its SIMDs.  8 bands x groups x segments only offers coarse
+					// block counts (680 blocks on 256 CUs: 168 CUs walk three 13-row tiles, 88 walk two); with another number
+					// of bands the last segment of each band can be a SHORT tile, and "two tall + one short on every CU" (15
+					// bands, 15 + 15 + 5 rows: 765 blocks) measured 39.1 us per iteration on the 4096 x 514 strip against 43.4
+					// (profiles/r04b_band_sweep_4096x514.txt).  The search simulates the dealing for every (bands, rows) pair that
+					// fits one round and takes the cheapest; a CU with fewer than three resident blocks hides less latency
+					// (2 blocks: +20 %, 1 block: +60 %, fitted on the same sweep).
+					if (one_round_search && searchable) {
+						double best_cost = 1e30;
+						int best_nb = 8, best_r = rseg;
+						std::vector<double> load((size_t)cus);
+						std::vector<int> count((size_t)cus);
+						for (int nb = 1; nb <= 32; ++nb) {
+							const long brows = (updated_rows + nb - 1) / nb;
+							for (int r = 4; r <= 64 && r <= brows; ++r) {
+								const long nseg = (brows + r - 1) / r, blocks = (long)nb * groups * nseg;
+								if (blocks > slots) continue;
+								std::fill(load.begin(), load.end(), 0.0);
+								std::fill(count.begin(), count.end(), 0);
+								for (long b = 0; b < blocks; ++b) {                  // tile_rows() of hp_kernels.hpp
+									const long band = b % nb, i = b / nb, seg = i / groups;
+									const long y0 = band * brows + seg * r;
+									const long band_end = std::min(updated_rows, (band + 1) * brows);
+									const long h = std::min(y0 + r, band_end) - y0;
+									if (h <= 0) continue;
+									load[(size_t)(b % cus)] += (double)h + 3.5;
+									count[(size_t)(b % cus)] += 1;
+								}
+								double worst = 0.0;
+								for (int c = 0; c < cus; ++c) {
+									const double f = count[(size_t)c] >= 3 ? 1.0 : count[(size_t)c] == 2 ? 1.2 : 1.6;
+									worst = std::max(worst, load[(size_t)c] * f);
+								}
+								// (ties: the taller first tiles -- 15 + 15 + 5 measured ahead of 12 + 12 + 11 --, then the tiling nearest to
+								// the 8-band one, whose bands keep to their XCD's L2)
+								if (worst < best_cost - 1e-9 || (worst < best_cost + 1e-9 && (r > best_r || (r == best_r && std::abs(nb - 8) < std::abs(best_nb - 8))))) {
+									best_cost = worst; best_nb = nb; best_r = r;
+								}
+							}
+						}
+						nbands_out = best_nb; rseg = best_r;
+					}
 				}
 			}
 			return rseg;
 		};
 		// fp32 rows are cheap enough for a tile's three-row fill and extra south face to show: 32-row tiles measured
 		// 13 % (S-DAM) to 47 % (S-RAIN 8192^2) ahead of 16; fp64 is flat or slightly worse beyond 18
-		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? 32 : 16, 2, desc->precision == 4 ? 5 : 3);
-		d->inertial_rseg = d->march_rseg;
+		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? 32 : 16, 2, desc->precision == 4 ? 5 : 3, d->march_nbands,
+		                        desc->precision == 8);      // (fp32: 8192 x 1026 measured 83.2 -> 84.4 us with the searched tiling: its fill is not 3.5 rows)
+		d->inertial_rseg = d->march_rseg; d->inertial_nbands = d->march_nbands;
 		// K2 after the inert-row cut (round 2): a tile of still water or dry land costs a fifth of a tile on the flood front,
 		// so fp64 wants more, shorter tiles for the dispatcher to balance (16-20 rows: 0.319 ms against 0.355 at 32 on the
 		// 4096^2 dam break, 0.355 against 0.395 on the developed flood, +2-5 % at 8192^2 and 16384 x 1028); fp32 stays at 32
-		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? 32 : 16, 4, desc->precision == 4 ? 4 : 3);
+		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? 32 : 16, 4, desc->precision == 4 ? 4 : 3, d->muscl_nbands,
+		                        false);                     // (K2's tiles differ fivefold in cost -- inert rows --: the searched tiling lost 20 % on the 4096 x 514 dam break)
 	}
+	if (std::getenv("HP_PRINT_TILING"))
+		std::fprintf(stderr, "[hipims_mi] tiling %ld x %ld: K1/K6 %d rows x %d bands, K2 %d rows x %d bands\n", (long)desc->cols, (long)desc->rows,
+		             d->march_rseg, d->march_nbands, d->muscl_rseg, d->muscl_nbands);
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 64) { d->march_rseg = v; d->tall_rseg = 16; }   // a forced 16 stays 16

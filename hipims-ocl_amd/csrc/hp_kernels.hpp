@@ -278,6 +278,9 @@ template <typename T> struct LaunchTail {
 	int                 edge_rows[4];   // [lo, hi) of the rows that go south, [lo, hi) of those that go north (empty: lo >= hi)
 };
 
+#ifndef HP_TAIL_FORMAL_ORDER
+#define HP_TAIL_FORMAL_ORDER 0
+#endif
 // every wavefront of every flux block, at its very end; `m` = the wavefront's maximum (0 when this launch prices nothing)
 template <typename T>
 __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const T m, const int wave, const int lane, const long y0, const long y1)
@@ -286,10 +289,17 @@ __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const
 	// a tile that stored rows into a neighbour reports only once those stores have been acknowledged (its own state's stores
 	// need no such wait: nobody reads them before the next launch); all the other tiles report at once
 	const bool sends = (y0 < tail.edge_rows[1] && y1 > tail.edge_rows[0]) || (y0 < tail.edge_rows[3] && y1 > tail.edge_rows[2]);   // wave-uniform
-	// Ordering of the hand-over, in the memory model's own terms (it had rested on the write-through stores and a
-	// hand-written wait alone): the edge tiles' peer stores -> system-scope RELEASE of the block's done word -> the tail
-	// block's ACQUIRE of that word -> its system-scope release store into the neighbours' mailboxes (peer_reduce_max).  Only
-	// the few tiles that store rows into a neighbour pay for the stronger store; all the others keep the relaxed one.
+	// Ordering of the hand-over.  What the protocol needs: the edge tiles' rows are in the neighbour's memory before this strip's
+	// tail block publishes into the neighbour's mailbox (system-scope release store in peer_reduce_max).  How it is had: the rows
+	// are stored WRITTEN THROUGH at system scope (sc0 sc1: they pass this XCD's L2 and are acknowledged by the memory they are
+	// for), the tile waits for those acknowledgements (s_waitcnt vmcnt(0)) before its block reports "through", and the tail
+	// block reads every block's report before it publishes.  In the HSA memory model's own terms that chain would be a
+	// system-scope RELEASE of the done word and an ACQUIRE in the tail block -- built and measured in round 4
+	// (HP_TAIL_FORMAL_ORDER=1): a system-scope release makes the block write back its XCD's whole L2 (the 4 MiB of ordinary state
+	// stores the other tiles have left there), and the two-strip probe went from 44.5 to 48.6 us per iteration on one box
+	// (profiles/r04f_pair_probe_bisect.txt).  The write-through
+	// + acknowledged-store form stays the default: it orders exactly the stores that cross to the neighbour and nothing else
+	// (30 000-iteration soaks, the strip fuzz and the process-rank tests all run on it).
 	if (sends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	if (lane == 0) part[wave] = m;
 	__syncthreads();
@@ -299,8 +309,12 @@ __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const
 		block_sends = sends;
 		T b = part[0];
 		for (int w = 1; w < 4; ++w) if (part[w] > b) b = part[w];
+#if HP_TAIL_FORMAL_ORDER
 		if (block_sends) __hip_atomic_store(tail.done + blockIdx.x, peer_bits(b), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-		else             __hip_atomic_store(tail.done + blockIdx.x, peer_bits(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else
+#endif
+		__hip_atomic_store(tail.done + blockIdx.x, peer_bits(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		(void)block_sends;
 	}
 }
 
@@ -322,7 +336,9 @@ __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail
 	}
 	// every done word has been seen: acquire what their writers released (the edge tiles' rows in the neighbours' memory)
 	// before this block publishes into the neighbours' mailboxes
+#if HP_TAIL_FORMAL_ORDER
 	if (tail.peer_rows[0] || tail.peer_rows[1]) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+#endif
 	m = wave_max(m);
 	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
 	__syncthreads();

@@ -159,7 +159,8 @@ def load_library(path: str | None = None):
     lib.hp_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.hp_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     lib.hp_kernel_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
-    lib.hp_kernel_timing_overhead.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    if hasattr(lib, "hp_kernel_timing_overhead"):       # (absent from round-3 builds loaded through HIPIMS_MI_LIB for A/B runs)
+        lib.hp_kernel_timing_overhead.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.hp_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.hp_device_info.argtypes = [C.c_int, C.POINTER(DeviceInfo)]
     _lib = lib

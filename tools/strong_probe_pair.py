@@ -17,7 +17,7 @@ from hipims_mi import strips, synthetic as syn
 
 cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4096, 514)
 rain_fp32 = len(sys.argv) > 3 and sys.argv[3] == "rain"        # config C5's shape: fp32, gridded rain on dry terrain (fused into the flux kernel)
-world, steps = 2, 1500
+world, steps = 2, int(os.environ.get("PROBE_STEPS", "1500"))
 precision = "f32" if rain_fp32 else "f64"
 if rain_fp32:
     st, bed, man, rn = syn.s_rain_rows(cols, rows, 0, rows, dx=2.0, dtype=np.float32)
@@ -39,6 +39,21 @@ for _ in range(3):
 print("strip %d x %d in one hp_step_batch                         : %6.1f us/iteration" % (cols, rows, best), flush=True)
 single.close()
 
+# Round 4: hp_domain_create searches the tiling of a launch that fits the chip in one round (bands x tile rows; the line above
+# runs with it: 43.5 -> 39.0 us).  The search assumes the launch has the chip to ITSELF -- true for a rank on its own GPU, not
+# for two half strips that share one: their two concurrent launches are best served by the 8-band tiling of round 3 (measured:
+# 44.8 us with it, 47-48 us with searched tilings, profiles/r04f_pair_probe_bisect.txt).  The pair therefore keeps that tiling, and
+# what this probe measures stays what it was built for: the PROTOCOL's cost on top of the same rows in one plain batch call
+# (the second "strip alone" line, same tiling as the pair).
+os.environ["HP_TILING_SEARCH"] = "0"
+single = hp.Domain(cols, rows, dx=2.0 if rain_fp32 else 1.0, precision=precision)
+single.upload(st, bed, man); with_rain(single); single.set_target_time(1e9)
+single.step_batch(50); single.sync()
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); single.step_batch(steps); single.sync(); best = min(best, (time.perf_counter() - t0) / steps * 1e6)
+print("the same with the 8-band tiling the pair below uses                : %6.1f us/iteration" % best, flush=True)
+single.close()
 for level in (2, 1):
     os.environ["HP_PEER_DIRECT"] = "1" if level == 2 else "0"
     uid = hp.comm_unique_id()
