@@ -163,6 +163,13 @@ struct hp_domain {
 	bool             tail_want = false;               // step_begin_impl: this iteration qualifies, if the launch is small enough
 	int              tail_fresh = 0;                  // ... and this is what its advance would be told
 	bool             tail_done = false;               // launch_march: the launch carried it -- hp_step_end launches nothing
+	// speculative STRICT fp64 batches (hp_math.hpp: div_shared; spec_begin / spec_resolve below)
+	bool             spec_now = false;                // the flux launches queued now are the shared-reciprocal instantiations
+	uint32_t         spec_pending = 0;                // iterations of a speculative batch whose flag word has not been looked at yet
+	void*            spec_state = nullptr;            // snapshot in front of the batch: both state buffers ...
+	void*            spec_scalars = nullptr;          // ... Scalars<T> + the slot block
+	struct { int use_alt, adv_fresh; bool need_full_reduce, edge_dirty; long ghost_valid; uint64_t cells_calculated, iterations; } spec_host;
+	uint64_t         spec_batches = 0, spec_replays = 0;
 };
 
 namespace {
@@ -421,13 +428,21 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 		return HP_OK;
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit_k2k6(), tail);
-#define HP_LAUNCH_K2(UNIFORM_, TAIL_)                                                                                               \
-	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, UNIFORM_, TAIL_, T>), dim3(blocks), dim3(256), 0, stream, p,                   \
+#define HP_LAUNCH_K2S(UNIFORM_, TAIL_, SPEC_)                                                                                        \
+	hipLaunchKernelGGL((muscl_march<STRICT, CFL_MODE, UNIFORM_, TAIL_, T, SPEC_>), dim3(blocks), dim3(256), 0, stream, p,            \
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, tail)
+#define HP_LAUNCH_K2(UNIFORM_, TAIL_) HP_LAUNCH_K2S(UNIFORM_, TAIL_, false)
+	// a speculative STRICT fp64 batch (spec_begin): the shared-reciprocal instantiation; single domains only (TAIL 0 / 1)
+	constexpr bool CAN_SPEC = STRICT && sizeof(T) == 8;
+	if (CAN_SPEC && d->spec_now && tail_kind != 2 && part == PART_ALL) {
+		if (d->manning_uniform) { if (tail_kind == 1) HP_LAUNCH_K2S(true, 1, CAN_SPEC); else HP_LAUNCH_K2S(true, 0, CAN_SPEC); }
+		else                    { if (tail_kind == 1) HP_LAUNCH_K2S(false, 1, CAN_SPEC); else HP_LAUNCH_K2S(false, 0, CAN_SPEC); }
+	} else
 	if (d->manning_uniform) { if (tail_kind == 2) HP_LAUNCH_K2(true, 2); else if (tail_kind == 1) HP_LAUNCH_K2(true, 1); else HP_LAUNCH_K2(true, 0); }
 	else                    { if (tail_kind == 2) HP_LAUNCH_K2(false, 2); else if (tail_kind == 1) HP_LAUNCH_K2(false, 1); else HP_LAUNCH_K2(false, 0); }
 #undef HP_LAUNCH_K2
+#undef HP_LAUNCH_K2S
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
 }
@@ -446,11 +461,22 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit(), tail);
-#define HP_LAUNCH_K1(FUSED_, TAIL_, LIST_, NEXT_)                                                                                   \
-	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, FUSED_, TAIL_, T>), dim3(blocks), dim3(256), 0, stream, p,                   \
+#define HP_LAUNCH_K1S(FUSED_, TAIL_, LIST_, NEXT_, SPEC_)                                                                                   \
+	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, FUSED_, TAIL_, T, SPEC_>), dim3(blocks), dim3(256), 0, stream, p,                   \
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, LIST_, NEXT_,   \
 	                   truncated, tail)
+#define HP_LAUNCH_K1(FUSED_, TAIL_, LIST_, NEXT_) HP_LAUNCH_K1S(FUSED_, TAIL_, LIST_, NEXT_, false)
+	constexpr bool CAN_SPEC = STRICT && sizeof(T) == 8;       // a speculative STRICT fp64 batch: see launch_muscl
+	if (CAN_SPEC && d->spec_now && tail_kind != 2 && part == PART_ALL) {
+		if (d->fusable) {
+			if (tail_kind == 1) HP_LAUNCH_K1S(true, 1, (const AreaBdyList<T>*)d->fused_list, d->fuse_next, CAN_SPEC);
+			else                HP_LAUNCH_K1S(true, 0, (const AreaBdyList<T>*)d->fused_list, d->fuse_next, CAN_SPEC);
+		} else {
+			if (tail_kind == 1) HP_LAUNCH_K1S(false, 1, (const AreaBdyList<T>*)nullptr, 0, CAN_SPEC);
+			else                HP_LAUNCH_K1S(false, 0, (const AreaBdyList<T>*)nullptr, 0, CAN_SPEC);
+		}
+	} else
 	if (d->fusable) {
 		if (tail_kind == 2)      HP_LAUNCH_K1(true, 2, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
 		else if (tail_kind == 1) HP_LAUNCH_K1(true, 1, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
@@ -460,6 +486,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 		else if (tail_kind == 1) HP_LAUNCH_K1(false, 1, (const AreaBdyList<T>*)nullptr, 0);
 		else                     HP_LAUNCH_K1(false, 0, (const AreaBdyList<T>*)nullptr, 0);
 	}
+#undef HP_LAUNCH_K1S
 #undef HP_LAUNCH_K1
 	HIP_TRY(hipGetLastError());
 	return HP_OK;
@@ -776,12 +803,16 @@ int refresh_fusable(hp_domain* d)
 	return HP_OK;
 }
 
+int spec_resolve(hp_domain* d);
 int check_domain(hp_domain* d)
 {
 	if (d) d->fork_is_advance = false;        // any entry point may queue work behind the last advance_time
 	if (!d) return fail(HP_ERR_INVALID, "null domain");
 	hipError_t e = hipSetDevice(d->desc.device);
 	if (e != hipSuccess) return fail(HP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+	// a speculative STRICT batch is still to be looked at: whoever enters the library next does that first, so that nothing is
+	// ever queued behind -- or read from -- a batch that has to be re-run
+	if (d->spec_pending) return spec_resolve(d);
 	return HP_OK;
 }
 
@@ -1060,6 +1091,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
 	hipFree(d->scalars); hipFree(d->cfl_slot);
 	hipFree(d->saved_state); hipFree(d->saved_scalars); hipFree(d->fused_list); hipFree(d->tail_words);
+	hipFree(d->spec_state); hipFree(d->spec_scalars);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
 	if (d->ev_stop) hipEventDestroy(d->ev_stop);
@@ -1393,11 +1425,50 @@ int hp_step_end(hp_domain_t* d)
 	return dispatch_end(d);
 }
 
-int hp_step_batch(hp_domain_t* d, uint32_t n_iterations)
+} // extern "C"
+namespace {
+// ---- speculative STRICT fp64 batches -------------------------------------------------------------------------------------
+// The STRICT flux kernels have a flavour whose quotients share refined reciprocals (hp_math.hpp: div_shared): bit-identical to
+// the plain divisions except for operands at the ends of the exponent range, which it DETECTS (SLOT_SPEC) but does not handle
+// -- every in-kernel fall-back cost more than the sharing gains (profiles/r04i).  A batch of at least SPEC_MIN iterations on a
+// single domain therefore runs speculatively: snapshot (both state buffers, scalars, slot block: as hp_state_save), the
+// shared-reciprocal kernels, the flag word copied to pinned memory behind the last launch.  The next entry into the library
+// (check_domain) waits for the batch, looks at the word and, if it is raised, puts the snapshot back and runs the same
+// iterations with the plain kernels.  Cost of the snapshot: two device copies of the state per batch (0.45 ms at 4096^2, i.e.
+// one iteration's worth per batch); HP_STRICT_SPECULATE=1 switches it on (see spec_wanted for why it is off by default),
+// HP_STRICT_SPEC_FORCE=k pretends every k-th batch raised the word (tests).
+constexpr uint32_t SPEC_MIN = 8;
+constexpr size_t HOST_SPEC_FLAG = 464;      // byte offset in the pinned block (0..127 scalars, 256..447 handshake, 480..495 read-backs)
+bool spec_wanted(const hp_domain* d, uint32_t n)
 {
-	int rc = check_domain(d);
-	if (rc != HP_OK) return rc;
-	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	// OPT-IN (HP_STRICT_SPECULATE=1).  Measured with the rigorous flag (profiles/r04j_strict_lines_*): the Godunov kernel gains 2-3 %
+	// (S-DAM 4096^2 0.490 -> 0.479 ms, S-RAIN 0.716 -> 0.697), the MUSCL-Hancock kernel LOSES 9-13 % (0.580 -> 0.657, 1.069 -> 1.164):
+	// the denominator-side v_div_scale + compare that make the detection exact cost most of what the shared reciprocal saves
+	// (without any detection the same kernels run at 0.426 / 0.657 / 0.518 / 0.926 ms).  Not worth a snapshot per batch by default.
+	static const bool enabled = std::getenv("HP_STRICT_SPECULATE") && std::atoi(std::getenv("HP_STRICT_SPECULATE")) != 0;
+	return enabled && n >= SPEC_MIN && d->desc.math_mode == HP_MATH_STRICT && d->desc.precision == 8 && !d->comm &&
+	       d->desc.kernel != HP_KERNEL_BASIC && (d->desc.scheme == HP_SCHEME_GODUNOV || d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK);
+}
+int spec_begin(hp_domain* d)
+{
+	const size_t bytes = d->cells * 4 * d->esize, sc_bytes = sizeof(Scalars<double>);
+	if (!d->spec_state) HIP_TRY(hipMalloc(&d->spec_state, 2 * bytes));
+	if (!d->spec_scalars) HIP_TRY(hipMalloc(&d->spec_scalars, sc_bytes + CFL_SLOT_BYTES));
+	HIP_TRY(hipMemsetAsync((char*)d->cfl_slot + (size_t)SLOT_SPEC * d->esize, 0, d->esize, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->spec_state, d->state[0], bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync((char*)d->spec_state + bytes, d->state[1], bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->spec_scalars, d->scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync((char*)d->spec_scalars + sc_bytes, d->cfl_slot, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
+	d->spec_host.use_alt = d->use_alt; d->spec_host.adv_fresh = d->adv_fresh;
+	d->spec_host.need_full_reduce = d->need_full_reduce; d->spec_host.edge_dirty = d->edge_dirty;
+	d->spec_host.ghost_valid = d->ghost_valid;
+	d->spec_host.cells_calculated = d->cells_calculated; d->spec_host.iterations = d->iterations;
+	d->spec_now = true;
+	return HP_OK;
+}
+int run_iterations(hp_domain* d, uint32_t n_iterations)
+{
+	int rc;
 	for (uint32_t i = 0; i < n_iterations; ++i) {
 		// (K1 FUSED) every iteration but the last carries its successor's rain / loss: between batches the buffers are
 		// what the reference's are -- a download never sees rain of an iteration that has not begun
@@ -1410,6 +1481,51 @@ int hp_step_batch(hp_domain_t* d, uint32_t n_iterations)
 	}
 	d->fuse_next = 0;
 	return HP_OK;
+}
+int spec_resolve(hp_domain* d)
+{
+	const uint32_t n = d->spec_pending;
+	d->spec_pending = 0;
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	static const long force = std::getenv("HP_STRICT_SPEC_FORCE") ? std::atol(std::getenv("HP_STRICT_SPEC_FORCE")) : 0;
+	const double flag = *(volatile double*)((char*)d->host_scalars + HOST_SPEC_FLAG);
+	const bool raised = flag != 0.0 || (force > 0 && d->spec_batches % (uint64_t)force == 0);
+	if (!raised) return HP_OK;
+	// some quotient of the batch fell outside what the shared-reciprocal division covers: the batch never happened
+	d->spec_replays++;
+	log_line(HP_LOG_INFORMATION, "a speculative STRICT batch of " + std::to_string(n) + " iterations is re-run with the plain divisions");
+	const size_t bytes = d->cells * 4 * d->esize, sc_bytes = sizeof(Scalars<double>);
+	HIP_TRY(hipMemcpyAsync(d->state[0], d->spec_state, bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->state[1], (char*)d->spec_state + bytes, bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->scalars, d->spec_scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->spec_scalars + sc_bytes, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
+	d->use_alt = d->spec_host.use_alt; d->adv_fresh = d->spec_host.adv_fresh;
+	d->need_full_reduce = d->spec_host.need_full_reduce; d->edge_dirty = d->spec_host.edge_dirty;
+	d->ghost_valid = d->spec_host.ghost_valid;
+	d->cells_calculated = d->spec_host.cells_calculated; d->iterations = d->spec_host.iterations;
+	d->fork_is_advance = false;
+	return run_iterations(d, n);
+}
+} // namespace
+extern "C" {
+
+int hp_step_batch(hp_domain_t* d, uint32_t n_iterations)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
+	const bool speculate = spec_wanted(d, n_iterations);
+	if (speculate && (rc = spec_begin(d)) != HP_OK) return rc;
+	rc = run_iterations(d, n_iterations);
+	if (speculate) {
+		d->spec_now = false;
+		if (rc != HP_OK) return rc;
+		d->spec_batches++;
+		HIP_TRY(hipMemcpyAsync((char*)d->host_scalars + HOST_SPEC_FLAG, (char*)d->cfl_slot + (size_t)SLOT_SPEC * d->esize, 8,
+		                       hipMemcpyDeviceToHost, d->stream));
+		d->spec_pending = n_iterations;
+	}
+	return rc;
 }
 
 // The mailboxes' sticky error word (a strip that was not heard from within HP_PEER_TIMEOUT_MS: the tail / advance kernel then
@@ -1470,7 +1586,13 @@ int hp_is_busy(hp_domain_t* d, int* busy)
 	if (!d || !busy) return fail(HP_ERR_INVALID, "null argument");
 	hipError_t e = hipStreamQuery(d->stream);
 	if (e == hipSuccess && d->stream_halo) e = hipStreamQuery(d->stream_halo);       // halo segments of a split step
-	if (e == hipSuccess) { *busy = 0; return HP_OK; }
+	if (e == hipSuccess) {
+		*busy = 0;
+		// (an idle domain whose speculative batch has not been looked at yet: do that now -- the caller polls this to learn
+		// whether the batch's results can be read)
+		if (d->spec_pending) { hipSetDevice(d->desc.device); return spec_resolve(d); }
+		return HP_OK;
+	}
 	if (e == hipErrorNotReady) { *busy = 1; return HP_OK; }
 	return fail(HP_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
 }

@@ -604,8 +604,16 @@ template <typename T> struct FusedBdy {
 // is the reference's buffer, without the next iteration's rain -- and the kernel declines when dt's sign is not certain
 // (within VERY_SMALL of the sync point, at the end time): the word at cfl_slot[SLOT_BDY] tells the stand-alone pass of
 // the next iteration whether there is anything left for it to do.
-template <bool STRICT, int CFL_MODE, bool FUSED, int TAIL, typename T>          // TAIL: 0 none, 1 tail block, 2 tail block + ghost rows stored into the neighbours
-__global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Scalars<T>* sc,
+// waves per SIMD the register allocator is asked to make room for (as muscl_waves below): fp64 runs three (FAST needs 147
+// VGPRs; STRICT with the shared reciprocals of round 4 would take 181 if left alone -- the scheduler interleaves the quotient
+// chains -- and lose the third wave)
+template <typename T> constexpr int march_waves() { return sizeof(T) == 4 ? 5 : 3; }
+
+// SPEC (STRICT fp64 only): the speculative flavour of a STRICT batch -- quotients that share a denominator share its refined
+// reciprocal (hp_math.hpp: div_shared), a lane whose operands fall outside what that covers raises the domain's SLOT_SPEC
+// word at the end of its tile, and the host re-runs the batch with the plain instantiation (hp_engine.hip: spec_resolve)
+template <bool STRICT, int CFL_MODE, bool FUSED, int TAIL, typename T, bool SPEC = false>          // TAIL: 0 none, 1 tail block, 2 tail block + ghost rows stored into the neighbours
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves<T>()))) void godunov_march(const Params<T> p, const Scalars<T>* sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
@@ -628,6 +636,8 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	const bool out_x = lane >= 1 && lane <= MARCH_COLS && x <= p.cols - 2;         // x >= 1 is implied
 
 	const T dt = sc->dt, vs = p.vs;
+	constexpr bool PL = !SPEC;                 // plain divisions (everything but a speculative STRICT fp64 batch)
+	T* const spec_bad = cfl_slot + SLOT_SPEC;  // (SPEC) raised when a quotient falls outside what the shared-reciprocal division covers
 	const bool skip_step = dt <= T(0);                                             // CLSchemeGodunov.clc:201-206
 	const bool with_friction = p.friction != 0;
 	T vmax = T(0);
@@ -775,13 +785,13 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 	bool dryS;
 	{
 		const RowRegs<T> rs = load_row(y0 - 1);
-		const Side<T> sS = make_side<STRICT>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
-		sC = make_side<STRICT>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
+		const Side<T> sS = make_side_impl<STRICT, PL>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs, spec_bad);
+		sC = make_side_impl<STRICT, PL>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs, spec_bad);
 		dryS = (rs.c.z - rs.zb) < vs;
 		// both sides are asked for although only the north cell's is used: the tile below finishes this same face as
 		// ITS north face, and the two must take the same code path or results would depend on where tiles (and strip
 		// boundaries) fall
-		if (!skip_step) fS = face_solve<AXIS_Y, STRICT, true, true>(sS, sC, vs).forR;
+		if (!skip_step) fS = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sS, sC, vs, spec_bad).forR;
 	}
 
 	// one row: `rc` is updated, `rn` is its northern neighbour (already landed), `pre` receives the prefetch of row y+2
@@ -794,7 +804,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		if (!skip_step) {
 			// east face first: its result has to travel to the next lane while the north face is solved
 			const Side<T> sE = side_from_east(sC);
-			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sC, sE, vs);
+			const FacePair<T> fx = face_solve_impl<AXIS_X, STRICT, true, true, PL>(sC, sE, vs, spec_bad);
 			const FaceFlux<T> fE = fx.forL, forW = fx.forR;
 			FaceFlux<T> fW;
 			fW.f0 = from_west(forW.f0); fW.fx = from_west(forW.fx);
@@ -807,14 +817,14 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			const bool dryE = (sE.eta - sE.zb) < vs;
 			const bool dryN = (rn.c.z - rn.zb) < vs;
 
-			sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
-			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sC, sN, vs);
+			sN = make_side_impl<STRICT, PL>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs, spec_bad);
+			const FacePair<T> fy = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sC, sN, vs, spec_bad);
 			const FaceFlux<T> fN = fy.forL;
 
 			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
 			const bool dry5 = dryC && dryN && dryE && dryS && dryW;                   // :248-255
-			const State4<T> upd = godunov_update<STRICT>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx, vs,
-			                                             with_friction);
+			const State4<T> upd = godunov_update_impl<STRICT, false, PL>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx, vs,
+			                                                            with_friction, spec_bad);
 			if (!disabled) {
 				if (dry5) {                                                               // dst untouched (Q3)
 					write = false;
@@ -841,12 +851,12 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 		if (!priced) {
 		} else if (CFL_MODE == 1) {
 			if (write) {
-				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs);
+				const T s = cfl_speed_impl<STRICT, PL>(out.z, out.zmax, out.qx, out.qy, rc.zb, p.qs, false, spec_bad);
 				if (s > vmax) vmax = s;
 			}
 		} else if (CFL_MODE == 2) {
 			if (out_x) {
-				const T s = cfl_speed<STRICT>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
+				const T s = cfl_speed_impl<STRICT, PL>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs, false, spec_bad);
 				if (s > vmax) vmax = s;
 			}
 		}
@@ -871,7 +881,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
 			const bool write = out_x && disabled;                                      // nulls are carried, dry cells untouched (Q3)
 			if (out_x && !disabled) stale_rows |= 1ull << (unsigned)(y - y0);
-			const Side<T> sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
+			const Side<T> sN = make_side_impl<STRICT, PL>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs, spec_bad);
 			fS = face_dry_for_right<AXIS_Y, STRICT>(sC, sN, vs);
 			// (FUSED: the only cells this loop stores are nulls, which no boundary kernel touches)
 			buf_store_state(rc.c, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
@@ -879,12 +889,12 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 			if (!((int)y >= tm.price_lo && (int)y < tm.price_hi)) {
 			} else if (CFL_MODE == 1) {
 				if (write) {
-					const T s = cfl_speed<STRICT>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
+					const T s = cfl_speed_impl<STRICT, PL>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs, false, spec_bad);
 					if (s > vmax) vmax = s;
 				}
 			} else if (CFL_MODE == 2) {
 				if (out_x) {
-					const T s = cfl_speed<STRICT>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs);
+					const T s = cfl_speed_impl<STRICT, PL>(rc.c.z, rc.c.zmax, rc.c.qx, rc.c.qy, rc.zb, p.qs, false, spec_bad);
 					if (s > vmax) vmax = s;
 				}
 			}
@@ -908,7 +918,7 @@ __global__ __launch_bounds__(256) void godunov_march(const Params<T> p, const Sc
 				const State4<T> c = dst[id];
 				const T zb = bed[id];
 				if (CFL_MODE == 1 && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
-					const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, zb, p.qs);
+					const T s = cfl_speed_impl<STRICT, PL>(c.z, c.zmax, c.qx, c.qy, zb, p.qs, false, spec_bad);
 					if (s > vmax) vmax = s;
 				}
 				if (FUSED && fuse) {
@@ -966,7 +976,7 @@ __device__ __forceinline__ Raw<T> raw_from_west(const Raw<T>& r)
 // would spill there and keeps two; fp32 has room for four
 template <bool STRICT, typename T> constexpr int muscl_waves() { return sizeof(T) == 4 ? 4 : (STRICT ? 2 : 3); }
 
-template <bool STRICT, int CFL_MODE, bool UNIFORM_N, int TAIL, typename T>
+template <bool STRICT, int CFL_MODE, bool UNIFORM_N, int TAIL, typename T, bool SPEC = false>      // SPEC: see K1
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves<STRICT, T>()))) void muscl_march(const Params<T> p, const Scalars<T>* sc,
                                                    const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                    State4<T>* __restrict__ dst, const T* __restrict__ manning,
@@ -993,6 +1003,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 	const bool out_x = lane >= 2 && lane <= MUSCL_COLS + 1 && x <= p.cols - 3;
 
 	const T dt = sc->dt, vs = p.vs;
+	constexpr bool PL = !SPEC;
+	T* const spec_bad = cfl_slot + SLOT_SPEC;
 	const bool skip_step = dt <= T(0);                                             // :576-577, :69-70
 	const bool with_friction = p.friction != 0;
 	T vmax = T(0);
@@ -1033,14 +1045,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		const Raw<T> e = raw_from_east(c), w = raw_from_west(c);
 		dry_e = e.zmax < vs;                                                       // :633 tests Zmax, not depth (Q6)
 		dry_w = w.zmax < vs;
-		return muscl_predict<STRICT>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs, p.muscl_nb_bed != 0, quiet, same);
+		return muscl_predict_impl<STRICT, PL>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs, p.muscl_nb_bed != 0, quiet, same, spec_bad);
 	};
 	// A "quiet" row (muscl_predict's wave-uniform fast path: all four face states of every lane equal the cell state)
 	// needs neither the LDS round trip of its face values nor three separate sides: one side built from the cell state
 	// serves its E, W and N faces -- the same values the general path would produce, with a third of the reciprocals.
 	auto cell_side = [&](const RowRegs<T>& r) {
 		Face4<T> cc; cc.z = r.c.z; cc.h = r.c.z - r.zb; cc.qx = r.c.qx; cc.qy = r.c.qy;
-		return side_from_face<STRICT>(cc, r.c.qx, r.c.qy, vs);
+		return side_from_face_impl<STRICT, PL>(cc, r.c.qx, r.c.qy, vs, spec_bad);
 	};
 
 	RowRegs<T> rA = load_row(y0);
@@ -1067,9 +1079,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			stash[4][lane] = pc.e.z; stash[5][lane] = pc.e.h; stash[6][lane] = pc.e.qx; stash[7][lane] = pc.e.qy;
 			stash[8][lane] = pc.w.z; stash[9][lane] = pc.w.h; stash[10][lane] = pc.w.qx; stash[11][lane] = pc.w.qy;
 			}
-			const Side<T> sS = side_from_face<STRICT>(ps.n, rs.c.qx, rs.c.qy, vs);
-			const Side<T> sC = side_from_face<STRICT>(pc.s, rc.c.qx, rc.c.qy, vs);
-			fS = face_solve<AXIS_Y, STRICT, true, true>(sS, sC, vs).forR;
+			const Side<T> sS = side_from_face_impl<STRICT, PL>(ps.n, rs.c.qx, rs.c.qy, vs, spec_bad);
+			const Side<T> sC = side_from_face_impl<STRICT, PL>(pc.s, rc.c.qx, rc.c.qy, vs, spec_bad);
+			fS = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sS, sC, vs, spec_bad).forR;
 		}
 	}
 
@@ -1128,9 +1140,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 					pc_n.z = stash[0][lane]; pc_n.h = stash[1][lane]; pc_n.qx = stash[2][lane]; pc_n.qy = stash[3][lane];
 					pc_e.z = stash[4][lane]; pc_e.h = stash[5][lane]; pc_e.qx = stash[6][lane]; pc_e.qy = stash[7][lane];
 					pc_w.z = stash[8][lane]; pc_w.h = stash[9][lane]; pc_w.qx = stash[10][lane]; pc_w.qy = stash[11][lane];
-					sE_mine = side_from_face<STRICT>(pc_e, rc.c.qx, rc.c.qy, vs);
-					sW_mine = side_from_face<STRICT>(pc_w, rc.c.qx, rc.c.qy, vs);
-					sN_mine = side_from_face<STRICT>(pc_n, rc.c.qx, rc.c.qy, vs);
+					sE_mine = side_from_face_impl<STRICT, PL>(pc_e, rc.c.qx, rc.c.qy, vs, spec_bad);
+					sW_mine = side_from_face_impl<STRICT, PL>(pc_w, rc.c.qx, rc.c.qy, vs, spec_bad);
+					sN_mine = side_from_face_impl<STRICT, PL>(pc_n, rc.c.qx, rc.c.qy, vs, spec_bad);
 				}
 			}
 			if (!quiet_n) {
@@ -1146,8 +1158,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			if (inert) {
 				if (inertD && !inertD_n) {
 					const Side<T> sN_dry = cell_side(rc);                                 // a dry row is a quiet row
-					const Side<T> sN_nb = side_from_face<STRICT>(pn_s, rn.c.qx, rn.c.qy, vs);
-					fS = face_solve<AXIS_Y, STRICT, true, true>(sN_dry, sN_nb, vs).forR;
+					const Side<T> sN_nb = side_from_face_impl<STRICT, PL>(pn_s, rn.c.qx, rn.c.qy, vs, spec_bad);
+					fS = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sN_dry, sN_nb, vs, spec_bad).forR;
 					fS_ok = true;
 				} else {
 					fS_ok = false;
@@ -1162,11 +1174,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			still_priced = false;
 			if (!fS_ok) {                                   // the row below was a still row: its state is this row's state
 				const Side<T> cs = cell_side(rc);
-				fS = face_solve<AXIS_Y, STRICT, true, true>(cs, cs, vs).forR;
+				fS = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(cs, cs, vs, spec_bad).forR;
 			}
 			// east face: my E-face state against the east neighbour's W-face state
 			const Side<T> sE_nb = side_from_east(sW_mine);
-			const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sE_mine, sE_nb, vs);
+			const FacePair<T> fx = face_solve_impl<AXIS_X, STRICT, true, true, PL>(sE_mine, sE_nb, vs, spec_bad);
 			const FaceFlux<T> fE = fx.forL, forW = fx.forR;
 			FaceFlux<T> fW;
 			fW.f0 = from_west(forW.f0); fW.fx = from_west(forW.fx);
@@ -1175,12 +1187,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			fW.stop = from_west((int)forW.stop) != 0;
 
 			// north face: my N-face state against the north neighbour's S-face state
-			const Side<T> sN_nb = side_from_face<STRICT>(pn_s, rn.c.qx, rn.c.qy, vs);
-			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sN_mine, sN_nb, vs);
+			const Side<T> sN_nb = side_from_face_impl<STRICT, PL>(pn_s, rn.c.qx, rn.c.qy, vs, spec_bad);
+			const FacePair<T> fy = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sN_mine, sN_nb, vs, spec_bad);
 			const FaceFlux<T> fN = fy.forL;
 
-			const State4<T> upd = godunov_update<STRICT, true>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx,
-			                                                    vs, with_friction);
+			const State4<T> upd = godunov_update_impl<STRICT, true, PL>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx,
+			                                                             vs, with_friction, spec_bad);
 			if (!disabled && !dry5) out = upd;
 
 			fS = fy.forR;
@@ -1195,7 +1207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		buf_store_state(out, srd_dst, out_x ? voff_state : HP_OOB, (unsigned)(y - (y0 - 2)) * row_state);
 		if (TAIL == 2) store_peer(out, y, out_x);
 		if (CFL_MODE == 1 && !skip_cfl && out_x && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
-			const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, zb_c, p.qs);
+			const T s = cfl_speed_impl<STRICT, PL>(out.z, out.zmax, out.qx, out.qy, zb_c, p.qs, false, spec_bad);
 			if (s > vmax) vmax = s;
 		}
 		if (!skip_step) {            // row y+2 comes back into the registers of the row that is finished

@@ -108,6 +108,88 @@ __device__ __forceinline__ float rcbrt_fast(float x)
 	return __builtin_fmaf(y * (1.0f / 3.0f), e, y);
 }
 
+// ---- STRICT-flavour division with a SHARED reciprocal (round 4) ----
+// What an fp64 `a / b` compiles to on gfx950 (the IEEE-correct expansion; hp_engine.s, any STRICT kernel):
+//     d0 = v_div_scale(b, b, a)          d1, vcc = v_div_scale(a, b, a)
+//     r  = v_rcp(d0);  e = fma(-d0, r, 1);  r = fma(r, e, r);  e = fma(-d0, r, 1);  r = fma(r, e, r)
+//     q0 = d1 * r;  rem = fma(-d0, q0, d1);  q = v_div_fmas(rem, r, q0 | vcc);  result = v_div_fixup(q, b, a)
+// -- 11 VALU instructions, one of them (v_rcp_f64) at a quarter of the rate, and the two v_div_scale only ever change an
+// operand whose exponent is within ~50 of the ends of the range.  Where several quotients share ONE denominator -- qx/h and
+// qy/h, the two HLL middle-state fluxes over s_R - s_L, the eight flux differences over dx -- the STRICT kernels now refine
+// the reciprocal ONCE and run only the numerator's part per quotient, with the SAME instructions in the SAME order:
+//     recip_of(b)      : r as above from b itself; flags b unless it is a normal number below 2^1000 (1/b normal)
+//     div_shared(a, .) : d1, vcc = v_div_scale(a, b, a) and d0 = v_div_scale(b, b, a) as the compiler issues them; the lane is
+//                        flagged if d0 differs from b -- the hardware rescaled the DENOMINATOR for this numerator (exponents
+//                        768 apart, a quotient near the ends of the range), so r is not the reciprocal the compiler's
+//                        sequence would have refined; then q0 = d1 r, rem = fma(-b, q0, d1), q = v_div_fmas(rem, r, q0 | vcc),
+//                        v_div_fixup(q, b, a).  A rescaled NUMERATOR (below about 2^-960: denormal discharges) and a zero
+//                        numerator (v_div_scale answers NaN, v_div_fixup delivers the signed zero) go through the hardware's
+//                        own path, v_div_fmas and v_div_fixup, exactly as in the compiler's sequence.
+// An unflagged lane has executed the compiler's own sequence on the compiler's own operands (d0 == b, hence the same r; the same
+// d1 and vcc): the same bits by construction, not by an error analysis -- and tools/divcheck compares 2e9 random pairs over every
+// exponent window plus a table of special operands on the GPU: no unflagged quotient differs from the plain division.  A flagged
+// lane raises a word that makes the HOST re-run the batch with the plain divisions (below).  7 VALU per quotient after the first
+// instead of 11 + the quarter-rate v_rcp.  fp32 keeps the plain division (its expansion is short).
+template <typename T> struct Recip { T b, r; bool bad; };
+// PLAIN = true: the plain `a / b` everywhere (the twin a flagged wavefront re-runs, and what fp32 always takes)
+template <bool PLAIN> __device__ __forceinline__ Recip<double> recip_of(const double b)
+{
+	Recip<double> d;
+	d.b = b; d.r = 0.0; d.bad = false;
+	if (!PLAIN) {
+		d.bad = !__builtin_amdgcn_class(b, 0x108) || !(__builtin_fabs(b) < 0x1p1000);      // 0x108: -normal | +normal
+		double r = __builtin_amdgcn_rcp(b);
+		double e = __builtin_fma(-b, r, 1.0);
+		r = __builtin_fma(r, e, r);
+		e = __builtin_fma(-b, r, 1.0);
+		d.r = __builtin_fma(r, e, r);
+	}
+	return d;
+}
+// `use` == false: the caller selects the quotient away (b may hold anything there); such a lane never raises the flag
+template <bool PLAIN> __device__ __forceinline__ double div_shared(const double a, const Recip<double>& d, bool& bad, const bool use = true)
+{
+	if (PLAIN) return a / d.b;
+	bool vcc, vcc_den;
+	const double d1 = __builtin_amdgcn_div_scale(a, d.b, true, &vcc);
+	const double d0 = __builtin_amdgcn_div_scale(a, d.b, false, &vcc_den);
+	// the one thing the shared reciprocal cannot follow: v_div_scale rescaling the DENOMINATOR for this numerator (exponents 768
+	// apart, a quotient beyond the range) -- `<>` is the ordered not-equal, so the NaN it answers for a zero numerator does not
+	// flag.  (A cheaper test -- "vcc set although d1 == a", without the second v_div_scale -- misses pairs for which the
+	// hardware rescales BOTH operands: 2.5 M of 2.5e8 over the whole exponent range, tools/divcheck; it was not faster either.)
+	bad = bad || ((d.bad || __builtin_islessgreater(d0, d.b)) && use);
+	const double q0 = d1 * d.r;
+	const double rem = __builtin_fma(-d.b, q0, d1);
+	return __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(rem, d.r, q0, vcc), d.b, a);
+}
+// the end of a group of quotients: raise the domain's SLOT_SPEC word if any lane of the wavefront flagged.  The branch is
+// predicted not taken and its body -- one store -- sits out of line: nothing of the group has to stay alive for it.
+template <bool PLAIN, typename T> __device__ __forceinline__ void spec_raise(const bool bad, T* word)
+{
+	if (!PLAIN && sizeof(T) == 8)
+		if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) *word = T(1);
+}
+template <bool PLAIN> __device__ __forceinline__ Recip<float> recip_of(const float b) { return Recip<float>{b, 0.0f, false}; }
+template <bool PLAIN> __device__ __forceinline__ float div_shared(const float a, const Recip<float>& d, bool&, const bool = true) { return a / d.b; }
+// a0 / b and a1 / b
+template <bool PLAIN, typename T>
+__device__ __forceinline__ void div2_strict(const T a0, const T a1, const T b, const bool use, T& q0, T& q1, bool& bad)
+{
+	const Recip<T> d = recip_of<PLAIN>(b);
+	q0 = div_shared<PLAIN>(a0, d, bad, use);
+	q1 = div_shared<PLAIN>(a1, d, bad, use);
+}
+// Where the flag goes: out of the kernel.  Every in-kernel fall-back was built and measured (profiles/r04i_*): a branch behind
+// every quotient that patches a flagged lane up at once (in line: forty-odd jumps over cold code per cell, S-DAM 0.544 -> 0.643
+// ms; out of line with __builtin_expect: 1.07 ms -- the cold divisions' live ranges cost the kernel its registers); one
+// wave-uniform test per GROUP of statements re-running the group's plain twin (1.80 ms: scratch); a plain division behind a real
+// function call (1.25 ms); and a per-lane flag ORed across the whole tile (0.68 ms: SGPR spills in the row loop) -- against 0.426
+// ms for the same kernel with no fall-back at all.  So a group of quotients only raises ONE WORD in the domain's slot block
+// (spec_raise: a store, out of line, behind a branch that is never taken), and the fall-back is the HOST's: hp_step_batch takes
+// a device-side snapshot in front of a speculative batch, and whoever next enters the library finds the word raised, puts the
+// snapshot back and re-runs the batch with the plain kernels (hp_engine.hip: spec_begin / spec_resolve).
+template <bool STRICT, typename T> constexpr bool shares_reciprocals() { return STRICT && sizeof(T) == 8; }
+
 // a*b + c: two roundings in STRICT (what the reference computes without -cl-mad-enable), one FMA in FAST
 template <bool STRICT, typename T> __device__ __forceinline__ T mad(const T a, const T b, const T c)
 {
@@ -118,21 +200,30 @@ template <bool STRICT, typename T> __device__ __forceinline__ T mad(const T a, c
 // reconstructInterface (CLSchemeGodunov.clc:39-61): u0 = (Z - zb < VERY_SMALL) ? 0 : Qx / (Z - zb).
 template <typename T> struct Side { T eta, zb, qx, qy, u0, v0; };
 
-template <bool STRICT, typename T>
-__device__ __forceinline__ Side<T> make_side(T z, T qx, T qy, T zb, T vs)
+template <bool STRICT, bool PLAIN, typename T>
+__device__ __forceinline__ Side<T> make_side_impl(T z, T qx, T qy, T zb, T vs, T* spec_word)
 {
+	bool bad = false;
 	Side<T> s;
 	s.eta = z; s.zb = zb; s.qx = qx; s.qy = qy;
 	const T h0 = z - zb;
 	if (STRICT) {
-		s.u0 = (h0 < vs ? T(0) : qx / h0);
-		s.v0 = (h0 < vs ? T(0) : qy / h0);
+		T u, v;
+		div2_strict<PLAIN>(qx, qy, h0, !(h0 < vs), u, v, bad);
+		spec_raise<PLAIN>(bad, spec_word);
+		s.u0 = (h0 < vs ? T(0) : u);
+		s.v0 = (h0 < vs ? T(0) : v);
 	} else {
 		const T inv = (h0 < vs ? T(0) : rcp_fast(h0));
 		s.u0 = qx * inv;
 		s.v0 = qy * inv;
 	}
 	return s;
+}
+template <bool STRICT, typename T>                       // the plain flavour (everything but the speculative K1 / K2 instantiations)
+__device__ __forceinline__ Side<T> make_side(T z, T qx, T qy, T zb, T vs)
+{
+	return make_side_impl<STRICT, true>(z, qx, qy, zb, vs, (T*)nullptr);
 }
 
 // What a cell needs from one of its four faces: the flux vector (mass, x-momentum, y-momentum), the
@@ -169,9 +260,12 @@ template <typename T> struct FaceCore {
 };
 
 // Shift-dependent tail of a STRICT face solve for one of the two cells (the FAST flavour finishes a face once, see face_solve)
-template <int AXIS, typename T>
-__device__ __forceinline__ FaceFlux<T> finish_wet(const FaceCore<T>& k, const T s, const bool own_left, const bool stop)
+template <int AXIS, bool PLAIN, typename T>
+__device__ __forceinline__ FaceFlux<T> finish_wet(const FaceCore<T> k, const Recip<T> rds, const T s, const bool own_left, const bool stop, bool& bad)
 {
+	// (k and rds by VALUE, the tangential velocity picked into a local first: with references the speculative instantiations kept
+	// the face core in scratch memory -- the select between two of its fields had become a load from a selected address)
+	const T ut_mid = k.bMid1 ? k.utL : k.utR;
 	const T half_g = T(0.5) * gravity<T>();
 	const T a = k.etaL - s, b = k.etaR - s, zb = k.zbm - s;
 	// normal-momentum flux of each side in free-surface form, left bed on both sides (:146-157, Q4)
@@ -181,10 +275,11 @@ __device__ __forceinline__ FaceFlux<T> finish_wet(const FaceCore<T>& k, const T 
 	if (k.bLeft)       { f0 = k.qnL; fn = fnL; ft = k.unL * k.qtL; }
 	else if (k.bRight) { f0 = k.qnR; fn = fnR; ft = k.unR * k.qtR; }
 	else {
-		// HLL middle state (:200-224)
-		const T f1m = (k.sR * k.qnL - k.sL * k.qnR + k.sLsR * (b - a)) / (k.sR - k.sL);
-		const T f2m = (k.sR * fnL - k.sL * fnR + k.sLsR * (k.qnR - k.qnL)) / (k.sR - k.sL);
-		f0 = f1m; fn = f2m; ft = f1m * (k.bMid1 ? k.utL : k.utR);
+		// HLL middle state (:200-224); both quotients (and both finishes of the face) share s_R - s_L
+		const T n1 = k.sR * k.qnL - k.sL * k.qnR + k.sLsR * (b - a);
+		const T n2 = k.sR * fnL - k.sL * fnR + k.sLsR * (k.qnR - k.qnL);
+		const T f1m = div_shared<PLAIN>(n1, rds, bad), f2m = div_shared<PLAIN>(n2, rds, bad);   // (rds: s_R - s_L and its refined reciprocal)
+		f0 = f1m; fn = f2m; ft = f1m * ut_mid;
 	}
 	FaceFlux<T> o;
 	o.f0 = f0;
@@ -202,9 +297,10 @@ template <typename T> struct FacePair { FaceFlux<T> forL, forR; };
 //   forL : the face as cell L sees it (its E or N face; "own" = left,  ucDirection < DOMAIN_DIR_S)
 //   forR : the face as cell R sees it (its W or S face; "own" = right)
 // Reference: reconstructInterface (CLSchemeGodunov.clc:27-159) + riemannSolver (CLSolverHLLC.clc:27-248).
-template <int AXIS, bool STRICT, bool WANT_L, bool WANT_R, typename T>
-__device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T>& R, const T vs)
+template <int AXIS, bool STRICT, bool WANT_L, bool WANT_R, bool PLAIN, typename T>
+__device__ __forceinline__ FacePair<T> face_solve_impl(const Side<T>& L, const Side<T>& R, const T vs, T* spec_word)
 {
+	bool bad = false;
 	const T g = gravity<T>();
 
 	// ---- reconstruction (:84-97) ----
@@ -317,9 +413,13 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 		oL = finish_dry<AXIS>(etaL, etaR, zbm, shL, true, stopL);
 		oR = finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
 	} else {
-		// velocities recomputed from the reconstructed discharges as the reference does (:87-92)
-		const T uL = (hL < vs ? T(0) : qxL / hL), vL = (hL < vs ? T(0) : qyL / hL);
-		const T uR = (hR < vs ? T(0) : qxR / hR), vR = (hR < vs ? T(0) : qyR / hR);
+		// velocities recomputed from the reconstructed discharges as the reference does (:87-92); the two quotients of a side
+		// share its depth (div2_strict)
+		T uL, vL, uR, vR;
+		div2_strict<PLAIN>(qxL, qyL, hL, !(hL < vs), uL, vL, bad);
+		div2_strict<PLAIN>(qxR, qyR, hR, !(hR < vs), uR, vR, bad);
+		uL = (hL < vs ? T(0) : uL); vL = (hL < vs ? T(0) : vL);
+		uR = (hR < vs ? T(0) : uR); vR = (hR < vs ? T(0) : vR);
 		FaceCore<T> k;
 		k.etaL = etaL; k.etaR = etaR; k.zbm = zbm;
 		k.unL = (AXIS == AXIS_X ? uL : vL); k.unR = (AXIS == AXIS_X ? uR : vR);           // dVel   (:95-98)
@@ -332,7 +432,8 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 		const T a_avg = (aL + aR) / 2;
 		const T tmp = a_avg + (k.unL - k.unR) / 4;
 		const T u_star = (k.unL + k.unR) / 2 + aL - aR;
-		const T a_star = sqrt_(g * ((tmp * tmp) / g));
+		const T hstar = div_shared<PLAIN>(tmp * tmp, recip_of<PLAIN>(g), bad);            // (tmp * tmp) / g: a constant denominator
+		const T a_star = sqrt_(g * hstar);
 		T sL, sR;
 		if (hL < vs) sL = k.unR - 2 * aR;
 		else         sL = (((k.unL - aL) > (u_star - a_star)) ? (u_star - a_star) : (k.unL - aL));
@@ -349,14 +450,30 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 		const bool bMid2 = sL < T(0) && sR >= T(0) && !k.bMid1;
 		k.bRight = !k.bLeft && !k.bMid1 && !bMid2;
 		k.inv_ds = T(0);
+		const Recip<T> rds = recip_of<PLAIN>(sR - sL);
 
-		oL = finish_wet<AXIS>(k, shL, true, stopL);
-		oR = finish_wet<AXIS>(k, shR, false, stopR);
+		oL = finish_wet<AXIS, PLAIN>(k, rds, shL, true, stopL, bad);
+		// Where the two cells of a face see the same vertical shift -- everywhere except where a cell's level lies below its
+		// neighbour's bed -- the second finish would repeat the first on the same operands: same statements, same bits.  It is
+		// skipped when that holds for every lane that is here (round 4; FAST has had its own form of this since round 1).
+		if (WANT_L && WANT_R && __all(shL == shR)) {
+			oR = oL;
+			oR.eta_nb = k.etaL - shR;                                                     // finish_wet's `a` (own cell = right)
+			oR.stop = stopR;
+		} else {
+			oR = finish_wet<AXIS, PLAIN>(k, rds, shR, false, stopR, bad);
+		}
 	}
+	if (STRICT) spec_raise<PLAIN>(bad, spec_word);
 	FacePair<T> out;
 	out.forL = oL;
 	out.forR = oR;
 	return out;
+}
+template <int AXIS, bool STRICT, bool WANT_L, bool WANT_R, typename T>
+__device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T>& R, const T vs)
+{
+	return face_solve_impl<AXIS, STRICT, WANT_L, WANT_R, true>(L, R, vs, (T*)nullptr);
 }
 
 // The face between two DRY cells as the cell on its right / north side sees it: exactly what face_solve returns in
@@ -388,8 +505,8 @@ __device__ __forceinline__ FaceFlux<T> face_dry_for_right(const Side<T>& L, cons
 }
 
 // Point-implicit Manning friction (Schemes/CLFriction.clc:26-72)
-template <bool STRICT, typename T>
-__device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, const T n, const T dt, const T vs)
+template <bool STRICT, bool PLAIN, typename T>
+__device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, const T n, const T dt, const T vs, bool& bad)
 {
 	static_assert(STRICT, "the FAST flavour goes through friction_fast (below)");
 	const T g = gravity<T>();
@@ -397,13 +514,20 @@ __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, co
 	const T h = z - zb;
 	if (h < vs || q < vs) return;
 	const T cf  = (g * n * n) / pow13_(h);                           // CLFriction.clc:43
-	const T sfx = (-cf / (h * h)) * qx * q;
-	const T sfy = (-cf / (h * h)) * qy * q;
-	const T dx  = T(1.0) + dt * (cf / (h * h)) * (2 * (qx * qx) + (qy * qy)) / q;
-	const T dy  = T(1.0) + dt * (cf / (h * h)) * ((qx * qx) + 2 * (qy * qy)) / q;
+	// (-cf) / (h h) is -(cf / (h h)) exactly: one quotient serves the four places it is written (:44-50); the two `/ q` share q,
+	// and the two clamps -qx / dt, -qy / dt share dt (:52-65) -- div2_strict, same bits as the separate divisions
+	const T k   = cf / (h * h);
+	const T sfx = (-k) * qx * q;
+	const T sfy = (-k) * qy * q;
+	T tx, ty;
+	div2_strict<PLAIN>(dt * k * (2 * (qx * qx) + (qy * qy)), dt * k * ((qx * qx) + 2 * (qy * qy)), q, true, tx, ty, bad);
+	const T dx  = T(1.0) + tx;
+	const T dy  = T(1.0) + ty;
 	T fx = sfx / dx, fy = sfy / dy;
-	if (qx >= T(0)) { if (fx < -qx / dt) fx = -qx / dt; } else { if (fx > -qx / dt) fx = -qx / dt; }
-	if (qy >= T(0)) { if (fy < -qy / dt) fy = -qy / dt; } else { if (fy > -qy / dt) fy = -qy / dt; }
+	T mx, my;
+	div2_strict<PLAIN>(-qx, -qy, dt, true, mx, my, bad);
+	if (qx >= T(0)) { if (fx < mx) fx = mx; } else { if (fx > mx) fx = mx; }
+	if (qy >= T(0)) { if (fy < my) fy = my; } else { if (fy > my) fy = my; }
 	qx = qx + dt * fx;
 	qy = qy + dt * fy;
 }
@@ -444,21 +568,24 @@ __device__ __forceinline__ T small_to_zero(const T v, const T vs)
 
 // Godunov cell update from its four finished faces (CLSchemeGodunov.clc:321-383).
 // Returns the new state; `c` holds {Z, Zmax, Qx, Qy} of the cell before the step.
-template <bool STRICT, bool CLAMP_FIRST = false, typename T>
-__device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, const T n, const T dt,
-                                                    const FaceFlux<T>& fN, const FaceFlux<T>& fE,
-                                                    const FaceFlux<T>& fS, const FaceFlux<T>& fW,
-                                                    const T dx, const T inv_dx, const T vs, const bool with_friction)
+template <bool STRICT, bool CLAMP_FIRST, bool PLAIN, typename T>
+__device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb, const T n, const T dt,
+                                                         const FaceFlux<T>& fN, const FaceFlux<T>& fE,
+                                                         const FaceFlux<T>& fS, const FaceFlux<T>& fW,
+                                                         const T dx, const T inv_dx, const T vs, const bool with_friction, T* spec_word)
 {
+	bool bad = false;
 	const T g = gravity<T>();
 	T d0, d2, d3;
 	if (STRICT) {
 		// bed-slope source from the neighbour-side reconstructed values (:323-325)
-		const T sx = -1 * g * ((fE.eta_nb + fW.eta_nb) / 2) * ((fE.zb_nb - fW.zb_nb) / dx);
-		const T sy = -1 * g * ((fN.eta_nb + fS.eta_nb) / 2) * ((fN.zb_nb - fS.zb_nb) / dx);
-		d0 = (fE.f0 - fW.f0) / dx + (fN.f0 - fS.f0) / dx - T(0);      // :328-336
-		d2 = (fE.fx - fW.fx) / dx + (fN.fx - fS.fx) / dx - sx;
-		d3 = (fE.fy - fW.fy) / dx + (fN.fy - fS.fy) / dx - sy;
+		// eight quotients over the same dx (== dy): one refined reciprocal, hoisted out of the row loop by the compiler
+		const Recip<T> rdx = recip_of<PLAIN>(dx);
+		const T sx = -1 * g * ((fE.eta_nb + fW.eta_nb) / 2) * div_shared<PLAIN>(fE.zb_nb - fW.zb_nb, rdx, bad);
+		const T sy = -1 * g * ((fN.eta_nb + fS.eta_nb) / 2) * div_shared<PLAIN>(fN.zb_nb - fS.zb_nb, rdx, bad);
+		d0 = div_shared<PLAIN>(fE.f0 - fW.f0, rdx, bad) + div_shared<PLAIN>(fN.f0 - fS.f0, rdx, bad) - T(0);      // :328-336
+		d2 = div_shared<PLAIN>(fE.fx - fW.fx, rdx, bad) + div_shared<PLAIN>(fN.fx - fS.fx, rdx, bad) - sx;
+		d3 = div_shared<PLAIN>(fE.fy - fW.fy, rdx, bad) + div_shared<PLAIN>(fN.fy - fS.fy, rdx, bad) - sy;
 	} else {
 		// dx == dy: one multiplication by 1/dx per component instead of eight divisions
 		const T hg = T(0.5) * g;
@@ -478,7 +605,8 @@ __device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, con
 		c.z  = c.z  - dt * d0;                                       // :358-360
 		c.qx = c.qx - dt * d2;
 		c.qy = c.qy - dt * d3;
-		if (with_friction) friction<true>(c.qx, c.qy, c.z, zb, n, dt, vs);        // :362-372
+		if (with_friction) friction<true, PLAIN>(c.qx, c.qy, c.z, zb, n, dt, vs, bad);        // :362-372
+		spec_raise<PLAIN>(bad, spec_word);
 	} else {
 		if (__any(stop)) { c.qx = stop ? T(0) : c.qx; c.qy = stop ? T(0) : c.qy; }   // a stopping condition needs a dry side
 		c.z  = fma_(-dt, d0, c.z);
@@ -495,6 +623,14 @@ __device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, con
 		if (c.z - zb < vs) c.z = zb;                                 // :379-380
 	}
 	return c;
+}
+template <bool STRICT, bool CLAMP_FIRST = false, typename T>
+__device__ __forceinline__ State4<T> godunov_update(State4<T> c, const T zb, const T n, const T dt,
+                                                    const FaceFlux<T>& fN, const FaceFlux<T>& fE,
+                                                    const FaceFlux<T>& fS, const FaceFlux<T>& fW,
+                                                    const T dx, const T inv_dx, const T vs, const bool with_friction)
+{
+	return godunov_update_impl<STRICT, CLAMP_FIRST, true>(c, zb, n, dt, fN, fE, fS, fW, dx, inv_dx, vs, with_friction, (T*)nullptr);
 }
 
 // =================================================================================================
@@ -543,11 +679,12 @@ __device__ __forceinline__ Face4<T> face_extrapolate(const T zb, const Face4<T>&
 }
 
 // mch_1st (:301-382): limited slopes, face extrapolation, half-step evolution, re-extrapolation
-template <bool STRICT, typename T>
-__device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>& n, const Raw<T>& e, const Raw<T>& s,
-                                                  const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs,
-                                                  const bool nb_y_is_bed, bool& quiet_row, bool& same_row)
+template <bool STRICT, bool PLAIN, typename T>
+__device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Raw<T>& n, const Raw<T>& e, const Raw<T>& s,
+                                                       const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs,
+                                                       const bool nb_y_is_bed, bool& quiet_row, bool& same_row, T* spec_word)
 {
+	bool bad = false;
 	const T g = gravity<T>();
 	Face4<T> cc; cc.z = c.z; cc.h = c.z - c.zb; cc.qx = c.qx; cc.qy = c.qy;           // :333
 	Faces<T> f; f.n = cc; f.e = cc; f.s = cc; f.w = cc;
@@ -607,11 +744,13 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 	// evolveCellState (:476-526)
 	T d0, d2, d3;
 	if (STRICT) {
-		const T s1 = -1 * g * ((f.e.z + f.w.z) / 2) * (((f.e.z - f.e.h) - (f.w.z - f.w.h)) / dx);
-		const T s2 = -1 * g * ((f.n.z + f.s.z) / 2) * (((f.n.z - f.n.h) - (f.s.z - f.s.h)) / dx);
-		d0 = (FE0 - FW0) / dx + (FN0 - FS0) / dx - T(0);
-		d2 = (FE1 - FW1) / dx + (FN1 - FS1) / dx - s1;
-		d3 = (FE2 - FW2) / dx + (FN2 - FS2) / dx - s2;
+		const Recip<T> rdx = recip_of<PLAIN>(dx);                          // eight quotients over dx, as in godunov_update
+		const T s1 = -1 * g * ((f.e.z + f.w.z) / 2) * div_shared<PLAIN>((f.e.z - f.e.h) - (f.w.z - f.w.h), rdx, bad);
+		const T s2 = -1 * g * ((f.n.z + f.s.z) / 2) * div_shared<PLAIN>((f.n.z - f.n.h) - (f.s.z - f.s.h), rdx, bad);
+		d0 = div_shared<PLAIN>(FE0 - FW0, rdx, bad) + div_shared<PLAIN>(FN0 - FS0, rdx, bad) - T(0);
+		d2 = div_shared<PLAIN>(FE1 - FW1, rdx, bad) + div_shared<PLAIN>(FN1 - FS1, rdx, bad) - s1;
+		d3 = div_shared<PLAIN>(FE2 - FW2, rdx, bad) + div_shared<PLAIN>(FN2 - FS2, rdx, bad) - s2;
+		spec_raise<PLAIN>(bad, spec_word);
 	} else {
 		const T hg = T(0.5) * g;
 		const T s1d = hg * (f.e.z + f.w.z) * ((f.e.z - f.e.h) - (f.w.z - f.w.h));
@@ -638,23 +777,39 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
 	f.w = face_extrapolate<STRICT>(c.zb, cc, sx, T(-0.5));
 	return f;
 }
+template <bool STRICT, typename T>
+__device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>& n, const Raw<T>& e, const Raw<T>& s,
+                                                  const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs,
+                                                  const bool nb_y_is_bed, bool& quiet_row, bool& same_row)
+{
+	return muscl_predict_impl<STRICT, true>(c, n, e, s, w, dt, dx, inv_dx, vs, nb_y_is_bed, quiet_row, same_row, (T*)nullptr);
+}
 
 // One side of a corrector face: the extrapolated face state + the RAW cell discharges the stopping conditions
 // test (2nd-order reconstructInterface, CLSchemeMUSCLHancock.clc:1119-1230; note `<=` in the velocity guard)
-template <bool STRICT, typename T>
-__device__ __forceinline__ Side<T> side_from_face(const Face4<T>& f, const T qx_raw, const T qy_raw, const T vs)
+template <bool STRICT, bool PLAIN, typename T>
+__device__ __forceinline__ Side<T> side_from_face_impl(const Face4<T>& f, const T qx_raw, const T qy_raw, const T vs, T* spec_word)
 {
+	bool bad = false;
 	Side<T> s;
 	s.eta = f.z; s.zb = f.z - f.h; s.qx = qx_raw; s.qy = qy_raw;
 	if (STRICT) {
-		s.u0 = (f.h <= vs ? T(0) : f.qx / f.h);
-		s.v0 = (f.h <= vs ? T(0) : f.qy / f.h);
+		T u, v;
+		div2_strict<PLAIN>(f.qx, f.qy, f.h, !(f.h <= vs), u, v, bad);
+		spec_raise<PLAIN>(bad, spec_word);
+		s.u0 = (f.h <= vs ? T(0) : u);
+		s.v0 = (f.h <= vs ? T(0) : v);
 	} else {
 		const T inv = (f.h <= vs ? T(0) : rcp_fast(f.h));
 		s.u0 = f.qx * inv;
 		s.v0 = f.qy * inv;
 	}
 	return s;
+}
+template <bool STRICT, typename T>
+__device__ __forceinline__ Side<T> side_from_face(const Face4<T>& f, const T qx_raw, const T qy_raw, const T vs)
+{
+	return side_from_face_impl<STRICT, true>(f, qx_raw, qy_raw, vs, (T*)nullptr);
 }
 
 // ---- partial-inertial scheme (CLSchemeInertial.clc) ----
@@ -707,16 +862,19 @@ __device__ __forceinline__ State4<T> inertial_update(const State4<T>& c, const T
 }
 
 // Wave speed of one cell for the CFL reduction (CLDynamicTimestep.clc:185-216)
-template <bool STRICT, typename T>
-__device__ __forceinline__ T cfl_speed(const T z, const T zmax, const T qx, const T qy, const T zb, const T qs,
-                                       const bool simplified = false)
+template <bool STRICT, bool PLAIN, typename T>
+__device__ __forceinline__ T cfl_speed_impl(const T z, const T zmax, const T qx, const T qy, const T zb, const T qs,
+                                            const bool simplified, T* spec_word)
 {
+	bool bad = false;
 	const T h = z - zb;
 	if (h > qs && zmax > T(-9999.0)) {
 		if (simplified)                                       // :205-210 (partial-inertial scheme)
 			return STRICT ? sqrt_(gravity<T>() * h) : sqrt_fast(gravity<T>() * h);
 		if (STRICT) {
-			T vx = qx / h, vy = qy / h;
+			T vx, vy;
+			div2_strict<PLAIN>(qx, qy, h, true, vx, vy, bad);
+			spec_raise<PLAIN>(bad, spec_word);
 			if (vx < T(0)) vx = -vx;
 			if (vy < T(0)) vy = -vy;
 			const T a = sqrt_(gravity<T>() * h);
@@ -728,6 +886,12 @@ __device__ __forceinline__ T cfl_speed(const T z, const T zmax, const T qx, cons
 		}
 	}
 	return T(0);
+}
+template <bool STRICT, typename T>
+__device__ __forceinline__ T cfl_speed(const T z, const T zmax, const T qx, const T qy, const T zb, const T qs,
+                                       const bool simplified = false)
+{
+	return cfl_speed_impl<STRICT, true>(z, zmax, qx, qy, zb, qs, simplified, (T*)nullptr);
 }
 
 // ---- order-preserving unsigned image of a non-negative float, for an exact atomic max ----
@@ -745,6 +909,8 @@ constexpr int SLOT_SAVED = 32, SLOT_EDGE = 64;          // separate 256-B apart 
 // strips: this rank's own last maximum (what it contributes when its buffer was not priced anew), the all-reduced maximum
 // (the collective writes it next to, not over, the local one), and the batch-start handshake's 2 x 8 elements
 constexpr int SLOT_LOCAL = 33, SLOT_GLOBAL = 34, SLOT_HANDSHAKE = 112;
+// raised (non-zero) by a SPECULATIVE flux launch in which some quotient fell outside what the shared-reciprocal division covers
+constexpr int SLOT_SPEC = 100;
 
 __device__ __forceinline__ double atomic_exchange_zero(double* slot)
 {
