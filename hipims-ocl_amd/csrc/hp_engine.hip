@@ -962,6 +962,8 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 					// fits one round and takes the cheapest; a CU with fewer than three resident blocks hides less latency
 					// (2 blocks: +20 %, 1 block: +60 %, fitted on the same sweep).
 					if (one_round_search && searchable) {
+						// a tile's fixed cost in row-times: 3.5 for fp64 K1 / K6 (the pipeline fill and the extra south face)
+						const double fill = std::getenv("HP_TILING_FILL") ? std::atof(std::getenv("HP_TILING_FILL")) : 3.5;
 						double best_cost = 1e30;
 						int best_nb = 8, best_r = rseg;
 						std::vector<double> load((size_t)cus);
@@ -979,7 +981,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 									const long band_end = std::min(updated_rows, (band + 1) * brows);
 									const long h = std::min(y0 + r, band_end) - y0;
 									if (h <= 0) continue;
-									load[(size_t)(b % cus)] += (double)h + 3.5;
+									load[(size_t)(b % cus)] += (double)h + fill;
 									count[(size_t)(b % cus)] += 1;
 								}
 								double worst = 0.0;
@@ -1003,13 +1005,16 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		// fp32 rows are cheap enough for a tile's three-row fill and extra south face to show: 32-row tiles measured
 		// 13 % (S-DAM) to 47 % (S-RAIN 8192^2) ahead of 16; fp64 is flat or slightly worse beyond 18
 		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? 32 : 16, 2, desc->precision == 4 ? 5 : 3, d->march_nbands,
-		                        desc->precision == 8);      // (fp32: 8192 x 1026 measured 83.2 -> 84.4 us with the searched tiling: its fill is not 3.5 rows)
+		                        desc->precision == 8 || std::getenv("HP_TILING_SEARCH_F32") != nullptr);      // (fp32: 8192 x 1026 measured 83.2 -> 84.4 us with the searched tiling: its fill is not 3.5 rows)
 		d->inertial_rseg = d->march_rseg; d->inertial_nbands = d->march_nbands;
 		// K2 after the inert-row cut (round 2): a tile of still water or dry land costs a fifth of a tile on the flood front,
 		// so fp64 wants more, shorter tiles for the dispatcher to balance (16-20 rows: 0.319 ms against 0.355 at 32 on the
 		// 4096^2 dam break, 0.355 against 0.395 on the developed flood, +2-5 % at 8192^2 and 16384 x 1028); fp32 stays at 32
-		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? 32 : 16, 4, desc->precision == 4 ? 4 : 3, d->muscl_nbands,
+		// (round 4, profiles/r04l_k2_rseg.txt: 12 rows: the 4096^2 dam break 0.300 -> 0.287 ms, developed flood 0.343 -> 0.340, 2048^2 -1.4 %,
+		// 8192^2 +0.6 %, every tile live +1.7 %; 10 and below lose again)
+		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? 32 : 12, 4, desc->precision == 4 ? 4 : 3, d->muscl_nbands,
 		                        false);                     // (K2's tiles differ fivefold in cost -- inert rows --: the searched tiling lost 20 % on the 4096 x 514 dam break)
+		if (d->muscl_rseg < 4) d->muscl_rseg = 4;
 	}
 	if (std::getenv("HP_PRINT_TILING"))
 		std::fprintf(stderr, "[hipims_mi] tiling %ld x %ld: K1/K6 %d rows x %d bands, K2 %d rows x %d bands\n", (long)desc->cols, (long)desc->rows,

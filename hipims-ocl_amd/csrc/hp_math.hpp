@@ -708,7 +708,23 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 
 	Face4<T> sx, sy;                                                                    // :343-346
 	sx.z = sx.h = sx.qx = sx.qy = sy.z = sy.h = sy.qx = sy.qy = T(0);
-	if (!first) { sx = limiter<STRICT>(w, c, e, vs); sy = limiter<STRICT>(s, c, n, vs); }
+	if (STRICT) {
+		if (!first) { sx = limiter<STRICT>(w, c, e, vs); sy = limiter<STRICT>(s, c, n, vs); }
+	} else {
+		// FAST (round 4): every reason a limited slope is zero -- a first-order cell (:325-330), a dry neighbour on the axis
+		// (slopeLimiter :26-46), differences that disagree in sign (MINMOD) -- goes into ONE select per slope; the slope itself is
+		// the smaller difference with the sign of the left one (v_min_f64 with |.| modifiers + v_bfi_b32), no second select.
+		// Was: three layers of selects on doubles, two v_cndmask_b32 each (64 per cell; now 16).
+		const bool zx = first || (w.z - w.zb) < vs || (e.z - e.zb) < vs, zy = first || (s.z - s.zb) < vs || (n.z - n.zb) < vs;
+		auto mm = [](const T l, const T m, const T r, const bool zero) {
+			const T dL = m - l, dR = r - m;
+			const T v = __builtin_copysign(fmin_(fabs_(dL), fabs_(dR)), dL);
+			return (zero || !(dL * dR > T(0))) ? T(0) : v;
+		};
+		const T hw = w.z - w.zb, hc = c.z - c.zb, he = e.z - e.zb, hs = s.z - s.zb, hn = n.z - n.zb;
+		sx.z = mm(w.z, c.z, e.z, zx);   sx.h = mm(hw, hc, he, zx);   sx.qx = mm(w.qx, c.qx, e.qx, zx);   sx.qy = mm(w.qy, c.qy, e.qy, zx);
+		sy.z = mm(s.z, c.z, n.z, zy);   sy.h = mm(hs, hc, hn, zy);   sy.qx = mm(s.qx, c.qx, n.qx, zy);   sy.qy = mm(s.qy, c.qy, n.qy, zy);
+	}
 	// Quiescent water (wave-uniform fast path).  Where every limited slope of every lane is zero -- still or uniformly
 	// moving water over a flat bed, wet/dry fronts (no slopes there, :26-46), first-order cells -- the four face states
 	// equal the cell state, the face fluxes cancel pairwise, the bed-slope term is g/2 (2 eta)(zb - zb) = 0, the half step
@@ -722,7 +738,11 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 		quiet_row = __all(first || flat);   // wave-uniform: every lane's four faces ARE its cell state
 	}
 	if (quiet_row) return f;
-	if (first) return f;
+	// STRICT leaves a first-order lane here (its faces are the cell state, :333-339).  FAST lets it run along: its slopes are
+	// zero, so its four faces ARE the cell state (c + 0.5 * 0), the face fluxes cancel pairwise (x - x), the bed-slope term is
+	// g/2 (2 z)(zb - zb) = 0, and with the half-step increments forced to zero below the re-extrapolated faces are the cell state
+	// again -- the same values as the early exit, without the sixteen selects on doubles that merging the two paths cost
+	if (STRICT && first) return f;
 
 	f.n = face_extrapolate<STRICT>(c.zb, cc, sy, T(+0.5));                                         // :349-352
 	f.e = face_extrapolate<STRICT>(c.zb, cc, sx, T(+0.5));
@@ -759,9 +779,15 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 		d2 = ((FE1 - FW1) + (FN1 - FS1) + s1d) * inv_dx;
 		d3 = ((FE2 - FW2) + (FN2 - FS2) + s2d) * inv_dx;
 	}
-	d0 = small_to_zero<STRICT>(d0, vs);
-	d2 = small_to_zero<STRICT>(d2, vs);
-	d3 = small_to_zero<STRICT>(d3, vs);
+	if (STRICT) {
+		d0 = small_to_zero<STRICT>(d0, vs);
+		d2 = small_to_zero<STRICT>(d2, vs);
+		d3 = small_to_zero<STRICT>(d3, vs);
+	} else {                                     // (first-order lanes: no half step, whatever their fluxes came to -- see above)
+		d0 = (first || fabs_(d0) < vs) ? T(0) : d0;
+		d2 = (first || fabs_(d2) < vs) ? T(0) : d2;
+		d3 = (first || fabs_(d3) < vs) ? T(0) : d3;
+	}
 	if (STRICT) {
 		cc.z  = cc.z  - T(0.5) * dt * d0;
 		cc.qx = cc.qx - T(0.5) * dt * d2;

@@ -13,6 +13,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#ifndef PB_STRICT
+#define PB_STRICT false          // -DPB_STRICT=true: the STRICT flavour of every piece (round 4's price list of the exact mode)
+#endif
 #ifndef HP_KERNELS
 #define HP_KERNELS "../../hipims-ocl_amd/csrc/hp_kernels.hpp"
 #endif
@@ -58,17 +61,17 @@ __global__ __launch_bounds__(256) void k_piece(const Snap s, const int iters, do
 	cell(s, x, y, c, zb); cell(s, x, y + 1, cn, zbn); cell(s, x + 1, y, ce, zbe); cell(s, x, y - 1, cs_, zbs); cell(s, x - 1, y, cw, zbw);
 	double dt = s.dt;
 	double acc = 0;
-	Side<double> sC = make_side<false>(c.z, c.qx, c.qy, zb, vs), sN = make_side<false>(cn.z, cn.qx, cn.qy, zbn, vs);
-	Side<double> sE = make_side<false>(ce.z, ce.qx, ce.qy, zbe, vs), sS = make_side<false>(cs_.z, cs_.qx, cs_.qy, zbs, vs);
-	Side<double> sW = make_side<false>(cw.z, cw.qx, cw.qy, zbw, vs);
-	FaceFlux<double> fN = face_solve<AXIS_Y, false, true, true>(sC, sN, vs).forL, fS = face_solve<AXIS_Y, false, true, true>(sS, sC, vs).forR;
-	FaceFlux<double> fE = face_solve<AXIS_X, false, true, true>(sC, sE, vs).forL, fW = face_solve<AXIS_X, false, true, true>(sW, sC, vs).forR;
+	Side<double> sC = make_side<PB_STRICT>(c.z, c.qx, c.qy, zb, vs), sN = make_side<PB_STRICT>(cn.z, cn.qx, cn.qy, zbn, vs);
+	Side<double> sE = make_side<PB_STRICT>(ce.z, ce.qx, ce.qy, zbe, vs), sS = make_side<PB_STRICT>(cs_.z, cs_.qx, cs_.qy, zbs, vs);
+	Side<double> sW = make_side<PB_STRICT>(cw.z, cw.qx, cw.qy, zbw, vs);
+	FaceFlux<double> fN = face_solve<AXIS_Y, PB_STRICT, true, true>(sC, sN, vs).forL, fS = face_solve<AXIS_Y, PB_STRICT, true, true>(sS, sC, vs).forR;
+	FaceFlux<double> fE = face_solve<AXIS_X, PB_STRICT, true, true>(sC, sE, vs).forL, fW = face_solve<AXIS_X, PB_STRICT, true, true>(sW, sC, vs).forR;
 	// MUSCL face states of this cell and its east / north neighbour (predictor output)
 	Raw<double> rc{c.z, c.zmax, c.qx, c.qy, zb}, rn{cn.z, cn.zmax, cn.qx, cn.qy, zbn}, re{ce.z, ce.zmax, ce.qx, ce.qy, zbe},
 	            rs{cs_.z, cs_.zmax, cs_.qx, cs_.qy, zbs}, rw{cw.z, cw.zmax, cw.qx, cw.qy, zbw};
 	bool q0, q1;
-	Faces<double> pc = muscl_predict<false>(rc, rn, re, rs, rw, dt, dx, inv_dx, vs, true, q0, q1);
-	Side<double> mE = side_from_face<false>(pc.e, c.qx, c.qy, vs), mN = side_from_face<false>(pc.n, c.qx, c.qy, vs);
+	Faces<double> pc = muscl_predict<PB_STRICT>(rc, rn, re, rs, rw, dt, dx, inv_dx, vs, true, q0, q1);
+	Side<double> mE = side_from_face<PB_STRICT>(pc.e, c.qx, c.qy, vs), mN = side_from_face<PB_STRICT>(pc.n, c.qx, c.qy, vs);
 	Side<double> mEnb, mNnb;
 	{
 		// neighbours' opposite faces: the east neighbour's W face, the north neighbour's S face (their own predictors)
@@ -79,14 +82,14 @@ __global__ __launch_bounds__(256) void k_piece(const Snap s, const int iters, do
 			cell(s, x + 1 + ox, y + oy, t, tz); r2[k] = Raw<double>{t.z, t.zmax, t.qx, t.qy, tz};
 		}
 		bool a, b;
-		Faces<double> pe = muscl_predict<false>(r2[0], r2[1], r2[2], r2[3], r2[4], dt, dx, inv_dx, vs, true, a, b);
-		mEnb = side_from_face<false>(pe.w, ce.qx, ce.qy, vs);
+		Faces<double> pe = muscl_predict<PB_STRICT>(r2[0], r2[1], r2[2], r2[3], r2[4], dt, dx, inv_dx, vs, true, a, b);
+		mEnb = side_from_face<PB_STRICT>(pe.w, ce.qx, ce.qy, vs);
 		for (int k = 0; k < 5; ++k) {
 			const long ox = (k == 2) - (k == 4), oy = (k == 1) - (k == 3);
 			cell(s, x + ox, y + 1 + oy, t, tz); r2[k] = Raw<double>{t.z, t.zmax, t.qx, t.qy, tz};
 		}
-		Faces<double> pn = muscl_predict<false>(r2[0], r2[1], r2[2], r2[3], r2[4], dt, dx, inv_dx, vs, true, a, b);
-		mNnb = side_from_face<false>(pn.s, cn.qx, cn.qy, vs);
+		Faces<double> pn = muscl_predict<PB_STRICT>(r2[0], r2[1], r2[2], r2[3], r2[4], dt, dx, inv_dx, vs, true, a, b);
+		mNnb = side_from_face<PB_STRICT>(pn.s, cn.qx, cn.qy, vs);
 	}
 
 	for (int it = 0; it < iters; ++it) {
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(256) void k_piece(const Snap s, const int iters, do
 			Side<double> L = PIECE == P_FACE_X ? sC : PIECE == P_FACE_Y ? sC : PIECE == P_MUSCL_FACE_X ? mE : mN;
 			Side<double> R = PIECE == P_FACE_X ? sE : PIECE == P_FACE_Y ? sN : PIECE == P_MUSCL_FACE_X ? mEnb : mNnb;
 			opaque(L); opaque(R);
-			const FacePair<double> f = (PIECE == P_FACE_X || PIECE == P_MUSCL_FACE_X) ? face_solve<AXIS_X, false, true, true>(L, R, vs)
-			                                                                             : face_solve<AXIS_Y, false, true, true>(L, R, vs);
+			const FacePair<double> f = (PIECE == P_FACE_X || PIECE == P_MUSCL_FACE_X) ? face_solve<AXIS_X, PB_STRICT, true, true>(L, R, vs)
+			                                                                             : face_solve<AXIS_Y, PB_STRICT, true, true>(L, R, vs);
 			acc += f.forL.f0 + f.forL.fx + f.forL.fy + f.forL.eta_nb + f.forL.zb_nb + (f.forL.stop ? 1.0 : 0.0)
 			     + f.forR.f0 + f.forR.fx + f.forR.fy + f.forR.eta_nb + f.forR.zb_nb + (f.forR.stop ? 2.0 : 0.0);
 		} else if (PIECE == P_UPDATE) {
@@ -103,26 +106,26 @@ __global__ __launch_bounds__(256) void k_piece(const Snap s, const int iters, do
 			FaceFlux<double> a = fN, b = fE, d = fS, e = fW;
 			opaque(a.f0); opaque(b.f0); opaque(d.f0); opaque(e.f0); opaque(a.fx); opaque(b.fy); opaque(d.fx); opaque(e.fy);
 			opaque(a.fy); opaque(b.fx); opaque(d.fy); opaque(e.fx); opaque(a.eta_nb); opaque(b.eta_nb); opaque(d.zb_nb); opaque(e.zb_nb);
-			const State4<double> u = godunov_update<false>(cc, zb, n, dt, a, b, d, e, dx, inv_dx, vs, true);
+			const State4<double> u = godunov_update<PB_STRICT>(cc, zb, n, dt, a, b, d, e, dx, inv_dx, vs, true);
 			acc += u.z + u.zmax + u.qx + u.qy;
 		} else if (PIECE == P_MAKE_SIDE) {
 			State4<double> cc = c; opaque(cc.z); opaque(cc.qx); opaque(cc.qy);
-			const Side<double> t = make_side<false>(cc.z, cc.qx, cc.qy, zb, vs);
+			const Side<double> t = make_side<PB_STRICT>(cc.z, cc.qx, cc.qy, zb, vs);
 			acc += t.u0 + t.v0;
 		} else if (PIECE == P_CFL) {
 			State4<double> cc = c; opaque(cc.z); opaque(cc.qx); opaque(cc.qy);
-			acc += cfl_speed<false>(cc.z, cc.zmax, cc.qx, cc.qy, zb, 1e-9);
+			acc += cfl_speed<PB_STRICT>(cc.z, cc.zmax, cc.qx, cc.qy, zb, 1e-9);
 		} else if (PIECE == P_PREDICT) {
 			Raw<double> a = rc; opaque(a.z); opaque(a.qx); opaque(a.qy);
 			Raw<double> b = rn; opaque(b.z); opaque(b.qx);
 			bool qa, qb;
-			const Faces<double> p = muscl_predict<false>(a, b, re, rs, rw, dt, dx, inv_dx, vs, true, qa, qb);
+			const Faces<double> p = muscl_predict<PB_STRICT>(a, b, re, rs, rw, dt, dx, inv_dx, vs, true, qa, qb);
 			acc += p.n.z + p.n.h + p.n.qx + p.n.qy + p.e.z + p.e.h + p.e.qx + p.e.qy + p.s.z + p.s.h + p.s.qx + p.s.qy + p.w.z + p.w.h + p.w.qx + p.w.qy;
 		} else if (PIECE == P_SIDE_FROM_FACE) {
 			Faces<double> p = pc; opaque(p.n.z); opaque(p.n.h); opaque(p.e.z); opaque(p.e.h); opaque(p.s.z); opaque(p.s.h); opaque(p.w.z); opaque(p.w.h);
 			opaque(p.n.qx); opaque(p.e.qx); opaque(p.s.qx); opaque(p.w.qx);
-			const Side<double> a = side_from_face<false>(p.n, c.qx, c.qy, vs), b = side_from_face<false>(p.e, c.qx, c.qy, vs),
-			                   d = side_from_face<false>(p.s, c.qx, c.qy, vs), e = side_from_face<false>(p.w, c.qx, c.qy, vs);
+			const Side<double> a = side_from_face<PB_STRICT>(p.n, c.qx, c.qy, vs), b = side_from_face<PB_STRICT>(p.e, c.qx, c.qy, vs),
+			                   d = side_from_face<PB_STRICT>(p.s, c.qx, c.qy, vs), e = side_from_face<PB_STRICT>(p.w, c.qx, c.qy, vs);
 			acc += a.u0 + a.v0 + a.zb + b.u0 + b.v0 + b.zb + d.u0 + d.v0 + d.zb + e.u0 + e.v0 + e.zb;
 		} else {
 			opaque(acc);
