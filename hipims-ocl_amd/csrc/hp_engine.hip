@@ -205,6 +205,13 @@ template <typename T> Params<T> make_params(const hp_domain* d)
 	p.manning_value = (T)d->manning_value;
 	p.simplified_cfl = d->desc.scheme == HP_SCHEME_INERTIAL ? 1 : 0;       // CLSchemeInertial.clh:25
 	p.muscl_nb_bed = (d->desc.quirks & HP_QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED) ? 1 : 0;
+	{
+		// dx a power of two (in T's arithmetic): STRICT's divisions by dx become multiplications by the exact 1 / dx
+		int e = 0;
+		const double m = std::frexp((double)(T)d->desc.dx, &e);
+		static const bool off = std::getenv("HP_STRICT_DX_POW2") && std::atoi(std::getenv("HP_STRICT_DX_POW2")) == 0;
+		p.inv_dx_pow2 = (m == 0.5 && !off && e > -100 && e < 100) ? (T)(1.0 / (double)(T)d->desc.dx) : T(0);
+	}
 	return p;
 }
 

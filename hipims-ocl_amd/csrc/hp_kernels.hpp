@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void godunov_basic(const Params<T> p, const Sc
 	const FaceFlux<T> fE = face_solve<AXIS_X, STRICT, true, false>(sC, sE, p.vs).forL;
 	const FaceFlux<T> fW = face_solve<AXIS_X, STRICT, false, true>(sW, sC, p.vs).forR;
 
-	dst[id] = godunov_update<STRICT>(c, zb, n, dt, fN, fE, fS, fW, p.dx, p.inv_dx, p.vs, p.friction != 0);
+	dst[id] = godunov_update<STRICT>(c, zb, n, dt, fN, fE, fS, fW, p.dx, STRICT ? p.inv_dx_pow2 : p.inv_dx, p.vs, p.friction != 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 
 			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
 			const bool dry5 = dryC && dryN && dryE && dryS && dryW;                   // :248-255
-			const State4<T> upd = godunov_update_impl<STRICT, false, PL>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx, vs,
+			const State4<T> upd = godunov_update_impl<STRICT, false, PL>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, STRICT ? p.inv_dx_pow2 : p.inv_dx, vs,
 			                                                            with_friction, spec_bad);
 			if (!disabled) {
 				if (dry5) {                                                               // dst untouched (Q3)
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		const Raw<T> e = raw_from_east(c), w = raw_from_west(c);
 		dry_e = e.zmax < vs;                                                       // :633 tests Zmax, not depth (Q6)
 		dry_w = w.zmax < vs;
-		return muscl_predict_impl<STRICT, PL>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, p.inv_dx, vs, p.muscl_nb_bed != 0, quiet, same, spec_bad);
+		return muscl_predict_impl<STRICT, PL>(c, raw_of(north), e, raw_of(south), w, dt, p.dx, STRICT ? p.inv_dx_pow2 : p.inv_dx, vs, p.muscl_nb_bed != 0, quiet, same, spec_bad);
 	};
 	// A "quiet" row (muscl_predict's wave-uniform fast path: all four face states of every lane equal the cell state)
 	// needs neither the LDS round trip of its face values nor three separate sides: one side built from the cell state
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			const FacePair<T> fy = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sN_mine, sN_nb, vs, spec_bad);
 			const FaceFlux<T> fN = fy.forL;
 
-			const State4<T> upd = godunov_update_impl<STRICT, true, PL>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, p.inv_dx,
+			const State4<T> upd = godunov_update_impl<STRICT, true, PL>(rc.c, rc.zb, rc.n, dt, fN, fE, fS, fW, p.dx, STRICT ? p.inv_dx_pow2 : p.inv_dx,
 			                                                             vs, with_friction, spec_bad);
 			if (!disabled && !dry5) out = upd;
 

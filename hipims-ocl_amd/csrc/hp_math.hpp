@@ -25,6 +25,7 @@ template <typename T> struct Params {
 	long cols, rows;             // local array size
 	long row_offset, global_rows;
 	T    dx, inv_dx, vs, qs, courant, t_end, dt_fixed;
+	T    inv_dx_pow2;            // 1 / dx where dx is a power of two (then x / dx == x * (1 / dx) bit for bit: STRICT multiplies), else 0
 	int  friction, dynamic_dt;
 	int  manning_uniform;        // every cell has the same Manning n (the usual "constant" data source): not re-read per step
 	T    manning_value;
@@ -579,6 +580,16 @@ __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb
 	T d0, d2, d3;
 	if (STRICT) {
 		// bed-slope source from the neighbour-side reconstructed values (:323-325)
+		if (inv_dx != T(0)) {
+			// STRICT is handed inv_dx only where dx is a POWER OF TWO (Params::inv_dx_pow2; the usual 0.5 / 1 / 2 / 4 m rasters):
+			// x / 2^k and x * 2^-k are the correctly rounded value of the same real number -- the same bits in every case,
+			// denormal results included -- so the eight divisions by dx (== dy) are eight multiplications (wave-uniform branch)
+			const T sx = -1 * g * ((fE.eta_nb + fW.eta_nb) / 2) * ((fE.zb_nb - fW.zb_nb) * inv_dx);
+			const T sy = -1 * g * ((fN.eta_nb + fS.eta_nb) / 2) * ((fN.zb_nb - fS.zb_nb) * inv_dx);
+			d0 = (fE.f0 - fW.f0) * inv_dx + (fN.f0 - fS.f0) * inv_dx - T(0);      // :328-336
+			d2 = (fE.fx - fW.fx) * inv_dx + (fN.fx - fS.fx) * inv_dx - sx;
+			d3 = (fE.fy - fW.fy) * inv_dx + (fN.fy - fS.fy) * inv_dx - sy;
+		} else {
 		// eight quotients over the same dx (== dy): one refined reciprocal, hoisted out of the row loop by the compiler
 		const Recip<T> rdx = recip_of<PLAIN>(dx);
 		const T sx = -1 * g * ((fE.eta_nb + fW.eta_nb) / 2) * div_shared<PLAIN>(fE.zb_nb - fW.zb_nb, rdx, bad);
@@ -586,6 +597,7 @@ __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb
 		d0 = div_shared<PLAIN>(fE.f0 - fW.f0, rdx, bad) + div_shared<PLAIN>(fN.f0 - fS.f0, rdx, bad) - T(0);      // :328-336
 		d2 = div_shared<PLAIN>(fE.fx - fW.fx, rdx, bad) + div_shared<PLAIN>(fN.fx - fS.fx, rdx, bad) - sx;
 		d3 = div_shared<PLAIN>(fE.fy - fW.fy, rdx, bad) + div_shared<PLAIN>(fN.fy - fS.fy, rdx, bad) - sy;
+		}
 	} else {
 		// dx == dy: one multiplication by 1/dx per component instead of eight divisions
 		const T hg = T(0.5) * g;
@@ -764,12 +776,20 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 	// evolveCellState (:476-526)
 	T d0, d2, d3;
 	if (STRICT) {
+		if (inv_dx != T(0)) {                                              // dx a power of two: products, as in godunov_update
+			const T s1 = -1 * g * ((f.e.z + f.w.z) / 2) * (((f.e.z - f.e.h) - (f.w.z - f.w.h)) * inv_dx);
+			const T s2 = -1 * g * ((f.n.z + f.s.z) / 2) * (((f.n.z - f.n.h) - (f.s.z - f.s.h)) * inv_dx);
+			d0 = (FE0 - FW0) * inv_dx + (FN0 - FS0) * inv_dx - T(0);
+			d2 = (FE1 - FW1) * inv_dx + (FN1 - FS1) * inv_dx - s1;
+			d3 = (FE2 - FW2) * inv_dx + (FN2 - FS2) * inv_dx - s2;
+		} else {
 		const Recip<T> rdx = recip_of<PLAIN>(dx);                          // eight quotients over dx, as in godunov_update
 		const T s1 = -1 * g * ((f.e.z + f.w.z) / 2) * div_shared<PLAIN>((f.e.z - f.e.h) - (f.w.z - f.w.h), rdx, bad);
 		const T s2 = -1 * g * ((f.n.z + f.s.z) / 2) * div_shared<PLAIN>((f.n.z - f.n.h) - (f.s.z - f.s.h), rdx, bad);
 		d0 = div_shared<PLAIN>(FE0 - FW0, rdx, bad) + div_shared<PLAIN>(FN0 - FS0, rdx, bad) - T(0);
 		d2 = div_shared<PLAIN>(FE1 - FW1, rdx, bad) + div_shared<PLAIN>(FN1 - FS1, rdx, bad) - s1;
 		d3 = div_shared<PLAIN>(FE2 - FW2, rdx, bad) + div_shared<PLAIN>(FN2 - FS2, rdx, bad) - s2;
+		}
 		spec_raise<PLAIN>(bad, spec_word);
 	} else {
 		const T hg = T(0.5) * g;

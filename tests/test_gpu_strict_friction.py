@@ -148,3 +148,23 @@ def test_strict_cell_boundary_with_critical_depth_is_bit_identical():
         dom.step_batch(300)
         assert np.array_equal(dom.download(), g[f"{name}_state"]), name
         dom.close()
+
+
+@pytest.mark.parametrize("dx", [1.5, 3.0, 0.7, 2.0, 0.25])
+@pytest.mark.parametrize("scheme", [hp.SCHEME_GODUNOV, hp.SCHEME_MUSCL_HANCOCK])
+def test_strict_cell_sizes_that_are_and_are_not_powers_of_two(scheme, dx):
+    """Round 4: where dx is a power of two STRICT multiplies by the exact 1 / dx instead of dividing by dx (x / 2^k and x * 2^-k
+    are the correctly rounded value of the same real number: hp_math.hpp godunov_update_impl / muscl_predict_impl); every other
+    dx keeps the divisions.  Both against the oracle, bit for bit (the seeded fuzz only draws 0.5 / 1 / 2 m cells)."""
+    cols, rows = 130, 75
+    st, bed, man = syn.s_rough(cols, rows, manning=None, seed=91)
+    quirks = oracle.QUIRKS_REFERENCE & ~(oracle.Q6_MUSCL_SERIAL if scheme == hp.SCHEME_MUSCL_HANCOCK else 0)
+    ref = oracle.OracleSim(cols, rows, dx=dx, scheme=scheme, quirks=quirks)
+    dom = hp.Domain(cols, rows, dx=dx, scheme=scheme, math_mode=hp.MATH_STRICT)
+    for s in (ref, dom):
+        s.upload(st, bed, man)
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    assert np.array_equal(dom.run(120), ref.run(120))
+    assert np.array_equal(dom.download(), ref.download())
+    assert dom.read_scalars()["time"] == ref.scalars()["t"]
+    dom.close()
