@@ -6,7 +6,7 @@
  * OpenCL runtime's all differ in the last bit on a few per cent of arguments, so no two runs of the reference on
  * different platforms agree bit for bit once friction is on -- and neither could a STRICT HIP kernel and a host
  * oracle.  This header fixes ONE result for that operation: the correctly rounded cube root, computed with IEEE
- * +, -, *, / and fma only (no table, no libm call), so that gcc on x86-64 and hipcc on gfx950 produce the same bits.
+ * +, -, * and fma only (no table, no libm call), so that gcc on x86-64 and hipcc on gfx950 produce the same bits.
  * A correctly rounded cbrt(x) differs from the infinitely precise pow(x, fl(1/3)) by |ln x| * 1.85e-17 relative
  * (fl(1/3) = 1/3 - 2^-54/3): at most 4.3 ulp at a depth of 1e-10 m, 1.3 ulp at 1 mm, 0.5 ulp at 1 m (its own rounding
  * included; measured in tests/test_crmath.py) -- a conforming `pow` result by a wide margin.
@@ -50,22 +50,29 @@ HP_CR_FN double hp_cr_cbrt(double x)
 	if (r < 0) { r += 3; k -= 1; }
 	const double m = hp_cr_from_bits((bits & 0x000fffffffffffffull) | ((uint64_t)(1023 + r) << 52));
 
-	/* seed: least-squares cubic for cbrt on [1, 8) (relative error < 1.4e-2), then three Halley steps (cubic convergence:
-	 * 1.4e-2 -> 1.7e-6 -> rounding level; the third is margin) */
-	double y = 0.7091350135760417 + m * (0.34001874249116359 + m * (-0.037495962996826379 + m * 0.0019167009490987253));
-	for (int i = 0; i < 3; ++i) {
-		const double y3 = y * y * y;
-		y = y * ((y3 + 2.0 * m) / (2.0 * y3 + m));
+	/* Division-free (round 4; the results are those of the round-3 routine, which spent four IEEE divisions here -- 4e9
+	 * random arguments compared bit for bit, tools/README.md).  s ~ m^(-1/3): a minimax cubic on [1, 8) (relative error
+	 * < 1.7e-2), then two steps of the third-order iteration s <- s (1 + d/3 + 2 d^2/9), d = 1 - m s^3 (error
+	 * e -> 14/81 e^3: 1.7e-2 -> 8e-7 -> rounding level).  y = m s^2 is the root to a few ulp, w = s^2/3 is 1/(3 y^2) to
+	 * ~1e-15, and one Newton step with a fused residual brings y within an ulp. */
+	double s = 1.2370148232167815 + m * (-0.2972025836621341 + m * (0.04589330067811839 + m * -0.002548799012225146));
+	for (int i = 0; i < 2; ++i) {
+		const double s3 = (s * s) * s;
+		const double d = __builtin_fma(-m, s3, 1.0);
+		const double t = d * __builtin_fma(d, 2.0 / 9.0, 1.0 / 3.0);
+		s = __builtin_fma(s, t, s);
 	}
+	const double w = (s * s) * (1.0 / 3.0);
+	double y = m * (s * s);
+	{ const double y2 = y * y; y = __builtin_fma(__builtin_fma(-y2, y, m), w, y); }
 	/* last step with the residual m - y^3 carried in double-double: y^2 = y2h + y2l and y2h*y = y3h + y3l exactly, so
-	 * y^3 = y3h + y3l + y2l*y up to 2^-106; m - y3h is exact (Sterbenz).  c = (m - y^3) / (3 y^2) is the Newton
-	 * correction, good to 2^-50 of itself, and |c| <= 1 ulp(y): RN(y + c) is the correctly rounded root unless the
-	 * root lies within ~2^-104 (relative) of a rounding boundary. */
+	 * y^3 = y3h + y3l + y2l*y up to 2^-106; m - y3h is exact (Sterbenz).  c = (m - y^3) w is the Newton correction, good
+	 * to 2^-49 of itself, and |c| <= 1 ulp(y): RN(y + c) is the correctly rounded root unless the root lies within
+	 * ~2^-102 (relative) of a rounding boundary. */
 	const double y2h = y * y, y2l = __builtin_fma(y, y, -y2h);
 	const double y3h = y2h * y, y3l = __builtin_fma(y2h, y, -y3h);
 	const double res = ((m - y3h) - y3l) - y2l * y;
-	const double c = res / (3.0 * y2h);
-	y = y + c;
+	y = __builtin_fma(res, w, y);
 	/* scale by 2^(k - bias): exact (the result is a normal number for every finite positive double) */
 	return y * hp_cr_from_bits((uint64_t)(1023 + k - bias) << 52);
 }
