@@ -480,14 +480,18 @@ __device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu
 constexpr int MARCH_COLS = 62;          // updated columns per wavefront (lanes 1..62)
 
 // Neighbour-lane moves.  A lane's column neighbours live in the adjacent lanes of the same wavefront; their values
-// arrive through DPP wavefront shifts (one v_mov_b32_dpp per dword, a VALU instruction) instead of a trip through the
-// LDS crossbar (ds_bpermute: an LDS instruction, an address VGPR and an lgkmcnt wait per batch).  Lanes without a
-// neighbour (63 for east, 0 for west) keep their own value -- they are halo lanes, and keeping a sane value there
-// keeps them out of the way of the wave-uniform fast paths.  (Directions verified on MI355X: tools/dpp_probe.)
-constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;     // dst[i] = src[i+1] / dst[i] = src[i-1]
+// arrive through DPP wavefront ROTATES (one v_mov_b32_dpp per dword, a VALU instruction) instead of a trip through the
+// LDS crossbar (ds_bpermute: an LDS instruction, an address VGPR and an lgkmcnt wait per batch).  A rotate, not a shift
+// (round 4): a shift leaves the lane without a neighbour (63 for east, 0 for west) its old contents, and keeping the lane's
+// own value there cost a v_mov_b32 in front of every v_mov_b32_dpp (the destination is tied to `old`).  With the rotate lane
+// 63's "east" is lane 0's cell and lane 0's "west" is lane 63's: both are halo lanes whose results are never stored, what
+// they receive is a real cell of the same row (finite, sane), and a wave-uniform test of the form "every lane and its
+// neighbours ..." is unchanged because the neighbour is some lane of the same wavefront either way.
+// (Directions verified on MI355X: tools/dpp_probe.)
+constexpr int DPP_WAVE_ROL1 = 0x134, DPP_WAVE_ROR1 = 0x13C;     // dst[i] = src[(i+1) % 64] / dst[i] = src[(i-1) % 64]
 template <int CTRL> __device__ __forceinline__ int lane_move(const int v)
 {
-	return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+	return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false);
 }
 template <int CTRL> __device__ __forceinline__ float lane_move(const float v)
 {
@@ -497,8 +501,8 @@ template <int CTRL> __device__ __forceinline__ double lane_move(const double v)
 {
 	return __hiloint2double(lane_move<CTRL>(__double2hiint(v)), lane_move<CTRL>(__double2loint(v)));
 }
-template <typename V> __device__ __forceinline__ V from_east(const V v) { return lane_move<DPP_WAVE_SHL1>(v); }   // lane + 1
-template <typename V> __device__ __forceinline__ V from_west(const V v) { return lane_move<DPP_WAVE_SHR1>(v); }   // lane - 1
+template <typename V> __device__ __forceinline__ V from_east(const V v) { return lane_move<DPP_WAVE_ROL1>(v); }   // lane + 1
+template <typename V> __device__ __forceinline__ V from_west(const V v) { return lane_move<DPP_WAVE_ROR1>(v); }   // lane - 1
 
 template <typename T> struct RowRegs { State4<T> c; T zb, n; };
 
@@ -607,13 +611,16 @@ template <typename T> struct FusedBdy {
 // waves per SIMD the register allocator is asked to make room for (as muscl_waves below): fp64 runs three (FAST needs 147
 // VGPRs; STRICT with the shared reciprocals of round 4 would take 181 if left alone -- the scheduler interleaves the quotient
 // chains -- and lose the third wave)
-template <typename T> constexpr int march_waves() { return sizeof(T) == 4 ? 5 : 3; }
+#ifndef HP_K1_STRICT_WAVES
+#define HP_K1_STRICT_WAVES 3
+#endif
+template <bool STRICT, typename T> constexpr int march_waves() { return sizeof(T) == 4 ? 5 : (STRICT ? HP_K1_STRICT_WAVES : 3); }
 
 // SPEC (STRICT fp64 only): the speculative flavour of a STRICT batch -- quotients that share a denominator share its refined
 // reciprocal (hp_math.hpp: div_shared), a lane whose operands fall outside what that covers raises the domain's SLOT_SPEC
 // word at the end of its tile, and the host re-runs the batch with the plain instantiation (hp_engine.hip: spec_resolve)
 template <bool STRICT, int CFL_MODE, bool FUSED, int TAIL, typename T, bool SPEC = false>          // TAIL: 0 none, 1 tail block, 2 tail block + ghost rows stored into the neighbours
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves<T>()))) void godunov_march(const Params<T> p, const Scalars<T>* sc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves<STRICT, T>()))) void godunov_march(const Params<T> p, const Scalars<T>* sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
