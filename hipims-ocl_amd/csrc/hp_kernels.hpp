@@ -1062,6 +1062,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 		return side_from_face_impl<STRICT, PL>(cc, r.c.qx, r.c.qy, vs, spec_bad);
 	};
 
+	// one side of a north / south face from a predicted face state; FAST predicts no faces for a quiet row (they are the cell state)
+	auto face_side = [&](const Face4<T>& fc, const RowRegs<T>& r, const bool quiet) {
+		if (!STRICT && quiet) return cell_side(r);
+		return side_from_face_impl<STRICT, PL>(fc, r.c.qx, r.c.qy, vs, spec_bad);
+	};
+
 	RowRegs<T> rA = load_row(y0);
 	RowRegs<T> rB = load_row(y0 + 1);                                              // y0+1 <= rows-2
 	RowRegs<T> rP = load_row((y0 + 2 < p.rows) ? (y0 + 2) : (p.rows - 1)), rQ;    // landing sets of the row two ahead
@@ -1086,8 +1092,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			stash[4][lane] = pc.e.z; stash[5][lane] = pc.e.h; stash[6][lane] = pc.e.qx; stash[7][lane] = pc.e.qy;
 			stash[8][lane] = pc.w.z; stash[9][lane] = pc.w.h; stash[10][lane] = pc.w.qx; stash[11][lane] = pc.w.qy;
 			}
-			const Side<T> sS = side_from_face_impl<STRICT, PL>(ps.n, rs.c.qx, rs.c.qy, vs, spec_bad);
-			const Side<T> sC = side_from_face_impl<STRICT, PL>(pc.s, rc.c.qx, rc.c.qy, vs, spec_bad);
+			const Side<T> sS = face_side(ps.n, rs, quiet_s);
+			const Side<T> sC = face_side(pc.s, rc, quiet_c);
 			fS = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sS, sC, vs, spec_bad).forR;
 		}
 	}
@@ -1165,7 +1171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			if (inert) {
 				if (inertD && !inertD_n) {
 					const Side<T> sN_dry = cell_side(rc);                                 // a dry row is a quiet row
-					const Side<T> sN_nb = side_from_face_impl<STRICT, PL>(pn_s, rn.c.qx, rn.c.qy, vs, spec_bad);
+					const Side<T> sN_nb = face_side(pn_s, rn, quiet_n);
 					fS = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sN_dry, sN_nb, vs, spec_bad).forR;
 					fS_ok = true;
 				} else {
@@ -1194,7 +1200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			fW.stop = from_west((int)forW.stop) != 0;
 
 			// north face: my N-face state against the north neighbour's S-face state
-			const Side<T> sN_nb = side_from_face_impl<STRICT, PL>(pn_s, rn.c.qx, rn.c.qy, vs, spec_bad);
+			const Side<T> sN_nb = face_side(pn_s, rn, quiet_n);
 			const FacePair<T> fy = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sN_mine, sN_nb, vs, spec_bad);
 			const FaceFlux<T> fN = fy.forL;
 

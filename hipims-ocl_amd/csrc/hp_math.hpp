@@ -699,7 +699,10 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 	bool bad = false;
 	const T g = gravity<T>();
 	Face4<T> cc; cc.z = c.z; cc.h = c.z - c.zb; cc.qx = c.qx; cc.qy = c.qy;           // :333
-	Faces<T> f; f.n = cc; f.e = cc; f.s = cc; f.w = cc;
+	// FAST does not produce the faces of a quiet row at all (quiet_row: they ARE the cell state, and the kernel builds what it
+	// needs from the cell state itself): pre-setting them cost sixteen v_mov_b64 in front of every predictor, dead on a live row
+	Faces<T> f;
+	if (STRICT) { f.n = cc; f.e = cc; f.s = cc; f.w = cc; }
 	// :325-330.  `pNeigData*.y` is the neighbour's BED in the reference's default configuration (kCachePrediction: the LDS tile
 	// of mch_1st_cachePrediction holds {Z, bed, Qx, Qy}, :201, :232-239) and its Zmax in mch_1st_cacheNone (:109-125);
 	// nb_y_is_bed is wave-uniform (HP_QUIRK_MUSCL_NEIGHBOUR_Y_IS_BED)
@@ -828,7 +831,12 @@ __device__ __forceinline__ Faces<T> muscl_predict(const Raw<T>& c, const Raw<T>&
                                                   const Raw<T>& w, const T dt, const T dx, const T inv_dx, const T vs,
                                                   const bool nb_y_is_bed, bool& quiet_row, bool& same_row)
 {
-	return muscl_predict_impl<STRICT, true>(c, n, e, s, w, dt, dx, inv_dx, vs, nb_y_is_bed, quiet_row, same_row, (T*)nullptr);
+	Faces<T> f = muscl_predict_impl<STRICT, true>(c, n, e, s, w, dt, dx, inv_dx, vs, nb_y_is_bed, quiet_row, same_row, (T*)nullptr);
+	if (!STRICT && quiet_row) {                  // (callers of this wrapper get the faces of a quiet row as well)
+		Face4<T> cc; cc.z = c.z; cc.h = c.z - c.zb; cc.qx = c.qx; cc.qy = c.qy;
+		f.n = cc; f.e = cc; f.s = cc; f.w = cc;
+	}
+	return f;
 }
 
 // One side of a corrector face: the extrapolated face state + the RAW cell discharges the stopping conditions
