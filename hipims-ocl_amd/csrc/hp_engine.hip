@@ -100,6 +100,8 @@ struct hp_domain {
 	int              muscl_rseg = 32;                 // ... of muscl_march (two warm-up rows per tile)
 	int              inertial_rseg = 32;              // ... of inertial_march
 	int              march_nbands = 8, muscl_nbands = 8, inertial_nbands = 8;   // row bands of a whole-domain launch (pick_tiling)
+	int              sweep_flip = 0;                  // parity of the whole-domain flux launches: every other one visits each band's tiles from
+	                                                  // the top down, so that it starts on the rows its predecessor wrote last (sweep_alternates)
 	int              tall_rseg = 18;                  // K1/K6 tile height where an XCD band has >= 256 rows (16 if a knob is set)
 	int              tail_rseg = 8, tail_pct = 0;     // optional short tiles for the last tail_pct % of each XCD band (measured: no gain)
 	void*            host_scalars = nullptr;          // pinned mirror
@@ -323,6 +325,7 @@ inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rs
 	if (need < g) need = g;                                             // rows at each end that a strip neighbour is sent
 	const long halo = halo_env >= need ? halo_env : (rseg > need ? rseg : need);
 	tm.price_lo = (int)price_lo; tm.price_hi = (int)(price_hi < 0x7fffffffL ? price_hi : 0x7fffffffL);
+	tm.flip = 0;
 	const bool can_split = hi - lo > 2 * halo;
 	tm.nstrips = nstrips;
 	tm.groups = (nstrips + 3) / 4;
@@ -422,6 +425,24 @@ static unsigned tail_limit_k2k6()
 	return std::min(tail_limit(), v);
 }
 
+// Alternating sweep direction.  A launch leaves the last ~250 MiB it loaded or stored in the Infinity Cache (256 MiB, stores
+// allocate: MI355X_MICROARCH.md), and what it stored last is the top of every row band -- exactly what the NEXT launch, which
+// reads the state this one wrote, would reach last.  Every other whole-domain launch therefore visits each band's tiles from the
+// top down (TileMap::flip: the same tiles mirrored within the band): it starts on rows whose new state and bed are still on the
+// die.  Pure scheduling: which wavefront solves a face never changes its bits.  HP_SWEEP_ALTERNATE=0 keeps every launch south to
+// north.
+inline bool sweep_alternates()
+{
+	static const bool on = !(std::getenv("HP_SWEEP_ALTERNATE") && std::atoi(std::getenv("HP_SWEEP_ALTERNATE")) == 0);
+	return on;
+}
+inline void sweep_direction(hp_domain* d, const int part, TileMap& tm)
+{
+	if (part != PART_ALL || !sweep_alternates()) return;
+	tm.flip = d->sweep_flip;
+	d->sweep_flip ^= 1;
+}
+
 template <typename T, bool STRICT, int CFL_MODE>
 int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int part, hipStream_t stream)
 {
@@ -433,6 +454,7 @@ int launch_muscl(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	if (!make_tile_map(lo, hi, 2, part, (int)((p.cols - 4 + MUSCL_COLS - 1) / MUSCL_COLS), d->muscl_rseg, d->tail_rseg < 8 ? 8 : d->tail_rseg, d->tail_pct, tm, blocks,
 	                   16, d->ghost_rows, d->own_lo, d->own_hi, d->muscl_nbands))
 		return HP_OK;
+	sweep_direction(d, part, tm);
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit_k2k6(), tail);
 #define HP_LAUNCH_K2S(UNIFORM_, TAIL_, SPEC_)                                                                                        \
@@ -465,6 +487,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
 	                   d->ghost_rows, d->own_lo, d->own_hi, d->march_nbands))
 		return HP_OK;
+	sweep_direction(d, part, tm);
 	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit(), tail);
@@ -510,6 +533,7 @@ int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, i
 	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
 	                   d->ghost_rows, d->own_lo, d->own_hi, d->inertial_nbands))
 		return HP_OK;
+	sweep_direction(d, part, tm);
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit_k2k6(), tail);
 #define HP_LAUNCH_K6(TAIL_)                                                                                                         \

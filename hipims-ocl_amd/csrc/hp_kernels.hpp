@@ -535,6 +535,7 @@ struct TileMap {
 	int  price_lo, price_hi;     // rows whose cells the fused CFL epilogue prices: the rows this rank OWNS (a strip with two
 	                             // reaches of ghost rows also updates rows it does not own, hp_engine.hip: strip loop); 32-bit so
 	                             // that the per-row test is two scalar compares
+	int  flip;                   // this launch visits the tiles of every band from the top down (hp_engine.hip: sweep_flip)
 };
 
 // rows [y0, y1) and the column strip of this wave; false if the block / wave has nothing to do (wave-uniform)
@@ -558,7 +559,13 @@ __device__ __forceinline__ bool tile_rows(const TileMap& tm, const int wave, lon
 	}
 	y1 = (y0 + h < band_y1) ? (y0 + h) : band_y1;
 	strip = (long)g * 4 + wave;
-	return y0 < band_y1 && strip < tm.nstrips;
+	const bool any = y0 < band_y1 && strip < tm.nstrips;
+	if (tm.flip) {                               // the same tiles, mirrored within the band (rows still march south to north inside a tile)
+		const long top = band_y0 + (band_y1 - y1);
+		y1 = band_y0 + (band_y1 - y0);
+		y0 = top;
+	}
+	return any;
 }
 
 // ---- area boundaries (bdy_Uniform / bdy_Gridded, Boundaries/CLBoundaries.clc:130-246): descriptors shared by the stand-alone
