@@ -425,15 +425,16 @@ static unsigned tail_limit_k2k6()
 	return std::min(tail_limit(), v);
 }
 
-// Alternating sweep direction.  A launch leaves the last ~250 MiB it loaded or stored in the Infinity Cache (256 MiB, stores
-// allocate: MI355X_MICROARCH.md), and what it stored last is the top of every row band -- exactly what the NEXT launch, which
-// reads the state this one wrote, would reach last.  Every other whole-domain launch therefore visits each band's tiles from the
-// top down (TileMap::flip: the same tiles mirrored within the band): it starts on rows whose new state and bed are still on the
-// die.  Pure scheduling: which wavefront solves a face never changes its bits.  HP_SWEEP_ALTERNATE=0 keeps every launch south to
-// north.
+// Alternating sweep direction (an experiment kept behind HP_SWEEP_ALTERNATE=1; off by default).  A launch leaves the last ~250 MiB
+// it loaded or stored in the Infinity Cache (256 MiB, stores allocate: MI355X_MICROARCH.md), and what it stored last is the top of
+// every row band -- exactly what the NEXT launch, which reads the state this one wrote, would reach last.  With the knob every
+// other whole-domain launch visits each band's tiles from the top down (TileMap::flip: the same tiles mirrored within the band), so
+// that it starts on rows whose new state and bed may still be on the die.  Pure scheduling: which wavefront solves a face never
+// changes its bits.  Measured (profiles/r04w_still_and_sweep_ab.txt, same box): fp32 S-DAM +4 %, S-RAIN / S-ROUGH +1.5 %, but fp64
+// S-DAM 4096^2 -4 % and the 16384 x 1026 strip -5 %: not the default.
 inline bool sweep_alternates()
 {
-	static const bool on = !(std::getenv("HP_SWEEP_ALTERNATE") && std::atoi(std::getenv("HP_SWEEP_ALTERNATE")) == 0);
+	static const bool on = std::getenv("HP_SWEEP_ALTERNATE") && std::atoi(std::getenv("HP_SWEEP_ALTERNATE")) != 0;
 	return on;
 }
 inline void sweep_direction(hp_domain* d, const int part, TileMap& tm)

@@ -501,6 +501,12 @@ template <int CTRL> __device__ __forceinline__ double lane_move(const double v)
 {
 	return __hiloint2double(lane_move<CTRL>(__double2hiint(v)), lane_move<CTRL>(__double2loint(v)));
 }
+// lane 0's value in every lane (a scalar)
+__device__ __forceinline__ float first_lane(const float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double first_lane(const double v)
+{
+	return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 template <typename V> __device__ __forceinline__ V from_east(const V v) { return lane_move<DPP_WAVE_ROL1>(v); }   // lane + 1
 template <typename V> __device__ __forceinline__ V from_west(const V v) { return lane_move<DPP_WAVE_ROR1>(v); }   // lane - 1
 
@@ -797,11 +803,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 	Side<T> sC;
 	FaceFlux<T> fS = {};
 	bool dryS;
+	// Still water (wave-uniform, round 4; K2 has had the same skip since round 3).  A row whose 64 cells hold ONE wet state at rest
+	// -- one level, one bed, zero discharge -- between a row south and a row north that hold the same state cell for cell comes out
+	// of the update exactly as it went in: each of a cell's four faces is solved on identical left and right states, opposite faces
+	// return identical values, every flux difference is x - x = +0, the bed-slope term is (zb - zb) = +0 times something finite,
+	// friction does not act on zero discharge, and Z - dt (+0) = Z, Q - dt (+0) = Q bit for bit, in FAST and in STRICT; only Zmax
+	// may have to follow Z (:375-376).  Such a row skips its faces, the north side and the update -- and leaves what the rows hand
+	// each other, the current row's side `sC` and its south flux `fS`, untouched: the row south of a still row holds the still row's
+	// state cell for cell (that is part of the test), so fS already IS the face between two such cells and sC the side of such a
+	// cell, and the row north of it holds that state too: whoever comes next, still or not, inherits exactly the values the full
+	// path would have produced for it (same values in, same bits out).  Lakes, reservoirs, the sea and both pools of the dam-break
+	// benchmark are such water.
+	// STRICT only.  The exact flavour's row costs 1300 VALU instructions and a still row 60: S-DAM 4096^2 0.436 -> 0.303 ms, the
+	// same bits.  The FAST flavour's launch is bound by the memory system in such water, not by its 420 instructions per row:
+	// with the skip it was 2 % SLOWER on S-DAM and 3-4 % slower where nothing is still (S-RAIN, S-ROUGH: the tests and what they
+	// did to the schedule) -- profiles/r04w_still_and_sweep_ab.txt.
+	constexpr bool STILL_SKIP = STRICT;
+	// (the wave-uniform facts below share ONE scalar register: as separate bools -- an SGPR pair each -- they pushed the fused
+	// flavour's scalar spills into the vector registers and those into scratch)
+	constexpr unsigned REST_S = 1, REST_C = 2, EQ_S = 4;   // every cell of the row south of the current one / of the current row is at
+	                                                       // rest (Q = 0); the two rows hold the same level and bed, cell for cell
+	constexpr unsigned PRICED = 16;                        // the still row below has put this (one) state's wave speed into vmax
+	unsigned st = 0;
+	auto at_rest = [&](const RowRegs<T>& r) { return __all(r.c.qx == T(0) && r.c.qy == T(0)) != 0; };
+	auto same_level = [&](const RowRegs<T>& a, const RowRegs<T>& b) { return __all(a.c.z == b.c.z && a.zb == b.zb) != 0; };
 	{
 		const RowRegs<T> rs = load_row(y0 - 1);
 		const Side<T> sS = make_side_impl<STRICT, PL>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs, spec_bad);
 		sC = make_side_impl<STRICT, PL>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs, spec_bad);
 		dryS = (rs.c.z - rs.zb) < vs;
+		if (STILL_SKIP) {
+			if (at_rest(rs)) st |= REST_S;
+			if (at_rest(rc)) st |= REST_C;
+			if (st == (REST_S | REST_C) && same_level(rs, rc)) st |= EQ_S;
+		}
 		// both sides are asked for although only the north cell's is used: the tile below finishes this same face as
 		// ITS north face, and the two must take the same code path or results would depend on where tiles (and strip
 		// boundaries) fall
@@ -814,8 +849,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 		State4<T> out = rc.c;
 		bool write = out_x;
 		Side<T> sN = sC;
+		bool skip_cfl = false;
 
-		if (!skip_step) {
+		// still water (see above): one state across the wavefront, the same state north and south.  Staged: moving water pays for the
+		// two compares of `rest_n` only
+		const bool rest_n = STILL_SKIP && at_rest(rn);
+		const bool eq_n = STILL_SKIP && (st & REST_C) && rest_n && same_level(rc, rn);
+		bool still = false;
+		if (STILL_SKIP && !skip_step && eq_n && (st & (EQ_S | REST_S)) == (EQ_S | REST_S)) {
+			const T z_first = first_lane(rc.c.z), b_first = first_lane(rc.zb);
+			still = __all(rc.c.z == z_first && rc.zb == b_first && (rc.c.z - rc.zb) > vs &&
+			              !(rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0))) != 0;
+		}
+		st = (st & PRICED) | ((st & REST_C) ? REST_S : 0u) | (rest_n ? REST_C : 0u) | (eq_n ? EQ_S : 0u);
+
+		if (still) {
+			if (out.z > out.zmax && out.zmax > T(-9990.0)) out.zmax = out.z;              // :375-376, all that is left of the update
+			dryS = false;
+			// CFL epilogue: ONE state across the wave; if the still row below (the same state, by its own test) has priced it, pricing
+			// it again cannot change the maximum
+			skip_cfl = (st & PRICED) != 0;
+			if ((int)y >= tm.price_lo && (int)y < tm.price_hi && __any(out_x && out.zmax > T(-9999.0))) st |= PRICED;
+		} else if (!skip_step) {
+			st &= ~PRICED;
 			// east face first: its result has to travel to the next lane while the north face is solved
 			const Side<T> sE = side_from_east(sC);
 			const FacePair<T> fx = face_solve_impl<AXIS_X, STRICT, true, true, PL>(sC, sE, vs, spec_bad);
@@ -861,7 +917,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 		if (FUSED && fuse) stored = apply_fused(out, rc.zb, y);
 		buf_store_state(stored, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
 		if (TAIL == 2) store_peer(stored, y, write);
-		const bool priced = (int)y >= tm.price_lo && (int)y < tm.price_hi;       // wave-uniform
+		const bool priced = (int)y >= tm.price_lo && (int)y < tm.price_hi && !skip_cfl;       // wave-uniform
 		if (!priced) {
 		} else if (CFL_MODE == 1) {
 			if (write) {
@@ -914,6 +970,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 			}
 			dryS = dryC;
 			rc = rP; sC = sN; rP = rQ;
+			st = 0;                                     // (dry rows are not still WATER; the general loop finds out for itself)
 			++y;
 		}
 	}
