@@ -168,3 +168,46 @@ def test_strict_cell_sizes_that_are_and_are_not_powers_of_two(scheme, dx):
     assert np.array_equal(dom.download(), ref.download())
     assert dom.read_scalars()["time"] == ref.scalars()["t"]
     dom.close()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("quirks_off", [0, hp.QUIRK_CFL_READS_PRIMARY])
+def test_strict_still_water_rows_keep_the_reference_bits(precision, quirks_off):
+    """K1's STRICT flavour does not solve the faces of a row whose cells, and the rows north and south of it, hold ONE wet state
+    at rest (hp_kernels.hpp: STILL_SKIP).  Everything such a row still owes the reference is checked here against the oracle, bit
+    for bit, on a grid wide enough for whole wavefronts (62 columns) of still water: a lake at rest beside a dam break that
+    eats into it; Zmax below Z in part of the lake (it has to follow, CLSchemeGodunov.clc:375-376), Zmax = -9999 and a NODATA
+    cell in the lake (never updated, not priced); a deeper second lake whose wave speed the CFL epilogue must find although only
+    still rows hold it; and a step in the bed under still water (equal levels, different beds: NOT still)."""
+    real = np.float64 if precision == "f64" else np.float32
+    cols, rows = 400, 200
+    bed = np.zeros((rows, cols), real)
+    bed[0, :] = bed[-1, :] = bed[:, 0] = bed[:, -1] = 9999.9
+    z = np.full((rows, cols), 2.0, real)
+    z[:, 330:] = 0.5                                                      # the dam: everything east of column 330 is shallow
+    z[100:, :326] = 5.0; bed[100:, :326] = 1.0                            # a second, deeper lake on a higher bed (its own still rows)
+    bed[20:30, 130:160] = 0.25                                            # a bed step under the first lake: same level, other bed
+    zmax = z.copy()
+    zmax[5:15, 10:300] = 1.0                                              # has to follow Z up to 2.0
+    zmax[16:18, 10:300] = -9999.0                                         # disabled by Zmax
+    z[33, 200] = -9999.0                                                  # ... and by Z
+    st = np.zeros((rows, cols, 4), real)
+    st[..., 0] = np.where(bed > 9000, bed, z); st[..., 1] = np.where(bed > 9000, bed, zmax)
+    man = np.full((rows, cols), 0.03, real)
+    q = oracle.QUIRKS_REFERENCE & ~oracle.quirks_from_engine(quirks_off)
+    ref = oracle.OracleSim(cols, rows, scheme=GOD, precision=precision, quirks=q)
+    dom = hp.Domain(cols, rows, scheme=GOD, precision=precision, math_mode=hp.MATH_STRICT, quirks=hp.QUIRKS_REFERENCE & ~quirks_off)
+    for s in (ref, dom):
+        s.upload(st, bed, man)
+    dom.set_target_time(1e9); ref.set_target(1e9)
+    for n in (1, 2, 57):                                                  # batches cut at odd places (a disturbance travels one cell a step)
+        assert np.array_equal(dom.run(n), ref.run(n))
+        assert np.array_equal(dom.download(), ref.download())
+    out = dom.download()
+    assert np.all(out[5:15, 10:250, 1] == real(2.0)) and np.all(out[5:15, 10:250, 0] == real(2.0))   # Zmax followed, nothing else moved
+    assert np.all(out[16:18, 10:300, 1] == real(-9999.0))
+    assert np.abs(out[..., 2]).max() > 0.1                               # the dam really broke
+    assert np.all(out[165:195, 10:250, 2:] == 0) and np.all(out[165:195, 10:250, 0] == real(5.0))   # ... and the far lake is still still
+    sc, sr = dom.read_scalars(), ref.scalars()
+    assert sc["time"] == sr["t"] and sc["timestep"] == sr["dt"]
+    dom.close()
