@@ -969,6 +969,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 			nbands_out = 8;
 			int rseg = tallest;
 			while (rseg > shortest && groups * ((updated_rows + rseg - 1) / rseg) < 350) rseg /= 2;
+			if (rseg < shortest) rseg = shortest;
 			// Round 3: a launch whose blocks all fit the chip at once (a row strip of a strong-scaling run: 4096 x 514 is 544
 			// tiles of 16 rows on 768 block slots) lasts as long as ONE tile does, so the shortest tile that still fits in one
 			// round wins: 13-row tiles put that strip into 680 blocks (56 -> 51 us per iteration).  Fine-tune within
@@ -1034,17 +1035,26 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 			}
 			return rseg;
 		};
-		// fp32 rows are cheap enough for a tile's three-row fill and extra south face to show: 32-row tiles measured
-		// 13 % (S-DAM) to 47 % (S-RAIN 8192^2) ahead of 16; fp64 is flat or slightly worse beyond 18
-		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? 32 : 16, 2, desc->precision == 4 ? 5 : 3, d->march_nbands,
+		// fp32 (round 4, profiles/r04za_rseg_f32.txt, r04z_band_sweep_f32_shapes.txt): a tile's fill and extra south face want tall
+		// tiles, the dispatcher wants many -- 32 rows is best only where that still leaves six rounds of blocks (8192^2: 6.8); below
+		// that shorter tiles win by more than the fill costs: 4096^2 S-DAM 0.143 -> 0.129 ms and S-RAIN 0.180 -> 0.168 at 12 rows,
+		// the 8192 x 1026 strip of config C5 0.113 -> 0.089 ms (S-RAIN) and 83 -> 66 us (S-DAM); 8 rows lose again.  (Round 2's "32
+		// rows, 13-47 % ahead of 16" was measured on kernels with a dearer fill.)  fp64 is flat from 10 to 20 rows.
+		auto tallest_f32 = [&](long updated_rows, long updated_cols, int tile_cols, int blocks_per_cu) {
+			const long groups = ((updated_cols + tile_cols - 1) / tile_cols + 3) / 4, band_rows = (updated_rows + 7) / 8;
+			for (int r : {32, 24, 16})
+				if (groups * 8 * ((band_rows + r - 1) / r) >= 6L * cus * blocks_per_cu) return r;
+			return 12;
+		};
+		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? tallest_f32(desc->rows - 2, desc->cols - 2, MARCH_COLS, 5) : 16, 2, desc->precision == 4 ? 5 : 3, d->march_nbands,
 		                        desc->precision == 8 || std::getenv("HP_TILING_SEARCH_F32") != nullptr);      // (fp32: 8192 x 1026 measured 83.2 -> 84.4 us with the searched tiling: its fill is not 3.5 rows)
 		d->inertial_rseg = d->march_rseg; d->inertial_nbands = d->march_nbands;
 		// K2 after the inert-row cut (round 2): a tile of still water or dry land costs a fifth of a tile on the flood front,
 		// so fp64 wants more, shorter tiles for the dispatcher to balance (16-20 rows: 0.319 ms against 0.355 at 32 on the
-		// 4096^2 dam break, 0.355 against 0.395 on the developed flood, +2-5 % at 8192^2 and 16384 x 1028); fp32 stays at 32
+		// 4096^2 dam break, 0.355 against 0.395 on the developed flood, +2-5 % at 8192^2 and 16384 x 1028)
 		// (round 4, profiles/r04l_k2_rseg.txt: 12 rows: the 4096^2 dam break 0.300 -> 0.287 ms, developed flood 0.343 -> 0.340, 2048^2 -1.4 %,
-		// 8192^2 +0.6 %, every tile live +1.7 %; 10 and below lose again)
-		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? 32 : 12, 4, desc->precision == 4 ? 4 : 3, d->muscl_nbands,
+		// 8192^2 +0.6 %, every tile live +1.7 %; 10 and below lose again; fp32: as K1 -- 4096^2 dam break 0.192 -> 0.161 ms at 12 rows)
+		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? tallest_f32(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 4) : 12, 4, desc->precision == 4 ? 4 : 3, d->muscl_nbands,
 		                        false);                     // (K2's tiles differ fivefold in cost -- inert rows --: the searched tiling lost 20 % on the 4096 x 514 dam break)
 		if (d->muscl_rseg < 4) d->muscl_rseg = 4;
 	}

@@ -41,9 +41,11 @@ print("default tiling (search off):", run_default(0))
 if os.environ.get("SWEEP", "1") == "0":
     sys.exit(0)
 upd = rows - 2 * g
-for nb in (8, 5, 6, 10, 12, 15, 30):
+NBS = [int(v) for v in os.environ.get("SWEEP_NB", "8,5,6,10,12,15,30").split(",")]
+RSEGS = [int(v) for v in os.environ.get("SWEEP_RSEG", "9,11,13,15,16,17,18,19,22,26").split(",")]
+for nb in NBS:
     line = []
-    for rseg in (9, 11, 13, 15, 16, 17, 18, 19, 22, 26):
+    for rseg in RSEGS:
         band = (upd + nb - 1) // nb
         if rseg > band: continue
         blocks = nb * groups * ((band + rseg - 1) // rseg)
