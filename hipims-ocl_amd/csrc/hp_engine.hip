@@ -1040,13 +1040,24 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		// that shorter tiles win by more than the fill costs: 4096^2 S-DAM 0.143 -> 0.129 ms and S-RAIN 0.180 -> 0.168 at 12 rows,
 		// the 8192 x 1026 strip of config C5 0.113 -> 0.089 ms (S-RAIN) and 83 -> 66 us (S-DAM); 8 rows lose again.  (Round 2's "32
 		// rows, 13-47 % ahead of 16" was measured on kernels with a dearer fill.)  fp64 is flat from 10 to 20 rows.
-		auto tallest_f32 = [&](long updated_rows, long updated_cols, int tile_cols, int blocks_per_cu) {
+		// fp64 (profiles/r04zc_rseg_f64_shapes.txt): flat from 10 to 20 rows where a launch is many rounds (4096^2, 16384 x 1026); between
+		// one round and 2.5 (2048^2, 4096 x 1026, 8192 x 1026 ...) 12 rows are 5-9 % ahead of 16 for K1, 10 rows 5-7 % ahead of 12 for K2.
+		const bool f32 = desc->precision == 4;
+		auto tallest_by_rounds = [&](long updated_rows, long updated_cols, int tile_cols, int blocks_per_cu, std::initializer_list<int> tall,
+		                             double rounds, int otherwise) {
 			const long groups = ((updated_cols + tile_cols - 1) / tile_cols + 3) / 4, band_rows = (updated_rows + 7) / 8;
-			for (int r : {32, 24, 16})
-				if (groups * 8 * ((band_rows + r - 1) / r) >= 6L * cus * blocks_per_cu) return r;
-			return 12;
+			// (fp64: a launch that fits the chip in about ONE round at the classic height belongs to the one-round logic inside pick();
+			// the 4096 x 516 MUSCL strip, 1.1 rounds at 12 rows, measured 3 % behind with 10)
+			if (!f32 && (double)(groups * 8 * ((band_rows + *tall.begin() - 1) / *tall.begin())) <= 1.25 * cus * blocks_per_cu) return *tall.begin();
+			for (int r : tall)
+				if ((double)(groups * 8 * ((band_rows + r - 1) / r)) >= rounds * cus * blocks_per_cu) return r;
+			return otherwise;
 		};
-		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, desc->precision == 4 ? tallest_f32(desc->rows - 2, desc->cols - 2, MARCH_COLS, 5) : 16, 2, desc->precision == 4 ? 5 : 3, d->march_nbands,
+		const int k1_tallest = f32 ? tallest_by_rounds(desc->rows - 2, desc->cols - 2, MARCH_COLS, 5, {32, 24, 16}, 6.0, 12)
+		                           : tallest_by_rounds(desc->rows - 2, desc->cols - 2, MARCH_COLS, 3, {16}, 2.5, 12);
+		const int k2_tallest = f32 ? tallest_by_rounds(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 4, {32, 24, 16}, 6.0, 12)
+		                           : tallest_by_rounds(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 3, {12}, 3.0, 10);
+		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, k1_tallest, 2, desc->precision == 4 ? 5 : 3, d->march_nbands,
 		                        desc->precision == 8 || std::getenv("HP_TILING_SEARCH_F32") != nullptr);      // (fp32: 8192 x 1026 measured 83.2 -> 84.4 us with the searched tiling: its fill is not 3.5 rows)
 		d->inertial_rseg = d->march_rseg; d->inertial_nbands = d->march_nbands;
 		// K2 after the inert-row cut (round 2): a tile of still water or dry land costs a fifth of a tile on the flood front,
@@ -1054,7 +1065,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		// 4096^2 dam break, 0.355 against 0.395 on the developed flood, +2-5 % at 8192^2 and 16384 x 1028)
 		// (round 4, profiles/r04l_k2_rseg.txt: 12 rows: the 4096^2 dam break 0.300 -> 0.287 ms, developed flood 0.343 -> 0.340, 2048^2 -1.4 %,
 		// 8192^2 +0.6 %, every tile live +1.7 %; 10 and below lose again; fp32: as K1 -- 4096^2 dam break 0.192 -> 0.161 ms at 12 rows)
-		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, desc->precision == 4 ? tallest_f32(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 4) : 12, 4, desc->precision == 4 ? 4 : 3, d->muscl_nbands,
+		d->muscl_rseg    = pick(desc->rows - 4, desc->cols - 4, MUSCL_COLS, k2_tallest, 4, desc->precision == 4 ? 4 : 3, d->muscl_nbands,
 		                        false);                     // (K2's tiles differ fivefold in cost -- inert rows --: the searched tiling lost 20 % on the 4096 x 514 dam break)
 		if (d->muscl_rseg < 4) d->muscl_rseg = 4;
 	}
