@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void k_march_halo(const d2* __restrict__ src, 
 	if (a[0].x + a[1].x == 1.2345e-300) dst[0] = a[0];                             // keep the trailing halo loads alive
 }
 
+extern __shared__ char march_lds[];
 template <int DEPTH, bool CONTIG>
 __global__ __launch_bounds__(256) void k_march(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst,
                                                int cols, int rows, int rseg, int groups, int ntiles)
@@ -159,6 +160,49 @@ __global__ __launch_bounds__(256) void k_march(const d2* __restrict__ src, const
 			else        { dst[(cell + lane) * 2] = va; dst[(cell + lane) * 2 + 1] = vb; }
 		}
 	}
+}
+
+
+// round 4: the march copy in K1's exact shape, one ingredient at a time.  WIN62: a wave's window starts at column 62 * strip (every
+// other window is 64 B off the 128-B lines) and the windows overlap by two columns; EDGE: lanes 0 and 63 do not store (the stores
+// of a row leave the first and the last 128-B line partly written, the neighbouring wave writes the rest); HALO: one row below and
+// one above the tile are read as well.
+template <bool WIN62, bool EDGE, bool HALO>
+__global__ __launch_bounds__(256) void k_march_k1(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst,
+                                                  int cols, int rows, int rseg, int groups, int ntiles)
+{
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int strip = (tile % groups) * 4 + wave, seg = tile / groups;
+	if (tile >= (unsigned)ntiles) return;
+	const int x0 = strip * (WIN62 ? 62 : 64);
+	if (x0 >= cols) return;
+	const int x = min(x0 + lane, cols - 1);
+	const bool st = (!EDGE || (lane >= 1 && lane <= 62)) && x0 + lane < cols;
+	const int y0 = seg * rseg, y1 = min(y0 + rseg, rows);
+	d2 a[2], b[2]; double z[2];
+	auto load = [&](int y, int slot) {
+		y = min(max(y, 0), rows - 1);
+		const size_t cell = (size_t)y * cols + x;
+		a[slot] = src[cell * 2]; b[slot] = src[cell * 2 + 1];
+		z[slot] = bed[cell];
+	};
+	double acc = 0;
+	if (HALO) { load(y0 - 1, 0); acc += a[0].x + b[0].y + z[0]; }
+	load(y0, 0); load(y0 + 1, 1);
+	for (int y = y0; y < y1; y += 2) {
+		#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			if (y + k >= y1) break;
+			d2 va = a[k], vb = b[k]; const double zz = z[k];
+			load(y + k + 2 < y1 + (HALO ? 1 : 0) ? y + k + 2 : y1 + (HALO ? 1 : 0) - 1, k);
+			va.x += (zz + acc) * 1e-300;
+			const size_t cell = (size_t)(y + k) * cols + x;
+			if (st) { dst[cell * 2] = va; dst[cell * 2 + 1] = vb; }
+		}
+	}
+	if (a[0].x + a[1].x == 1.2345e-300) dst[0] = a[0];
 }
 
 int main(int argc, char** argv)
@@ -236,6 +280,46 @@ int main(int argc, char** argv)
 		timeit(nm, [&] { hipLaunchKernelGGL((k_march<4, false>), dim3(blocks), dim3(256), 0, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
 		snprintf(nm, sizeof nm, "march lane-contiguous, depth 4, rseg=%d", rseg);
 		timeit(nm, [&] { hipLaunchKernelGGL((k_march<4, true>), dim3(blocks), dim3(256), 0, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+	}
+	// round 4: the march shape at K1's occupancy.  K1 runs 3 waves per SIMD (147 VGPRs) with ONE row in flight per wave while it
+	// computes; the kernels above run 8 waves per SIMD.  Dynamic LDS caps the blocks per CU (a block = 4 waves = one per SIMD):
+	// 52 KiB -> 3 blocks, 36 KiB -> 4, 28 KiB -> 5.  How much of the march copy's rate needs more bytes in flight than that?
+	{
+		CK(hipFuncSetAttribute((const void*)k_march<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+		CK(hipFuncSetAttribute((const void*)k_march<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+		CK(hipFuncSetAttribute((const void*)k_march<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+		CK(hipFuncSetAttribute((const void*)k_march<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+		for (int lds_kib : {52, 36, 28, 0}) for (int rseg : {16, 18}) {
+			const int groups = cols / 64 / 4, nsegs = (rows + rseg - 1) / rseg, ntiles = groups * nsegs;
+			const unsigned blocks = (ntiles + 7) / 8 * 8;
+			const int waves = lds_kib == 52 ? 3 : lds_kib == 36 ? 4 : lds_kib == 28 ? 5 : 8;
+			char nm[160];
+			snprintf(nm, sizeof nm, "march, %d waves/SIMD, rows in flight 1, rseg=%d", waves, rseg);
+			timeit(nm, [&] { hipLaunchKernelGGL((k_march<1, false>), dim3(blocks), dim3(256), lds_kib * 1024, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+			snprintf(nm, sizeof nm, "march, %d waves/SIMD, rows in flight 2, rseg=%d", waves, rseg);
+			timeit(nm, [&] { hipLaunchKernelGGL((k_march<2, false>), dim3(blocks), dim3(256), lds_kib * 1024, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+			snprintf(nm, sizeof nm, "march, %d waves/SIMD, rows in flight 3, rseg=%d", waves, rseg);
+			timeit(nm, [&] { hipLaunchKernelGGL((k_march<3, false>), dim3(blocks), dim3(256), lds_kib * 1024, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+			snprintf(nm, sizeof nm, "march, %d waves/SIMD, rows in flight 4, rseg=%d", waves, rseg);
+			timeit(nm, [&] { hipLaunchKernelGGL((k_march<4, false>), dim3(blocks), dim3(256), lds_kib * 1024, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+		}
+	}
+	{
+		// K1's shape, ingredient by ingredient (3 waves per SIMD through 52 KiB of dynamic LDS, 18-row tiles)
+		const int rseg = 18, lds = 52 * 1024;
+		auto run = [&](const char* what, auto kern, int width) {
+			CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+			const int strips = (cols + width - 1) / width, groups = (strips + 3) / 4, nsegs = (rows + rseg - 1) / rseg, ntiles = groups * nsegs;
+			const unsigned blocks = (ntiles + 7) / 8 * 8;
+			timeit(what, [&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+		};
+		for (int rep = 0; rep < 2; ++rep) {
+			run("K1 shape: 64-col windows", k_march_k1<false, false, false>, 64);
+			run("K1 shape: 64-col windows + halo rows", k_march_k1<false, false, true>, 64);
+			run("K1 shape: 62-col windows (all lanes store)", k_march_k1<true, false, false>, 62);
+			run("K1 shape: 62-col windows, edge lanes silent", k_march_k1<true, true, false>, 62);
+			run("K1 shape: 62-col, edge silent, halo rows", k_march_k1<true, true, true>, 62);
+		}
 	}
 	return 0;
 }
