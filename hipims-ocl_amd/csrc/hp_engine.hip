@@ -425,21 +425,25 @@ static unsigned tail_limit_k2k6()
 	return std::min(tail_limit(), v);
 }
 
-// Alternating sweep direction (an experiment kept behind HP_SWEEP_ALTERNATE=1; off by default).  A launch leaves the last ~250 MiB
-// it loaded or stored in the Infinity Cache (256 MiB, stores allocate: MI355X_MICROARCH.md), and what it stored last is the top of
-// every row band -- exactly what the NEXT launch, which reads the state this one wrote, would reach last.  With the knob every
-// other whole-domain launch visits each band's tiles from the top down (TileMap::flip: the same tiles mirrored within the band), so
-// that it starts on rows whose new state and bed may still be on the die.  Pure scheduling: which wavefront solves a face never
-// changes its bits.  Measured (profiles/r04w_still_and_sweep_ab.txt, same box): fp32 S-DAM +4 %, S-RAIN / S-ROUGH +1.5 %, but fp64
-// S-DAM 4096^2 -4 % and the 16384 x 1026 strip -5 %: not the default.
-inline bool sweep_alternates()
+// Alternating sweep direction.  A launch leaves the last ~250 MiB it loaded or stored in the Infinity Cache (256 MiB, stores
+// allocate: MI355X_MICROARCH.md), and what it stored last is the top of every row band -- exactly what the NEXT launch, which reads
+// the state this one wrote, would reach last.  Every other whole-domain launch therefore visits each band's tiles from the top down
+// (TileMap::flip: the same tiles mirrored within the band): it starts on rows whose new state and bed may still be on the die.  Pure
+// scheduling: which wavefront solves a face never changes its bits.  Measured (profiles/r04zv_sweep_alternate_again.txt,
+// r04zw_sweep_alternate_f64.txt; same box, interleaved): fp32, whose launch is 0.6 GB: S-DAM 4096^2 +5 %, S-RAIN +2.5 %, S-ROUGH
+// +3 %, MUSCL +2.3 %, 8192^2 +0.7 %; fp64 MUSCL +2.5 % on the dam break, +0.5 % on live water; fp64 Godunov and inertial: 0 to -3 %
+// (2048^2, 16384 x 1026, 16384 x 8192) and erratic at 4096^2 and 8192^2.  Box-dependent: a third box showed no difference at all
+// for fp32 (0.1290 / 0.1300 / 0.1291 ms).  So: on for fp32 and for fp64 MUSCL, where it was never behind; off for fp64 Godunov /
+// inertial; HP_SWEEP_ALTERNATE=0 / 1 forces it.
+inline bool sweep_alternates(const hp_domain* d)
 {
-	static const bool on = std::getenv("HP_SWEEP_ALTERNATE") && std::atoi(std::getenv("HP_SWEEP_ALTERNATE")) != 0;
-	return on;
+	static const int forced = std::getenv("HP_SWEEP_ALTERNATE") ? (std::atoi(std::getenv("HP_SWEEP_ALTERNATE")) != 0 ? 1 : 0) : -1;
+	if (forced >= 0) return forced != 0;
+	return d->desc.precision == 4 || d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK;
 }
 inline void sweep_direction(hp_domain* d, const int part, TileMap& tm)
 {
-	if (part != PART_ALL || !sweep_alternates()) return;
+	if (part != PART_ALL || !sweep_alternates(d)) return;
 	tm.flip = d->sweep_flip;
 	d->sweep_flip ^= 1;
 }
