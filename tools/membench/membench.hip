@@ -205,6 +205,41 @@ __global__ __launch_bounds__(256) void k_march_k1(const d2* __restrict__ src, co
 	if (a[0].x + a[1].x == 1.2345e-300) dst[0] = a[0];
 }
 
+
+// round 4: does keeping the four waves of a block on the SAME row (a barrier per row: 8 KB contiguous per row and block instead of
+// four drifting 2-KB streams) help the march?  WAVES: waves per block (4 or 8: 256 or 512 columns per block).
+template <int WAVES, bool SYNC>
+__global__ __launch_bounds__(WAVES * 64) void k_march_sync(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst,
+                                                            int cols, int rows, int rseg, int groups, int ntiles)
+{
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int strip = (tile % groups) * WAVES + wave, seg = tile / groups;
+	if (tile >= (unsigned)ntiles) return;
+	const int x0 = strip * 64;
+	const bool live = x0 < cols;
+	const int x = min(x0 + lane, cols - 1);
+	const int y0 = seg * rseg, y1 = min(y0 + rseg, rows);
+	d2 a[2], b[2]; double z[2];
+	auto load = [&](int y, int slot) {
+		y = min(max(y, 0), rows - 1);
+		const size_t cell = (size_t)y * cols + x;
+		a[slot] = src[cell * 2]; b[slot] = src[cell * 2 + 1];
+		z[slot] = bed[cell];
+	};
+	load(y0, 0);
+	for (int y = y0; y < y1; ++y) {
+		const int k = (y - y0) & 1;
+		if (SYNC) __syncthreads();
+		load(y + 1 < y1 ? y + 1 : y1 - 1, k ^ 1);
+		d2 va = a[k], vb = b[k]; const double zz = z[k];
+		va.x += zz * 1e-300;
+		const size_t cell = (size_t)y * cols + x;
+		if (live) { dst[cell * 2] = va; dst[cell * 2 + 1] = vb; }
+	}
+}
+
 int main(int argc, char** argv)
 {
 	const int cols = 4096, rows = argc > 1 ? atoi(argv[1]) : 4096;
@@ -313,6 +348,18 @@ int main(int argc, char** argv)
 			const unsigned blocks = (ntiles + 7) / 8 * 8;
 			timeit(what, [&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
 		};
+		auto run_sync = [&](const char* what, auto kern, int waves, int lds_bytes) {
+			CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+			const int strips = cols / 64, groups = (strips + waves - 1) / waves, nsegs = (rows + 16 - 1) / 16, ntiles = groups * nsegs;
+			const unsigned blocks = (ntiles + 7) / 8 * 8;
+			timeit(what, [&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds_bytes, 0, src, bed, dst, cols, rows, 16, groups, ntiles); });
+		};
+		for (int rep = 0; rep < 2; ++rep) {
+			run_sync("march 16 rows, 3 waves/SIMD, 4-wave blocks, free", k_march_sync<4, false>, 4, 52 * 1024);
+			run_sync("march 16 rows, 3 waves/SIMD, 4-wave blocks, barrier per row", k_march_sync<4, true>, 4, 52 * 1024);
+			run_sync("march 16 rows, 8-wave blocks (2 per CU = 4 waves/SIMD), free", k_march_sync<8, false>, 8, 64 * 1024);
+			run_sync("march 16 rows, 8-wave blocks, barrier per row", k_march_sync<8, true>, 8, 64 * 1024);
+		}
 		for (int rep = 0; rep < 2; ++rep) {
 			run("K1 shape: 64-col windows", k_march_k1<false, false, false>, 64);
 			run("K1 shape: 64-col windows + halo rows", k_march_k1<false, false, true>, 64);
