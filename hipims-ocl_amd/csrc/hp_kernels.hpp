@@ -623,7 +623,8 @@ template <typename T> struct FusedBdy {
 // the next iteration whether there is anything left for it to do.
 // waves per SIMD the register allocator is asked to make room for (as muscl_waves below): fp64 runs three (FAST needs 147
 // VGPRs; STRICT with the shared reciprocals of round 4 would take 181 if left alone -- the scheduler interleaves the quotient
-// chains -- and lose the third wave)
+// chains -- and lose the third wave; STRICT at TWO waves, no spills, measured 5.5 % behind three waves with 30-44 spilled registers:
+// profiles/r04s_dpp_rotate_and_k1_strict_waves_ab.txt, -DHP_K1_STRICT_WAVES=2)
 #ifndef HP_K1_STRICT_WAVES
 #define HP_K1_STRICT_WAVES 3
 #endif
