@@ -240,6 +240,36 @@ __global__ __launch_bounds__(WAVES * 64) void k_march_sync(const d2* __restrict_
 	}
 }
 
+
+// round 4: the march over a TILED layout -- a wave's tile (64 columns x rseg rows) contiguous in memory, row after row: what a
+// device-side layout change would buy the marching kernels (the bytes and the march are the same; only the addresses differ)
+__global__ __launch_bounds__(256) void k_march_tiled(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst,
+                                                     int cols, int rows, int rseg, int groups, int ntiles)
+{
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (tile >= (unsigned)ntiles) return;
+	const size_t wtile = (size_t)tile * 4 + wave;                  // this wave's tile
+	const size_t base = wtile * (size_t)rseg * 64;                // in cells
+	if (base + (size_t)rseg * 64 > (size_t)cols * rows) return;
+	d2 a[2], b[2]; double z[2];
+	auto load = [&](int r, int slot) {
+		const size_t cell = base + (size_t)min(r, rseg - 1) * 64 + lane;
+		a[slot] = src[cell * 2]; b[slot] = src[cell * 2 + 1];
+		z[slot] = bed[cell];
+	};
+	load(0, 0);
+	for (int r = 0; r < rseg; ++r) {
+		const int k = r & 1;
+		load(r + 1, k ^ 1);
+		d2 va = a[k], vb = b[k]; const double zz = z[k];
+		va.x += zz * 1e-300;
+		const size_t cell = base + (size_t)r * 64 + lane;
+		dst[cell * 2] = va; dst[cell * 2 + 1] = vb;
+	}
+}
+
 int main(int argc, char** argv)
 {
 	const int cols = 4096, rows = argc > 1 ? atoi(argv[1]) : 4096;
@@ -354,6 +384,14 @@ int main(int argc, char** argv)
 			const unsigned blocks = (ntiles + 7) / 8 * 8;
 			timeit(what, [&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds_bytes, 0, src, bed, dst, cols, rows, 16, groups, ntiles); });
 		};
+		for (int rep = 0; rep < 2; ++rep) for (int rseg : {16, 18, 32}) {
+			CK(hipFuncSetAttribute((const void*)k_march_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+			const int groups = cols / 64 / 4, nsegs = rows / rseg, ntiles = groups * nsegs;
+			const unsigned blocks = (ntiles + 7) / 8 * 8;
+			char nm[128];
+			snprintf(nm, sizeof nm, "march over a TILED layout, 3 waves/SIMD, rseg=%d", rseg);
+			timeit(nm, [&] { hipLaunchKernelGGL(k_march_tiled, dim3(blocks), dim3(256), 52 * 1024, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+		}
 		for (int rep = 0; rep < 2; ++rep) {
 			run_sync("march 16 rows, 3 waves/SIMD, 4-wave blocks, free", k_march_sync<4, false>, 4, 52 * 1024);
 			run_sync("march 16 rows, 3 waves/SIMD, 4-wave blocks, barrier per row", k_march_sync<4, true>, 4, 52 * 1024);
