@@ -270,6 +270,42 @@ __global__ __launch_bounds__(256) void k_march_tiled(const d2* __restrict__ src,
 	}
 }
 
+
+// round 4: the row-major march with the XCDs' column order SKEWED (XCD k starts k/8 of the way along the row): do the eight bands,
+// whose rows lie 64 MB apart, step on each other's channels when they walk the same columns at the same time?
+template <int SKEW>
+__global__ __launch_bounds__(256) void k_march_skew(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst,
+                                                    int cols, int rows, int rseg, int groups, int ntiles)
+{
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned xcd = blockIdx.x & 7u;
+	const unsigned tile = xcd * per_xcd + (blockIdx.x >> 3);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (tile >= (unsigned)ntiles) return;
+	int g = tile % groups;
+	if (SKEW == 1) g = (g + (int)xcd * groups / 8) % groups;
+	if (SKEW == 2) g = (g + (int)xcd * 3) % groups;
+	const int strip = g * 4 + wave, seg = tile / groups;
+	const int x0 = strip * 64;
+	if (x0 >= cols) return;
+	const int y0 = seg * rseg, y1 = min(y0 + rseg, rows);
+	d2 a[2], b[2]; double z[2];
+	auto load = [&](int y, int slot) {
+		const size_t cell = (size_t)min(y, rows - 1) * cols + x0 + lane;
+		a[slot] = src[cell * 2]; b[slot] = src[cell * 2 + 1];
+		z[slot] = bed[cell];
+	};
+	load(y0, 0);
+	for (int y = y0; y < y1; ++y) {
+		const int k = (y - y0) & 1;
+		load(y + 1, k ^ 1);
+		d2 va = a[k], vb = b[k]; const double zz = z[k];
+		va.x += zz * 1e-300;
+		const size_t cell = (size_t)y * cols + x0 + lane;
+		dst[cell * 2] = va; dst[cell * 2 + 1] = vb;
+	}
+}
+
 int main(int argc, char** argv)
 {
 	const int cols = 4096, rows = argc > 1 ? atoi(argv[1]) : 4096;
@@ -384,6 +420,16 @@ int main(int argc, char** argv)
 			const unsigned blocks = (ntiles + 7) / 8 * 8;
 			timeit(what, [&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds_bytes, 0, src, bed, dst, cols, rows, 16, groups, ntiles); });
 		};
+		for (int rep = 0; rep < 3; ++rep) {
+			const int rseg = 16, groups = cols / 64 / 4, nsegs = rows / rseg, ntiles = groups * nsegs;
+			const unsigned blocks = (ntiles + 7) / 8 * 8;
+			CK(hipFuncSetAttribute((const void*)k_march_skew<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+			CK(hipFuncSetAttribute((const void*)k_march_skew<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+			CK(hipFuncSetAttribute((const void*)k_march_skew<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+			timeit("march 16 rows, XCD column order: same", [&] { hipLaunchKernelGGL(k_march_skew<0>, dim3(blocks), dim3(256), 52 * 1024, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+			timeit("march 16 rows, XCD column order: skewed by 1/8 row", [&] { hipLaunchKernelGGL(k_march_skew<1>, dim3(blocks), dim3(256), 52 * 1024, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+			timeit("march 16 rows, XCD column order: skewed by 3 groups", [&] { hipLaunchKernelGGL(k_march_skew<2>, dim3(blocks), dim3(256), 52 * 1024, 0, src, bed, dst, cols, rows, rseg, groups, ntiles); });
+		}
 		for (int rep = 0; rep < 2; ++rep) for (int rseg : {16, 18, 32}) {
 			CK(hipFuncSetAttribute((const void*)k_march_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
 			const int groups = cols / 64 / 4, nsegs = rows / rseg, ntiles = groups * nsegs;
