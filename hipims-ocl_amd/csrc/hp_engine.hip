@@ -1115,6 +1115,8 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	HIP_TRY_C(hipMalloc(&d->manning, d->cells * d->esize));
 	HIP_TRY_C(hipMalloc(&d->scalars, 256));
 	HIP_TRY_C(hipMalloc(&d->cfl_slot, CFL_SLOT_BYTES));
+	if (std::getenv("HP_PRINT_BUFFERS"))
+		std::fprintf(stderr, "[hipims_mi] buffers: state[0] %p state[1] %p bed %p manning %p\n", d->state[0], d->state[1], d->bed, d->manning);
 
 	HIP_TRY_C(hipMalloc((void**)&d->tail_words, (TAIL_MAX_BLOCKS + 8) * sizeof(unsigned long long)));
 	HIP_TRY_C(hipMemset(d->tail_words, 0xff, (TAIL_MAX_BLOCKS + 8) * sizeof(unsigned long long)));      // every word EMPTY
