@@ -525,10 +525,22 @@ __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, co
 	const T dx  = T(1.0) + tx;
 	const T dy  = T(1.0) + ty;
 	T fx = sfx / dx, fy = sfy / dy;
-	T mx, my;
-	div2_strict<PLAIN>(-qx, -qy, dt, true, mx, my, bad);
-	if (qx >= T(0)) { if (fx < mx) fx = mx; } else { if (fx > mx) fx = mx; }
-	if (qy >= T(0)) { if (fy < my) fy = my; } else { if (fy > my) fy = my; }
+	// The clamps (:52-65) keep friction from REVERSING the flow: F is replaced by -q / dt where |F| exceeds |q| / dt.  The implicit
+	// denominators make |F| dt < |q| mathematically, so the clamp only ever acts through rounding, at |F| dt ~ |q|.  A lane whose
+	// |F| dt (1 + 2^-30), evaluated in floating point (two roundings: relative 2^-52), stays below |q| has |F| < (|q| / dt)(1 - 2^-31)
+	// < RN(|q| / dt) in exact arithmetic: neither `F < m` nor `F > m` can hold, whatever the quotient's last bit is; F = +-0 cannot
+	// be clamped either (m has the opposite sign of q or is a zero).  Where every active lane of the wavefront is such a lane the two
+	// quotients -qx / dt, -qy / dt are not needed -- the same bits without them (round 4; NaN or overflow fail the test and take
+	// the reference's statements).
+	const T margin = T(1) + (sizeof(T) == 8 ? T(9.313225746154785e-10) : T(6.103515625e-05));   // 1 + 2^-30 (fp64), 1 + 2^-14 (fp32)
+	const bool free_x = (fabs_(fx) * dt) * margin < fabs_(qx) || fx == T(0);
+	const bool free_y = (fabs_(fy) * dt) * margin < fabs_(qy) || fy == T(0);
+	if (!__all(free_x && free_y)) {
+		T mx, my;
+		div2_strict<PLAIN>(-qx, -qy, dt, true, mx, my, bad);
+		if (qx >= T(0)) { if (fx < mx) fx = mx; } else { if (fx > mx) fx = mx; }
+		if (qy >= T(0)) { if (fy < my) fy = my; } else { if (fy > my) fy = my; }
+	}
 	qx = qx + dt * fx;
 	qy = qy + dt * fy;
 }
