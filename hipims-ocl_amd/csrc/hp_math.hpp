@@ -938,14 +938,14 @@ __device__ __forceinline__ T cfl_speed_impl(const T z, const T zmax, const T qx,
 		if (simplified)                                       // :205-210 (partial-inertial scheme)
 			return STRICT ? sqrt_(gravity<T>() * h) : sqrt_fast(gravity<T>() * h);
 		if (STRICT) {
-			T vx, vy;
-			div2_strict<PLAIN>(qx, qy, h, true, vx, vy, bad);
-			spec_raise<PLAIN>(bad, spec_word);
-			if (vx < T(0)) vx = -vx;
-			if (vy < T(0)) vy = -vy;
-			const T a = sqrt_(gravity<T>() * h);
-			vx += a; vy += a;
-			return (vx < vy) ? vy : vx;
+			// max(|qx / h| + a, |qy / h| + a) (:222-236) with ONE quotient: IEEE rounding is monotonic and symmetric in sign, so for
+			// h > 0 the larger magnitude has the larger (or equal) rounded quotient, |RN(q / h)| = RN(|q| / h), and adding the same
+			// `a` keeps the order -- the value the reference's two quotients, two negations and final select deliver, bit for bit
+			// (a NaN discharge takes the same way through the compare as through the reference's `vx < vy`).
+			(void)bad; (void)spec_word;
+			const T ax = fabs_(qx), ay = fabs_(qy);
+			const T m = (ax < ay) ? ay : ax;
+			return m / h + sqrt_(gravity<T>() * h);
 		} else {
 			const T inv = rcp_fast(h);
 			return fmax_(fabs_(qx), fabs_(qy)) * inv + sqrt_fast(gravity<T>() * h);
