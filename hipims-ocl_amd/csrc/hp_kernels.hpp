@@ -628,7 +628,11 @@ template <typename T> struct FusedBdy {
 #ifndef HP_K1_STRICT_WAVES
 #define HP_K1_STRICT_WAVES 3
 #endif
-template <bool STRICT, typename T> constexpr int march_waves() { return sizeof(T) == 4 ? 5 : (STRICT ? HP_K1_STRICT_WAVES : 3); }
+// (FAST at FOUR waves: 128 VGPRs, 28-70 spilled, S-DAM 0.25 -> 0.35 ms, S-RAIN 0.32 -> 0.49: -DHP_K1_FAST_WAVES=4, round 4)
+#ifndef HP_K1_FAST_WAVES
+#define HP_K1_FAST_WAVES 3
+#endif
+template <bool STRICT, typename T> constexpr int march_waves() { return sizeof(T) == 4 ? 5 : (STRICT ? HP_K1_STRICT_WAVES : HP_K1_FAST_WAVES); }
 
 // SPEC (STRICT fp64 only): the speculative flavour of a STRICT batch -- quotients that share a denominator share its refined
 // reciprocal (hp_math.hpp: div_shared), a lane whose operands fall outside what that covers raises the domain's SLOT_SPEC
