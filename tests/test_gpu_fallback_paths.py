@@ -3,7 +3,9 @@ HP_LAUNCH_TAIL=0 -- the flux launch without its own tail block: atomic maxima + 
 launch_tail); HP_FUSE_BDY=0 -- rain / loss as the stand-alone boundary pass instead of the flux kernel's store
 epilogue (K5).  (HP_PEER_DIRECT=0, ghost rows through the collective library's send / receive, is the peer_max = 1 leg of
 tests/test_gpu_strips.py::test_cxx_strip_loop_with_several_ranks.)  Each leg: all three schemes, fp64 and fp32, uniform and
-coarse gridded rain, a sync point inside the run, ragged batches -- STRICT, bit for bit against the oracle."""
+coarse gridded rain, a sync point inside the run, ragged batches -- STRICT, bit for bit against the oracle.
+Round 4: HP_SWEEP_ALTERNATE=1 / 0 -- every other whole-domain launch visiting each band's tiles from the top down (TileMap::flip;
+the default is on for fp32 and fp64 MUSCL only), forced on for every kernel and forced off."""
 import os
 import subprocess
 import sys
@@ -14,8 +16,9 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(os.path.dirname(__file__), "fallback_worker.py")
 
 
-@pytest.mark.parametrize("env", [{}, {"HP_LAUNCH_TAIL": "0"}, {"HP_FUSE_BDY": "0"}, {"HP_LAUNCH_TAIL": "0", "HP_FUSE_BDY": "0"}],
-                         ids=["default", "no-tail-block", "stand-alone-rain", "both-off"])
+@pytest.mark.parametrize("env", [{}, {"HP_LAUNCH_TAIL": "0"}, {"HP_FUSE_BDY": "0"}, {"HP_LAUNCH_TAIL": "0", "HP_FUSE_BDY": "0"},
+                                 {"HP_SWEEP_ALTERNATE": "1"}, {"HP_SWEEP_ALTERNATE": "0"}],
+                         ids=["default", "no-tail-block", "stand-alone-rain", "both-off", "every-launch-pair-swept-both-ways", "never-flipped"])
 def test_switched_off_variants_equal_the_oracle(env):
     r = subprocess.run([sys.executable, WORKER], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stdout + r.stderr
