@@ -632,7 +632,10 @@ template <typename T> struct FusedBdy {
 #ifndef HP_K1_FAST_WAVES
 #define HP_K1_FAST_WAVES 3
 #endif
-template <bool STRICT, typename T> constexpr int march_waves() { return sizeof(T) == 4 ? 5 : (STRICT ? HP_K1_STRICT_WAVES : HP_K1_FAST_WAVES); }
+#ifndef HP_K1_F32_WAVES
+#define HP_K1_F32_WAVES 5
+#endif
+template <bool STRICT, typename T> constexpr int march_waves() { return sizeof(T) == 4 ? HP_K1_F32_WAVES : (STRICT ? HP_K1_STRICT_WAVES : HP_K1_FAST_WAVES); }
 
 // SPEC (STRICT fp64 only): the speculative flavour of a STRICT batch -- quotients that share a denominator share its refined
 // reciprocal (hp_math.hpp: div_shared), a lane whose operands fall outside what that covers raises the domain's SLOT_SPEC
