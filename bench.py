@@ -182,17 +182,18 @@ WORKLOAD_NAMES = {"s-rain": "S-RAIN gridded-rainfall on dry terrain", "s-rough":
                   "s-dam": "S-DAM flat-DEM dam-break"}
 
 
-def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=False, repeats=None, last=True):
+def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=False, repeats=None, last=True, workload=None):
     """One timed leg: build this rank's runner for a `cols x rows` grid cut into `world` strips, load the workload, pre-warm,
     then `repeats` x (restore, W warm-up steps, EXACTLY K timed steps between barrier + device sync); median repeat.
     Returns what rank 0 needs for the line (every rank gets the same timing numbers: max over ranks)."""
     from hipims_mi import synthetic as syn
+    workload = workload or args.workload
     scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
     levels = (2.0, 1.6) if args.scheme == "inertial" else (10.0, 1.0)     # the partial-inertial scheme wants a gentle step
     math_mode = hp.MATH_FAST if math == "fast" else hp.MATH_STRICT
     kernel = hp.KERNEL_AUTO if args.kernel == "auto" else hp.KERNEL_BASIC
     real = np.float64 if args.precision == "f64" else np.float32
-    dx = 2.0 if args.workload == "s-rain" else 1.0
+    dx = 2.0 if workload == "s-rain" else 1.0
     if world == 1:
         from hipims_mi.strips import SingleRunner
         runner = SingleRunner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
@@ -204,12 +205,12 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
         device = local_rank if backend == "nccl" else local_rank % max(1, hp.device_count())
         runner = StripRunner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
                              device=device, rank=rank, world=world, backend=backend)
-    if args.workload == "s-rain":
+    if workload == "s-rain":
         st, bed, man, rain = syn.s_rain_rows(cols, rows, runner.local_lo, runner.local_hi, dx=dx, dtype=real)
         runner.upload(st, bed, man)
         runner.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"],
                                   rain["off_y"], rain["interval"])
-    elif args.workload == "s-rough":
+    elif workload == "s-rough":
         if world != 1:
             raise SystemExit("--workload s-rough is a single-GPU diagnostic")
         st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
@@ -239,15 +240,21 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
 
     stride = max(1, args.steps // 12) | 1              # odd: both CFL flavours of the kernel get sampled
     runs = []
+    tail_carried = True                                 # every flux launch of every timed region carried its own tail block
     for _ in range(max(1, repeats if repeats is not None else args.repeats)):
         runner.restore()
         runner.step(args.warmup + args.evolve_steps)
         runner.domain.kernel_timing(stride)
         runner.barrier()
+        c0 = runner.domain.launch_counts()
         t0 = time.perf_counter()
         runner.step(args.steps)
         runner.barrier()
         el = runner.max_over_ranks(time.perf_counter() - t0)
+        c1 = runner.domain.launch_counts()
+        # asked of the library, not guessed from the command line: the engine can decline the tail block
+        # (HP_TAIL_MAX_BLOCKS, split steps, a library that predates the call)
+        tail_carried = tail_carried and c0 is not None and (c1[0] - c0[0], c1[1] - c0[1]) == (args.steps, args.steps)
         k_ms, k_n = runner.domain.kernel_timing_read()
         runs.append((el, k_ms, k_n))
     overhead_ms = runner.domain.kernel_timing_overhead()
@@ -268,10 +275,11 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
     leg = dict(cols=cols, rows=rows, world=world, math=math, elapsed=elapsed, runs=runs, k_ms=k_ms, k_n=k_n, sc=sc,
                overhead_ms=overhead_ms, strip_info=strip_info, loop=getattr(runner, "loop", "batch call"),
                cells_per_launch=cols * runner.local_rows_total, flux_kernel=runner.flux_kernel_name, levels=levels,
-               fused=(runner.domain.boundaries_fused() if args.workload == "s-rain" else None),
-               one_launch=(args.kernel == "auto" and os.environ.get("HP_LAUNCH_TAIL", "1") != "0"
-                           and (args.workload != "s-rain")
-                           and (world == 1 or bool(strip_info and strip_info["peer_halo"]))))
+               fused=(runner.domain.boundaries_fused() if workload == "s-rain" else None), workload=workload,
+               tail_carried=tail_carried,
+               # an iteration is ONE launch: the flux launch carried the time advance (counted by the library) and nothing else
+               # is queued per iteration (S-RAIN keeps the stand-alone boundary pass's launch, which declines when fused)
+               one_launch=(tail_carried and workload != "s-rain"))
     if world > 1 and not last:
         runner.close(destroy_group=False)
     else:
@@ -295,7 +303,8 @@ def roofline_of(args, leg):
          "avg_launch_ms": launch_ms, "frac_event_sampled": frac_of(ev_ms), "avg_launch_ms_event_sampled": ev_ms,
          "avg_launch_ms_raw": raw, "event_pair_overhead_ms": leg["overhead_ms"], "launches_sampled": leg["k_n"],
          "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": leg["cells_per_launch"]}
-    if args.workload in ("s-dam", "s-rain", "s-rough") and leg.get("manning_uniform", True):
+    r["flux_launches_carried_their_tail"] = bool(leg.get("tail_carried"))
+    if leg["workload"] in ("s-dam", "s-rain", "s-rough") and leg.get("manning_uniform", True):
         # the synthetic workloads have ONE Manning value, which the engine passes as a scalar: the bytes such a launch
         # really has to move are 72 (fp64) / 36 (fp32) per cell; SURVEY 8(d)'s contract figure stays above
         r["uniform_manning_bytes_per_cell_step"] = bpc * 0.9
@@ -319,7 +328,7 @@ def parallelism_of(leg):
 
 def workload_of(args, leg):
     lv = leg["levels"]
-    return (f"{WORKLOAD_NAMES[args.workload]} {leg['cols']}x{leg['rows']}{'' if lv[0] == 10.0 else ' (levels %g|%g m)' % lv}, "
+    return (f"{WORKLOAD_NAMES[leg['workload']]} {leg['cols']}x{leg['rows']}{'' if lv[0] == 10.0 else ' (levels %g|%g m)' % lv}, "
             f"{args.scheme + '+HLLC' if args.scheme != 'inertial' else 'partial-inertial'}, friction fused, "
             f"dynamic CFL dt, quirks=reference, math={leg['math']}, kernel={args.kernel}")
 
@@ -344,6 +353,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-manning-leg", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")
+    ap.add_argument("--no-moving-leg", action="store_true", help="skip the moving-water leg (S-ROUGH) of the default line")
     ap.add_argument("--no-single-leg", action="store_true", help="N > 1: skip rank 0's single-domain leg (speedup_vs_1gpu_same_run)")
     ap.add_argument("--repeats", type=int, default=3, help="timed repeats of --steps steps; the median is reported")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed time-based pre-warm (the state is restored afterwards)")
@@ -380,6 +390,11 @@ def main():
             manning_leg["manning_uniform"] = False
         if args.math == "fast" and not args.no_strict_leg:
             strict_leg = run_leg(args, hp, cols, rows, 1, 0, local_rank, "strict", repeats=1)
+        moving_leg = None
+        if args.workload == "s-dam" and not args.no_moving_leg:
+            # the headline window of S-DAM is ~98 % still water; this leg is the same grid, scheme and mode on water that moves
+            # everywhere (S-ROUGH: wet/dry rough terrain, every tile live) -- VERDICT r04 item 1
+            moving_leg = run_leg(args, hp, cols, rows, 1, 0, local_rank, args.math, repeats=1, workload="s-rough")
         scaling, weak_leg, single_leg = "weak", None, None
     else:
         legs = {"both": ("strong", "weak"), "weak": ("weak",), "strong": ("strong",)}[args.scaling]
@@ -401,7 +416,7 @@ def main():
                 single_leg = run_leg(args, hp, strong_grid[0], strong_grid[1], 1, 0, local_rank, args.math, repeats=max(1, args.repeats - 1))
             dist.barrier()
             dist.destroy_process_group()
-        manning_leg = strict_leg = None
+        manning_leg = strict_leg = moving_leg = None
         default_cfg = False
 
     if rank == 0:
@@ -415,7 +430,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload_of(args, main_leg),
                        "cells_per_gpu": cells // world, "parallelism": parallelism_of(main_leg),
-                       "area_boundaries": ("none" if args.workload != "s-rain" else
+                       "area_boundaries": ("none" if main_leg["workload"] != "s-rain" else
                                            "fused into the flux kernel's store epilogue" if main_leg["fused"] else "separate pass"),
                        "timed_steps": [args.warmup + args.evolve_steps, args.warmup + args.evolve_steps + args.steps],
                        "sim_time_s": main_leg["sc"]["time"], "successful_iterations": main_leg["sc"]["batch_successful"],
@@ -449,6 +464,13 @@ def main():
                              "value": cells * args.steps / strict_leg["elapsed"] / 1e6, "unit": "Mcell-steps/s",
                              "ms_per_step": strict_leg["elapsed"] / args.steps * 1e3, "frac": rs["frac"],
                              "frac_event_sampled": rs["frac_event_sampled"], "kernel": rs["kernel"]}
+        if moving_leg:
+            rw = roofline_of(args, moving_leg)
+            out["moving_water"] = {"what": "same grid, scheme and math mode on water that moves everywhere: " + workload_of(args, moving_leg),
+                                   "value": cells * args.steps / moving_leg["elapsed"] / 1e6, "unit": "Mcell-steps/s",
+                                   "ms_per_step": moving_leg["elapsed"] / args.steps * 1e3, "frac": rw["frac"],
+                                   "frac_basis": rw["frac_basis"], "frac_event_sampled": rw["frac_event_sampled"],
+                                   "kernel": rw["kernel"], "sim_time_s": moving_leg["sc"]["time"]}
         if default_cfg:
             tr = pmc_traffic(args.scheme + "_march<false", args.scheme)
             k_ms = out["roofline"]["avg_launch_ms"]

@@ -160,6 +160,8 @@ struct hp_domain {
 	bool             push_now = false;                // this iteration's advance kernel carries the ghost rows
 	// the flux launch's own tail block instead of a separate advance launch (LaunchTail, hp_kernels.hpp): small launches only
 	unsigned long long* tail_words = nullptr;         // one word per flux block (EMPTY between launches)
+	uint64_t         flux_launches = 0, flux_launches_tailed = 0;   // whole-domain flux launches of hp_step_batch / hp_strip_step_batch, and how many carried their own tail block
+	bool             tail_failed = false;             // a tail block gave up waiting (SLOT_TAIL_ERR seen by the host): the domain is unusable
 	bool             strip_first = false;             // hp_strip_step_batch: the batch's first iteration
 	bool             tail_allowed = false;            // inside hp_step_batch / hp_strip_step_batch (the host-driven split step has work in between)
 	bool             tail_want = false;               // step_begin_impl: this iteration qualifies, if the launch is small enough
@@ -386,12 +388,28 @@ inline void launch_rows(const hp_domain* d, long g, long& lo, long& hi)
 // compute the strip's first / last `ghost_rows` owned rows store them into the neighbours as well -- the neighbour's pointer
 // is shifted so that this strip's cell index lands on the neighbour's copy of the cell.  `limit`: launches of more blocks keep
 // the advance launch.  Returns 0 (no tail), 1 (tail block) or 2 (tail block + rows stored into the neighbours).
+// how long a launch's tail block waits for ONE flux block's word before it raises SLOT_TAIL_ERR (hp_kernels.hpp: launch_tail).
+// Generous: the wait only starts once the tail block runs, i.e. once its XCD has dispatched every flux block of the launch.
+static long tail_timeout_ms()
+{
+	static const long ms = std::getenv("HP_TAIL_TIMEOUT_MS") ? std::atol(std::getenv("HP_TAIL_TIMEOUT_MS")) : 20000;
+	return ms > 0 ? ms : 20000;
+}
+// (tests) the tail block also waits for one word that no block writes: the time-out must fire, the call sequence must fail
+static unsigned tail_debug_extra_word()
+{
+	static const unsigned v = std::getenv("HP_DEBUG_TAIL_EXTRA_WORD") && std::atoi(std::getenv("HP_DEBUG_TAIL_EXTRA_WORD")) != 0 ? 1u : 0u;
+	return v;
+}
 template <typename T> int make_tail(hp_domain* d, unsigned& blocks, int part, hipStream_t stream, unsigned limit, LaunchTail<T>& tail)
 {
 	tail = LaunchTail<T>{};
+	if (part == PART_ALL) d->flux_launches++;
 	if (!(d->tail_want && part == PART_ALL && stream == d->stream && blocks <= limit)) return 0;
 	tail.done = d->tail_words;
 	tail.flux_blocks = blocks;
+	tail.poll_blocks = blocks + tail_debug_extra_word();
+	tail.timeout = (unsigned long long)tail_timeout_ms() * 100000ull;       // wall_clock64: 100 MHz
 	tail.fresh = d->tail_fresh;
 	tail.sc = (Scalars<T>*)d->scalars;
 	tail.slot = (T*)d->cfl_slot;
@@ -414,6 +432,7 @@ template <typename T> int make_tail(hp_domain* d, unsigned& blocks, int part, hi
 	}
 	blocks += 1;
 	d->tail_done = true;
+	d->flux_launches_tailed++;
 	return kind;
 }
 // (K2 / K6 have their own knob for A/B runs.  A first probe had them lose 0.5 / 1.7 % at the 4608 blocks of 4096^2 and a limit of
@@ -840,12 +859,18 @@ int refresh_fusable(hp_domain* d)
 }
 
 int spec_resolve(hp_domain* d);
+int tail_failed_error()
+{
+	return fail(HP_ERR_STATE, "a flux launch's tail block gave up waiting for a flux block (HP_TAIL_TIMEOUT_MS): time and timestep "
+	                          "are frozen from that iteration on, the domain's state is not valid; destroy the domain");
+}
 int check_domain(hp_domain* d)
 {
 	if (d) d->fork_is_advance = false;        // any entry point may queue work behind the last advance_time
 	if (!d) return fail(HP_ERR_INVALID, "null domain");
 	hipError_t e = hipSetDevice(d->desc.device);
 	if (e != hipSuccess) return fail(HP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+	if (d->tail_failed) return tail_failed_error();      // (hp_domain_destroy does not come through here)
 	// a speculative STRICT batch is still to be looked at: whoever enters the library next does that first, so that nothing is
 	// ever queued behind -- or read from -- a batch that has to be re-run
 	if (d->spec_pending) return spec_resolve(d);
@@ -1609,17 +1634,41 @@ static int peer_error_check(hp_domain* d)
 	return HP_OK;
 }
 
+// The sticky word of a launch's tail block that gave up waiting for a flux block (hp_kernels.hpp: launch_tail; time and timestep
+// were left frozen from that launch on).  Read wherever the host blocks on the domain's stream anyway; once seen, every later call
+// on the domain fails with HP_ERR_STATE (check_domain) -- its state is not a state of the model.  `queued`: the read-back has been
+// queued by the caller (hp_read_scalars), only the verdict is left.
+constexpr size_t HOST_TAIL_ERR = 448;       // byte offset in the pinned block (next to HOST_SPEC_FLAG)
+static int tail_error_queue(hp_domain* d)
+{
+	*(volatile double*)((char*)d->host_scalars + HOST_TAIL_ERR) = 0.0;
+	HIP_TRY(hipMemcpyAsync((char*)d->host_scalars + HOST_TAIL_ERR, (char*)d->cfl_slot + (size_t)SLOT_TAIL_ERR * d->esize, d->esize,
+	                       hipMemcpyDeviceToHost, d->stream));
+	return HP_OK;
+}
+static int tail_error_verdict(hp_domain* d)
+{
+	const unsigned char* w = (const unsigned char*)d->host_scalars + HOST_TAIL_ERR;
+	bool raised = false;
+	for (size_t i = 0; i < d->esize; ++i) raised = raised || w[i] != 0;
+	if (!raised) return HP_OK;
+	d->tail_failed = true;
+	return tail_failed_error();
+}
+
 int hp_read_scalars(hp_domain_t* d, hp_scalars_t* out)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	if (!out) return fail(HP_ERR_INVALID, "out == NULL");
 	HIP_TRY(hipMemcpyAsync(d->host_scalars, d->scalars, 128, hipMemcpyDeviceToHost, d->stream));
+	if ((rc = tail_error_queue(d)) != HP_OK) return rc;
 	uint64_t* peer_error = (uint64_t*)((char*)d->host_scalars + 480);
 	*peer_error = 0;
 	if (d->peer_agreed)                      // the mailboxes' sticky error word: a strip that was not heard from in time
 		HIP_TRY(hipMemcpyAsync(peer_error, d->peer_mine + PEER_WORD_ERROR, 8, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
+	if ((rc = tail_error_verdict(d)) != HP_OK) return rc;
 	if (*peer_error)
 		return fail(HP_ERR_HIP, "the maximum over the strips is incomplete: rank " + std::to_string((long)*peer_error - 1) +
 		                        " was not heard from within the time limit (HP_PEER_TIMEOUT_MS)");
@@ -1641,7 +1690,9 @@ int hp_sync(hp_domain_t* d)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	if ((rc = tail_error_queue(d)) != HP_OK) return rc;
 	HIP_TRY(hipStreamSynchronize(d->stream));
+	if ((rc = tail_error_verdict(d)) != HP_OK) return rc;                // (nor may the state of a domain whose time stands still)
 	return peer_error_check(d);                                          // (a download / checkpoint of a broken exchange must not look fine)
 }
 
@@ -1654,7 +1705,13 @@ int hp_is_busy(hp_domain_t* d, int* busy)
 		*busy = 0;
 		// (an idle domain whose speculative batch has not been looked at yet: do that now -- the caller polls this to learn
 		// whether the batch's results can be read)
-		if (d->spec_pending) { hipSetDevice(d->desc.device); return spec_resolve(d); }
+		// -- and if that look re-queues the batch (the plain divisions' replay), the domain IS busy again: say so
+		if (d->spec_pending) {
+			hipSetDevice(d->desc.device);
+			const int rc = spec_resolve(d);
+			if (rc == HP_OK && hipStreamQuery(d->stream) == hipErrorNotReady) *busy = 1;
+			return rc;
+		}
 		return HP_OK;
 	}
 	if (e == hipErrorNotReady) { *busy = 1; return HP_OK; }
@@ -2321,6 +2378,16 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples)
 	}
 	*avg_ms = n ? total / n : 0.0;
 	*samples = n;
+	return HP_OK;
+}
+
+int hp_launch_counts(hp_domain_t* d, uint64_t* flux_launches, uint64_t* with_tail)
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!flux_launches || !with_tail) return fail(HP_ERR_INVALID, "null argument");
+	*flux_launches = d->flux_launches;
+	*with_tail = d->flux_launches_tailed;
 	return HP_OK;
 }
 

@@ -265,6 +265,8 @@ __global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const i
 template <typename T> struct LaunchTail {
 	unsigned long long* done;      // nullptr: no tail (the classic two launches)
 	unsigned            flux_blocks;
+	unsigned            poll_blocks;   // words the tail block waits for: flux_blocks (HP_DEBUG_TAIL_EXTRA_WORD=1: one more, which nobody writes -- the time-out's test)
+	unsigned long long  timeout;       // wall_clock64 ticks (100 MHz) the tail block waits for ONE word before it gives up (HP_TAIL_TIMEOUT_MS)
 	int                 fresh;     // advance_time's `fresh`
 	Scalars<T>*         sc;
 	T*                  slot;
@@ -321,18 +323,47 @@ __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const
 #ifndef HP_TAIL_POLL_SLEEP
 #define HP_TAIL_POLL_SLEEP 1
 #endif
+// The tail block's wait is BOUNDED (round 5).  It is correct under in-order block dispatch -- the tail block has the launch's
+// highest index, every flux block is resident or dispatched before it -- and a dispatcher that ever did otherwise would leave it
+// spinning on a block that cannot start: a hung GPU, on a shared box a reset.  So a word that has not arrived `timeout` ticks after
+// the tail block first found it empty (HP_TAIL_TIMEOUT_MS, generous: the tail block only starts once its XCD has dispatched every
+// flux block of the launch) raises the sticky word cfl_slot[SLOT_TAIL_ERR] instead: the tail block returns WITHOUT the mailbox round
+// and WITHOUT advance_body -- t and dt stay frozen, the flux blocks that were still to come run and end on their own -- later tail
+// blocks of the same batch see the word and return at once, and the host finds it wherever it next blocks on the stream
+// (hp_sync, hp_read_scalars; hp_engine.hip: tail_error_check) and fails the domain with HP_ERR_STATE.  The clock is only read on
+// the slow path (a word found empty), the common case is one load per word as before.
 template <typename T>
 __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail<T>& tail)
 {
 	__shared__ T part[4];
+	__shared__ int late_any;
+	if (threadIdx.x == 0) late_any = atomic_peek(tail.slot + SLOT_TAIL_ERR) != T(0);   // an earlier launch of this domain gave up
+	__syncthreads();
+	if (late_any) return;
 	T m = T(0);
-	for (unsigned i = threadIdx.x; i < tail.flux_blocks; i += blockDim.x) {
-		unsigned long long w;
-		while ((w = __hip_atomic_load(tail.done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == PEER_EMPTY) __builtin_amdgcn_s_sleep(HP_TAIL_POLL_SLEEP);
+	bool late = false;
+	for (unsigned i = threadIdx.x; i < tail.poll_blocks; i += blockDim.x) {
+		unsigned long long w = __hip_atomic_load(tail.done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (w == PEER_EMPTY) {
+			const unsigned long long t0 = wall_clock64();
+			for (;;) {
+				__builtin_amdgcn_s_sleep(HP_TAIL_POLL_SLEEP);
+				w = __hip_atomic_load(tail.done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (w != PEER_EMPTY) break;
+				if (wall_clock64() - t0 > tail.timeout) { late = true; break; }
+			}
+			if (late) break;
+		}
 		__hip_atomic_store(tail.done + i, PEER_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		T v;
 		peer_value(w, v);
 		if (v > m) m = v;
+	}
+	if (late) late_any = 1;                                     // (benign race: every writer writes 1)
+	__syncthreads();
+	if (late_any) {
+		if (threadIdx.x == 0) tail.slot[SLOT_TAIL_ERR] = T(1);
+		return;
 	}
 	// every done word has been seen: acquire what their writers released (the edge tiles' rows in the neighbours' memory)
 	// before this block publishes into the neighbours' mailboxes

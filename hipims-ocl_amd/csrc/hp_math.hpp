@@ -294,6 +294,94 @@ __device__ __forceinline__ FaceFlux<T> finish_wet(const FaceCore<T> k, const Rec
 
 template <typename T> struct FacePair { FaceFlux<T> forL, forR; };
 
+// ---- FAST flavour of a face solve: DEPTH FORM (round 5) ----------------------------------------------------------------------
+// The reference evaluates the pressure-like part of the normal-momentum flux in free-surface form on SHIFTED levels
+// (CLSolverHLLC.clc:146-157 on the output of CLSchemeGodunov.clc:84-97, :134-139): with a = eta_L - s, b = eta_R - s, zb = zbm - s
+// (s = the vertical shift of the cell the face is finished for, left bed on both sides, quirk Q4),
+//     F_n,L = u_L q_L + g/2 (a^2 - 2 zb a)          and, because a - zb = eta_L - zbm = h_L whatever s is,
+//           = u_L q_L + g/2 h_L^2 - g/2 Z^2,        Z = zbm - s                         (s = max(0, zbm - eta_own)),
+// likewise on the right with h_R.  The HLL average of two fluxes that both carry -g/2 Z^2 is the average minus g/2 Z^2, and the mass
+// flux only sees b - a = h_R - h_L: EVERYTHING the solver computes is independent of the shift except that one additive constant.
+// The cell update (CLSchemeGodunov.clc:323-336) then adds the bed-slope source g/2 (eta_E' + eta_W')(zb_E' - zb_W') on the
+// neighbour-side shifted values eta' = h_nb + Z, zb' = Z, and
+//     (F_E - F_W) + g/2 (eta_E' + eta_W')(Z_E - Z_W) = (F~_E - F~_W) - g/2 (Z_E^2 - Z_W^2) + g/2 (h_E + h_W + Z_E + Z_W)(Z_E - Z_W)
+//                                                     = (F~_E - F~_W) + g/2 (h_E + h_W)(Z_E - Z_W),           F~ = F + g/2 Z^2:
+// the constants cancel against the source term identically.  So the FAST face hands over the shift-free flux F~ (ONE value for
+// both cells: the second finish of round 2 and the per-cell C(s) of round 3 are gone), the neighbour-side DEPTH h_nb in
+// FaceFlux::eta_nb and Z in FaceFlux::zb_nb, and godunov_update's FAST branch -- the same expression as before on fields that
+// now mean (h_nb, Z) -- delivers the same sum.  Same mathematics, different rounding: the terms of size g/2 zb^2 that the
+// free-surface form adds and takes away again (5e4 at a 100 m bed: the reference's own noise floor, what its -cl-mad-enable and
+// strict builds differ by) never arise.  STRICT keeps the reference's statements.
+//
+// One formula for the whole fan: with s_L' = min(s_L, 0), s_R' = max(s_R, 0) the HLL expression
+//     F = (s_R' F_L - s_L' F_R + s_L' s_R' (U_R - U_L)) / (s_R' - s_L')
+// is F_L for s_L >= 0 and F_R for s_R <= 0 (:174-198) -- no region selects, no wave-uniform test for them; the tangential
+// momentum is the mass flux times the upwind tangential velocity in all three regions (:206-224; sign(s_M) = sign(F_1) as in
+// round 3, and in the supercritical regions u_n q_t = q_n u_t with q_n of the sign the region implies).  A face between two dry
+// cells (:45-61: zero mass and tangential flux, pressure of the mean level) goes through the same formula: its depths are below
+// VERY_SMALL, so F~ is below g/2 1e-20 and F_1 below 1e-14 -- against the reference's exact zeros both differences vanish under
+// the update's VERY_SMALL flush (:340-348); the celerity is clamped away from zero so that s_R' - s_L' never is.
+// A wavefront whose lanes all have water on both sides skips what only a dry side can need: zeroed velocities (:87-92), dry-side
+// wave speeds (:129-140), the shift and the stopping conditions (:101-133); a wet-wet lane gets the same bits either way.
+template <typename T> __device__ __forceinline__ T celerity_fast(const T gh);
+template <> __device__ __forceinline__ double celerity_fast(const double gh) { return sqrt_fast(gh); }        // clamps at 1e-150
+template <> __device__ __forceinline__ float  celerity_fast(const float gh)  { return __builtin_amdgcn_sqrtf(__builtin_fmaxf(gh, 1e-30f)); }
+
+template <int AXIS, typename T>
+__device__ __forceinline__ FacePair<T> face_solve_fast(const Side<T>& L, const Side<T>& R, const T vs)
+{
+	const T g = gravity<T>(), half_g = T(0.5) * g;
+	const T zbm = fmax_(L.zb, R.zb);
+	const T hL = fmax_(L.eta - zbm, T(0)), hR = fmax_(R.eta - zbm, T(0));                 // :84-97
+	T unL = (AXIS == AXIS_X ? L.u0 : L.v0), unR = (AXIS == AXIS_X ? R.u0 : R.v0);
+	T utL = (AXIS == AXIS_X ? L.v0 : L.u0), utR = (AXIS == AXIS_X ? R.v0 : R.u0);
+	const bool all_wet = __all(hL > vs && hR > vs);
+	const bool dryL = hL < vs, dryR = hR < vs;
+	T ZL = zbm, ZR = zbm;
+	bool stopL = false, stopR = false;
+	if (!all_wet) {
+		// stopping conditions (:101-133) on the cell-centre velocities and raw discharges
+		const T qrawL = (AXIS == AXIS_X ? L.qx : L.qy), qrawR = (AXIS == AXIS_X ? R.qx : R.qy);
+		const bool shared = (hR <= vs && unL < T(0)) || (hL <= vs && unR > T(0));
+		stopL = shared || (hL <= vs && qrawL > T(0));
+		stopR = shared || (hR <= vs && qrawR < T(0));
+		unL = dryL ? T(0) : unL; utL = dryL ? T(0) : utL;                                 // :87-92
+		unR = dryR ? T(0) : unR; utR = dryR ? T(0) : utR;
+		// zbm - shift, the shift formed as the reference forms it (:85-86, :136-139): mathematically min(zbm, eta_own), but where
+		// a level lies far below the common bed -- the 9999.9 m walls of every closed edge -- fl(zbm - fl(zbm - eta)) is eta + delta
+		// with delta up to half an ulp OF THE WALL (1e-12 m), and that delta is the reference's dominant rounding term there: its
+		// wall pressure is -g/2 (eta + delta)^2, the momentum balance of a cell at rest against a wall comes out as -g/2 delta h
+		// instead of zero, survives the VERY_SMALL flush, and its SIGN decides whether the stopping conditions (:101-133) fire on
+		// the cells along a wall in a flow that is symmetric about them.  Two more instructions keep that term, sign and size.
+		ZL = zbm - fmax_(zbm - L.eta, T(0)); ZR = zbm - fmax_(zbm - R.eta, T(0));
+	}
+	const T qnL = hL * unL, qnR = hR * unR;                                               // :99-102
+	const T ghL = g * hL, ghR = g * hR;
+	const T aL = celerity_fast(ghL), aR = celerity_fast(ghR);                             // :103-106
+	const T tmp = fma_(T(0.25), unL - unR, T(0.5) * (aL + aR));                           // :123-126
+	const T u_star = fma_(T(0.5), unL + unR, aL - aR);
+	const T a_star = fabs_(tmp);
+	T sL = fmin_(unL - aL, u_star - a_star), sR = fmax_(unR + aR, u_star + a_star);       // :129-140
+	if (!all_wet) {
+		sL = dryL ? fma_(T(-2), aR, unR) : sL;
+		sR = dryR ? fma_(T(2), aL, unL) : sR;
+	}
+	sL = fmin_(sL, T(0)); sR = fmax_(sR, T(0));                                           // the whole fan (:174-198)
+	const T inv_ds = rcp_fast(sR - sL);
+	const T sLsR = sL * sR;
+	const T fnL = fma_(unL, qnL, (T(0.5) * ghL) * hL), fnR = fma_(unR, qnR, (T(0.5) * ghR) * hR);   // u q + g/2 h^2
+	const T f0 = fma_(sLsR, hR - hL, fma_(sR, qnL, -(sL * qnR))) * inv_ds;                // :200-203
+	const T fn = fma_(sLsR, qnR - qnL, fma_(sR, fnL, -(sL * fnR))) * inv_ds;
+	const T ft = f0 * ((f0 >= T(0)) ? utL : utR);                                         // :206-224
+	(void)half_g;
+	FacePair<T> o;
+	o.forL.f0 = f0; o.forL.fx = (AXIS == AXIS_X ? fn : ft); o.forL.fy = (AXIS == AXIS_X ? ft : fn);
+	o.forL.eta_nb = hR; o.forL.zb_nb = ZL; o.forL.stop = stopL;
+	o.forR.f0 = f0; o.forR.fx = o.forL.fx; o.forR.fy = o.forL.fy;
+	o.forR.eta_nb = hL; o.forR.zb_nb = ZR; o.forR.stop = stopR;
+	return o;
+}
+
 // Solve the face between cell L (west/south) and cell R (east/north).
 //   forL : the face as cell L sees it (its E or N face; "own" = left,  ucDirection < DOMAIN_DIR_S)
 //   forR : the face as cell R sees it (its W or S face; "own" = right)
@@ -301,6 +389,7 @@ template <typename T> struct FacePair { FaceFlux<T> forL, forR; };
 template <int AXIS, bool STRICT, bool WANT_L, bool WANT_R, bool PLAIN, typename T>
 __device__ __forceinline__ FacePair<T> face_solve_impl(const Side<T>& L, const Side<T>& R, const T vs, T* spec_word)
 {
+	if (!STRICT) return face_solve_fast<AXIS>(L, R, vs);            // (depth form, above; everything below is the exact flavour)
 	bool bad = false;
 	const T g = gravity<T>();
 
@@ -332,85 +421,8 @@ __device__ __forceinline__ FacePair<T> face_solve_impl(const Side<T>& L, const S
 
 	// ---- HLLC ----
 	FaceFlux<T> oL, oR;
-	if (!STRICT) {
-		// ---- FAST flavour (round 3 formulation) ----
-		// (1) The vertical shift enters a finished face only through the pressure-like terms g/2 (eta^2 - 2 zb eta) of the
-		//     normal-momentum flux, and identically on both sides: with a = eta - s and zb = zbm - s,
-		//         a (a - 2 zb) = eta (eta - 2 zbm) - s (s - 2 zbm),
-		//     so F_n(s) = F_n(0) - C(s), C(s) = g/2 s (s - 2 zbm), in all three regions of the fan (in the middle one
-		//     the HLL average of two fluxes that both carry -C is the average minus C).  The face is therefore finished ONCE
-		//     without shift; each of the two cells subtracts its own C (4 operations; C(0) = 0 exactly) instead of the
-		//     second finish round 2 paid for (16 operations + selects).
-		// (2) s_M is only needed for its sign (which side's tangential velocity the middle state carries, :206-224), and
-		//     s_M = -(s_R - s_L) F_1 / den with den < 0 whenever a side is wet: sign(s_M) = sign of the HLL mass flux F_1,
-		//     which is computed anyway.  (Round 2 evaluated s_M's numerator and denominator: 12 operations.)
-		// (3) Wave-uniform short cuts: when every lane of the wavefront has water on both sides of its face, none of the
-		//     dry-side forms, zeroed velocities, shifts or stopping conditions can apply (they all need h <= VERY_SMALL),
-		//     and when every lane is in the subcritical "middle" region of the fan only the HLL middle state is needed:
-		//     the selects between alternatives nobody takes are simply not executed.  Otherwise the wavefront runs
-		//     STRAIGHT-LINE code: dry-side wave speeds
-		//     (:129-140), region (:174-198) and the dry-dry flux (:45-61) are per-lane selects over ONE instruction stream
-		//     (round 2: divergent branches, each under its own exec mask, ~190 VALU per face; now ~140).  A wet-wet
-		//     lane executes exactly the operations of the all-wet path, so a face has the same bits whichever wavefront
-		//     (tile, strip) solves it.
-		const T half_g = T(0.5) * g;
-		const bool all_wet = __all(hL > vs && hR > vs);
-		const bool dryL = hL < vs, dryR = hR < vs;
-		T unL = (AXIS == AXIS_X ? L.u0 : L.v0), unR = (AXIS == AXIS_X ? R.u0 : R.v0);     // dVel (:87-98)
-		T utL = (AXIS == AXIS_X ? L.v0 : L.u0), utR = (AXIS == AXIS_X ? R.v0 : R.u0);
-		if (!all_wet) {                                                                   // zero velocity on a dry side
-			unL = dryL ? T(0) : unL; utL = dryL ? T(0) : utL;
-			unR = dryR ? T(0) : unR; utR = dryR ? T(0) : utR;
-		}
-		const T qnL = (AXIS == AXIS_X ? qxL : qyL), qnR = (AXIS == AXIS_X ? qxR : qyR);   // dDis (:99-102)
-		const T aL = sqrt_fast(g * hL), aR = sqrt_fast(g * hR);                           // dA (:103-106)
-		const T tmp = (aL + aR) / 2 + (unL - unR) / 4;                                    // :123-126
-		const T u_star = (unL + unR) / 2 + aL - aR;
-		const T a_star = fabs_(tmp);
-		T sL = fmin_(unL - aL, u_star - a_star), sR = fmax_(unR + aR, u_star + a_star);   // :129-140
-		if (!all_wet) {
-			sL = dryL ? (unR - 2 * aR) : sL;
-			sR = dryR ? (unL + 2 * aL) : sR;
-		}
-		const T sLsR = sL * sR;
-		const T inv_ds = rcp_fast(sR - sL);
-		// unshifted normal-momentum fluxes of the two sides (left bed on both sides, Q4) and the HLL middle state (:200-203)
-		const T fnL = fma_(unL, qnL, half_g * (etaL * (etaL - 2 * zbm)));
-		const T fnR = fma_(unR, qnR, half_g * (etaR * (etaR - 2 * zbm)));
-		const T f1m = fma_(sLsR, (etaR - etaL), fma_(sR, qnL, -(sL * qnR))) * inv_ds;
-		const T f2m = fma_(sLsR, (qnR - qnL), fma_(sR, fnL, -(sL * fnR))) * inv_ds;
-		const T ftm = f1m * ((f1m >= T(0)) ? utL : utR);                                  // (2)
-		T f0 = f1m, fn = f2m, ft = ftm;
-		if (!__all(sL < T(0) && sR >= T(0))) {                                            // not subcritical everywhere
-			const bool bLeft = sL >= T(0), mid = sL < T(0) && sR >= T(0), bRight = !bLeft && !mid;   // NaN speeds -> "right"
-			f0 = bLeft ? qnL : (bRight ? qnR : f1m);
-			fn = bLeft ? fnL : (bRight ? fnR : f2m);
-			const T qtL = (AXIS == AXIS_X ? qyL : qxL), qtR = (AXIS == AXIS_X ? qyR : qxR);   // only the supercritical regions use them
-			ft = bLeft ? (unL * qtL) : (bRight ? (unR * qtR) : ftm);
-		}
-		T fnForL = fn, fnForR = fn;
-		if (!all_wet) {
-			// (1): each cell subtracts its own C(s); a wet-wet face has no shift (a level below the common bed means a dry side)
-			fnForL = fn - half_g * (shL * (shL - 2 * zbm));
-			fnForR = fn - half_g * (shR * (shR - 2 * zbm));
-			const bool both_dry = dryL && dryR;
-			if (__any(both_dry)) {                                                        // :45-61, the statements of finish_dry
-				const T a1 = etaL - shL, b1 = etaR - shL, z1 = zbm - shL;
-				const T a2 = etaL - shR, b2 = etaR - shR, z2 = zbm - shR;
-				const T p1 = half_g * (((a1 + b1) / 2) * ((a1 + b1) / 2) - z1 * (a1 + b1));
-				const T p2 = half_g * (((a2 + b2) / 2) * ((a2 + b2) / 2) - z2 * (a2 + b2));
-				f0 = both_dry ? T(0) : f0;
-				ft = both_dry ? T(0) : ft;
-				fnForL = both_dry ? p1 : fnForL;
-				fnForR = both_dry ? p2 : fnForR;
-			}
-		}
-		oL.f0 = f0; oL.fx = (AXIS == AXIS_X ? fnForL : ft); oL.fy = (AXIS == AXIS_X ? ft : fnForL);
-		oL.eta_nb = etaR - shL; oL.zb_nb = zbm - shL; oL.stop = stopL;
-		oR.f0 = f0; oR.fx = (AXIS == AXIS_X ? fnForR : ft); oR.fy = (AXIS == AXIS_X ? ft : fnForR);
-		oR.eta_nb = etaL - shR; oR.zb_nb = zbm - shR; oR.stop = stopR;
-	} else if (hL < vs && hR < vs) {
-		// ---- STRICT flavour: the reference's statements in the reference's order ----
+	if (hL < vs && hR < vs) {
+		// ---- the reference's statements in the reference's order ----
 		oL = finish_dry<AXIS>(etaL, etaR, zbm, shL, true, stopL);
 		oR = finish_dry<AXIS>(etaL, etaR, zbm, shR, false, stopR);
 	} else {
@@ -485,6 +497,9 @@ __device__ __forceinline__ FacePair<T> face_solve(const Side<T>& L, const Side<T
 template <int AXIS, bool STRICT, typename T>
 __device__ __forceinline__ FaceFlux<T> face_dry_for_right(const Side<T>& L, const Side<T>& R, const T vs)
 {
+	// FAST (depth form, round 5) has no dry-dry branch: a face between dry cells goes through the one formula, here as wherever
+	// else the face might be solved -- a face has the same bits whichever tile, and whichever loop of a tile, produces it
+	if (!STRICT) return face_solve_fast<AXIS>(L, R, vs).forR;
 	T zbm, hL, hR, shR;
 	if (STRICT) {
 		zbm = (L.zb > R.zb ? L.zb : R.zb);
@@ -771,17 +786,50 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 	// again -- the same values as the early exit, without the sixteen selects on doubles that merging the two paths cost
 	if (STRICT && first) return f;
 
+	T d0, d2, d3;
+	if (!STRICT) {
+		// ---- FAST: the half step in DEPTH FORM (round 5; see face_solve_fast for the same step on the corrector's faces) ----
+		// estimateFluxVectorX / Y (:420-471) evaluate u q + g/2 (z^2 - 2 (z - h) z) on the extrapolated face states and evolveCellState
+		// (:476-526) adds the face-bed source g/2 (z_E + z_W)(zb_E - zb_W), zb = z - h.  With z^2 - 2 zb z = h^2 - zb^2 the pressure
+		// difference and the source of one axis add up to g/2 (h_E + h_W)(z_E - z_W) -- and the two faces of a cell are the cell
+		// state +- half a slope, so h_E + h_W = 2 h and z_E - z_W = slope.z: the whole term is g h slope.z.  The level faces of the
+		// first extrapolation are not needed at all, nor the eight products of the free-surface form.
+		// Face depths: a lane that gets here with slopes has h >= 1e-5 (:325-330) and MINMOD keeps a face value between the cell and
+		// the midpoint to its neighbour, so h_face >= h / 2 > VERY_SMALL: the reference's `h < VERY_SMALL ? 0 : q / h` never takes
+		// its first arm on a lane whose increments are used; first-order lanes ride along and have their increments forced to
+		// zero below (a SELECT: whatever 1 / 0 made of them does not propagate).  Four quotients, one reciprocal.
+		const T hc = cc.h;
+		const T hE = fma_(T(0.5), sx.h, hc), hW = fma_(T(-0.5), sx.h, hc), hN = fma_(T(0.5), sy.h, hc), hS = fma_(T(-0.5), sy.h, hc);
+		const T qxE = fma_(T(0.5), sx.qx, c.qx), qxW = fma_(T(-0.5), sx.qx, c.qx), qyE = fma_(T(0.5), sx.qy, c.qy), qyW = fma_(T(-0.5), sx.qy, c.qy);
+		const T qxN = fma_(T(0.5), sy.qx, c.qx), qxS = fma_(T(-0.5), sy.qx, c.qx), qyN = fma_(T(0.5), sy.qy, c.qy), qyS = fma_(T(-0.5), sy.qy, c.qy);
+		T iE, iW, iN, iS;
+		if (sizeof(T) == 8) {
+			const T pEW = hE * hW, pNS = hN * hS;
+			const T r = rcp_fast(pEW * pNS);                       // >= (h/2)^4 >= 6e-23 on the lanes that count
+			const T rEW = r * pNS, rNS = r * pEW;                  // 1 / (hE hW), 1 / (hN hS)
+			iE = rEW * hW; iW = rEW * hE; iN = rNS * hS; iS = rNS * hN;
+		} else {
+			iE = rcp_fast(hE); iW = rcp_fast(hW); iN = rcp_fast(hN); iS = rcp_fast(hS);     // (fp32: v_rcp_f32 is one instruction, the product would underflow)
+		}
+		const T uE = qxE * iE, uW = qxW * iW, vN = qyN * iN, vS = qyS * iS;
+		const T gh = g * hc;
+		d0 = ((qxE - qxW) + (qyN - qyS)) * inv_dx;
+		d2 = fma_(gh, sx.z, fma_(uE, qxE, -(uW * qxW)) + fma_(vN, qxN, -(vS * qxS))) * inv_dx;
+		d3 = fma_(gh, sy.z, fma_(uE, qyE, -(uW * qyW)) + fma_(vN, qyN, -(vS * qyS))) * inv_dx;
+		d0 = (first || fabs_(d0) < vs) ? T(0) : d0;               // (first-order lanes: no half step, whatever their fluxes came to)
+		d2 = (first || fabs_(d2) < vs) ? T(0) : d2;
+		d3 = (first || fabs_(d3) < vs) ? T(0) : d3;
+		const T mh = T(-0.5) * dt;
+		cc.z = fma_(mh, d0, cc.z); cc.qx = fma_(mh, d2, cc.qx); cc.qy = fma_(mh, d3, cc.qy);
+	} else {
 	f.n = face_extrapolate<STRICT>(c.zb, cc, sy, T(+0.5));                                         // :349-352
 	f.e = face_extrapolate<STRICT>(c.zb, cc, sx, T(+0.5));
 	f.s = face_extrapolate<STRICT>(c.zb, cc, sy, T(-0.5));
 	f.w = face_extrapolate<STRICT>(c.zb, cc, sx, T(-0.5));
 
 	// estimateFluxVectorX / Y (:420-471): FSL form with zb = Z - H
-	auto press = [&](const Face4<T>& a) {
-		return STRICT ? T(0.5) * g * ((a.z * a.z) - 2 * (a.z - a.h) * a.z)
-		              : (T(0.5) * g) * (a.z * fma_(T(2), a.h, -a.z));              // z^2 - 2 (z - h) z = z (2h - z)
-	};
-	auto vel = [&](const T q, const T h) { return STRICT ? (h < vs ? T(0) : q / h) : (h < vs ? T(0) : q * rcp_fast(h)); };
+	auto press = [&](const Face4<T>& a) { return T(0.5) * g * ((a.z * a.z) - 2 * (a.z - a.h) * a.z); };
+	auto vel = [&](const T q, const T h) { return h < vs ? T(0) : q / h; };
 	const T uE = vel(f.e.qx, f.e.h), uW = vel(f.w.qx, f.w.h), vN = vel(f.n.qy, f.n.h), vS = vel(f.s.qy, f.s.h);
 	const T FE0 = f.e.qx, FE1 = mad<STRICT>(uE, f.e.qx, press(f.e)), FE2 = uE * f.e.qy;
 	const T FW0 = f.w.qx, FW1 = mad<STRICT>(uW, f.w.qx, press(f.w)), FW2 = uW * f.w.qy;
@@ -789,8 +837,7 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 	const T FS0 = f.s.qy, FS1 = vS * f.s.qx, FS2 = mad<STRICT>(vS, f.s.qy, press(f.s));
 
 	// evolveCellState (:476-526)
-	T d0, d2, d3;
-	if (STRICT) {
+	{
 		if (inv_dx != T(0)) {                                              // dx a power of two: products, as in godunov_update
 			const T s1 = -1 * g * ((f.e.z + f.w.z) / 2) * (((f.e.z - f.e.h) - (f.w.z - f.w.h)) * inv_dx);
 			const T s2 = -1 * g * ((f.n.z + f.s.z) / 2) * (((f.n.z - f.n.h) - (f.s.z - f.s.h)) * inv_dx);
@@ -806,30 +853,13 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 		d3 = div_shared<PLAIN>(FE2 - FW2, rdx, bad) + div_shared<PLAIN>(FN2 - FS2, rdx, bad) - s2;
 		}
 		spec_raise<PLAIN>(bad, spec_word);
-	} else {
-		const T hg = T(0.5) * g;
-		const T s1d = hg * (f.e.z + f.w.z) * ((f.e.z - f.e.h) - (f.w.z - f.w.h));
-		const T s2d = hg * (f.n.z + f.s.z) * ((f.n.z - f.n.h) - (f.s.z - f.s.h));
-		d0 = ((FE0 - FW0) + (FN0 - FS0)) * inv_dx;
-		d2 = ((FE1 - FW1) + (FN1 - FS1) + s1d) * inv_dx;
-		d3 = ((FE2 - FW2) + (FN2 - FS2) + s2d) * inv_dx;
 	}
-	if (STRICT) {
-		d0 = small_to_zero<STRICT>(d0, vs);
-		d2 = small_to_zero<STRICT>(d2, vs);
-		d3 = small_to_zero<STRICT>(d3, vs);
-	} else {                                     // (first-order lanes: no half step, whatever their fluxes came to -- see above)
-		d0 = (first || fabs_(d0) < vs) ? T(0) : d0;
-		d2 = (first || fabs_(d2) < vs) ? T(0) : d2;
-		d3 = (first || fabs_(d3) < vs) ? T(0) : d3;
-	}
-	if (STRICT) {
-		cc.z  = cc.z  - T(0.5) * dt * d0;
-		cc.qx = cc.qx - T(0.5) * dt * d2;
-		cc.qy = cc.qy - T(0.5) * dt * d3;
-	} else {
-		const T mh = T(-0.5) * dt;
-		cc.z = fma_(mh, d0, cc.z); cc.qx = fma_(mh, d2, cc.qx); cc.qy = fma_(mh, d3, cc.qy);
+	d0 = small_to_zero<STRICT>(d0, vs);
+	d2 = small_to_zero<STRICT>(d2, vs);
+	d3 = small_to_zero<STRICT>(d3, vs);
+	cc.z  = cc.z  - T(0.5) * dt * d0;
+	cc.qx = cc.qx - T(0.5) * dt * d2;
+	cc.qy = cc.qy - T(0.5) * dt * d3;
 	}
 
 	f.n = face_extrapolate<STRICT>(c.zb, cc, sy, T(+0.5));                                         // :376-379
@@ -977,6 +1007,8 @@ constexpr int SLOT_SAVED = 32, SLOT_EDGE = 64;          // separate 256-B apart 
 constexpr int SLOT_LOCAL = 33, SLOT_GLOBAL = 34, SLOT_HANDSHAKE = 112;
 // raised (non-zero) by a SPECULATIVE flux launch in which some quotient fell outside what the shared-reciprocal division covers
 constexpr int SLOT_SPEC = 100;
+// raised (non-zero, sticky) by a launch's tail block that gave up waiting for a flux block's word (hp_kernels.hpp: launch_tail)
+constexpr int SLOT_TAIL_ERR = 104;
 
 __device__ __forceinline__ double atomic_exchange_zero(double* slot)
 {

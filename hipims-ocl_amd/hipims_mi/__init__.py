@@ -37,6 +37,7 @@ EXPORTS = [
     "hp_strip_comm_destroy", "hp_strip_info", "hp_strip_peer_ticket", "hp_strip_peer_connect", "hp_strip_peer_round",
     "hp_strip_peer_disconnect", "hp_timer_start",
     "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read", "hp_kernel_timing_overhead",
+    "hp_launch_counts",
 ]
 
 
@@ -161,6 +162,8 @@ def load_library(path: str | None = None):
     lib.hp_kernel_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     if hasattr(lib, "hp_kernel_timing_overhead"):       # (absent from round-3 builds loaded through HIPIMS_MI_LIB for A/B runs)
         lib.hp_kernel_timing_overhead.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    if hasattr(lib, "hp_launch_counts"):                # (absent from builds before round 5, as above)
+        lib.hp_launch_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.hp_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.hp_device_info.argtypes = [C.c_int, C.POINTER(DeviceInfo)]
     _lib = lib
@@ -485,8 +488,20 @@ class Domain:
         _check(self.lib, self.lib.hp_kernel_timing_read(self.h, C.byref(avg), C.byref(n)), "hp_kernel_timing_read")
         return avg.value, n.value
 
+    def launch_counts(self):
+        """(whole-domain flux launches queued so far, how many carried their own tail block); None with a library that
+        predates the call (round-4 builds loaded through HIPIMS_MI_LIB for A/B runs)."""
+        if not hasattr(self.lib, "hp_launch_counts"):
+            return None
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self.lib, self.lib.hp_launch_counts(self.h, C.byref(a), C.byref(b)), "hp_launch_counts")
+        return a.value, b.value
+
     def kernel_timing_overhead(self):
-        """Cost of an empty event pair (ms) that kernel_timing_read() has taken off every sample."""
+        """Cost of an empty event pair (ms) that kernel_timing_read() has taken off every sample (0.0 with a library that
+        predates the call)."""
+        if not hasattr(self.lib, "hp_kernel_timing_overhead"):
+            return 0.0
         ms = C.c_double(0)
         _check(self.lib, self.lib.hp_kernel_timing_overhead(self.h, C.byref(ms)), "hp_kernel_timing_overhead")
         return ms.value

@@ -227,7 +227,13 @@ typedef struct {
 /* CSchemeGodunov::readKeyStatistics (:1817-1835) after the five queueReadAll calls (:1309-1313); BLOCKS */
 int hp_read_scalars(hp_domain_t* d, hp_scalars_t* out);
 int hp_sync(hp_domain_t* d);                          /* COCLDevice::blockUntilFinished */
-int hp_is_busy(hp_domain_t* d, int* busy);            /* COCLDevice::isBusy */
+/* COCLDevice::isBusy.  With HP_STRICT_SPECULATE=1 the call that finds a speculative batch finished also looks at its verdict
+ * and may re-queue the batch with the plain divisions: *busy is then 1 again (the call may ENQUEUE work; it never blocks on it). */
+int hp_is_busy(hp_domain_t* d, int* busy);
+/* Inside a batch an iteration is one launch whose last block waits for the flux blocks' maxima and advances the time.  That wait
+ * is bounded (HP_TAIL_TIMEOUT_MS, environment, default 20000): a block that never reports -- only possible if blocks were ever
+ * dispatched out of order -- freezes time and timestep instead of hanging the GPU, and hp_sync / hp_read_scalars and every later
+ * call on the domain fail with HP_ERR_STATE.  (No reference counterpart: its queue is a sequence of separate kernels.) */
 
 /* ---- multi-GPU strips (one process per GPU).  The engine never talks to other ranks itself: the host
  *      moves ghost rows and the wave-speed maximum with its collective library (RCCL through
@@ -337,6 +343,10 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples);   
 /* The cost of an empty event pair that the last hp_kernel_timing() measured and hp_kernel_timing_read() takes off every
  * sample (raw average = avg_ms + this): reported so that lines with and without the correction can be compared. */
 int hp_kernel_timing_overhead(hp_domain_t* d, double* overhead_ms);
+/* How many whole-domain flux launches the domain has queued since it was created, and how many of them carried their own tail
+ * block (reduction + time advance inside the flux launch: an iteration is then ONE launch; otherwise the flux launch is followed
+ * by an advance launch).  bench.py states its roofline basis from the difference of two readings around the timed region. */
+int hp_launch_counts(hp_domain_t* d, uint64_t* flux_launches, uint64_t* with_tail);
 
 #ifdef __cplusplus
 }

@@ -398,10 +398,11 @@ class RefSim(_SimBase):
     def __init__(self, *a, mad=False, libm_pow=False, **k):
         super().__init__(*a, **k)
         stem = {GODUNOV: "god_", MUSCL: "mch_", INERTIAL: "ine_"}[self.scheme] + self.precision + ("_mad" if mad else "")
-        if libm_pow:                                 # pow() from the host libm instead of hp_crmath.h (fp64 Godunov only)
-            assert stem == "god_f64", "libm-pow reference build: Godunov fp64 strict only"
+        if libm_pow:                                 # pow() from the host libm instead of hp_crmath.h (fp64 strict builds)
+            assert stem in ("god_f64", "mch_f64", "ine_f64"), "libm-pow reference build: fp64 strict only"
             stem += "_libm"
         if not self.friction:                        # FRICTION_ENABLED undefined: Godunov / MUSCL fp64 builds exist
+            assert not libm_pow
             assert stem in ("god_f64", "mch_f64") and self.dynamic_dt, "no-friction reference build: fp64 Godunov/MUSCL"
             stem += "_nofric"
         if not self.dynamic_dt:                      # the TIMESTEP_FIXED program exists for Godunov fp64 only

@@ -287,6 +287,46 @@ def newcastle(precision, tag, mad=False, libm_pow=False):
          z=final[..., 0], qx=final[..., 2].astype(np.float32), qy=final[..., 3].astype(np.float32))
 
 
+C1_BATCH = 512          # the reference's queueMode="fixed" with this queue size: batch boundaries (and with them the number of
+                        # suspended iterations behind every output time, quirk Q1's buffer parity) are part of the run
+
+
+def newcastle_full(tag, mad=False, libm_pow=False, threads=8):
+    """F16: config C1 TO ITS END -- test/newcastle-centre.xml is 7200 s with rasters every 600 s (CModel.cpp:723-770: the
+    target time is clipped to every output time; CDomainCartesian.cpp:804-829), 1.0e5 iterations of the reference's kernels
+    under the front end's CModel loop (hipims_mi.model.Model with the reference kernels as its `sim`), fixed batches of
+    C1_BATCH.  Stored for the strict build: the simulation time, iteration counts and the SHA-256 of the float64 depth and
+    maxdepth rasters (as derive_output computes them) at all twelve output times -- what a bit-for-bit comparison needs -- and
+    the rasters themselves at four of them (600, 2400, 4800, 7200 s; the tolerance curve of the FAST mode).  The
+    -cl-mad-enable build and the libm-pow build store depth at 2400 s and 7200 s (the bracket)."""
+    import hashlib
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from model_dir import make_newcastle
+    from hipims_mi.model import Model
+
+    def make_sim(cfg, cols, rows, res):
+        return oracle.RefSim(cols, rows, precision="f64", dx=res, end_time=cfg.duration, mad=mad, libm_pow=libm_pow, threads=threads)
+    with tempfile.TemporaryDirectory() as tmp:
+        m = Model(make_newcastle(tmp), make_sim=make_sim, output_format=None)
+        m.scheme.automatic_queue = False
+        m.scheme.queue_addition_size = C1_BATCH
+        outs = m.run()
+        iterations, ok = m.scheme.iterations, m.scheme.batch_successful
+    times = np.array([t for t, _ in outs])
+    assert len(outs) == 12 and abs(times[-1] - 7200.0) < 1e-5
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+    if mad or libm_pow:
+        save(f"f16_newcastle_full_{tag}", t=times[[3, 11]], depth=np.stack([outs[k][1]["depth"] for k in (3, 11)]),
+             iterations=np.array(iterations), successful=np.array(ok))
+        return
+    keep = (0, 3, 7, 11)
+    save(f"f16_newcastle_full_{tag}", t=times, kept=np.array(keep), depth=np.stack([outs[k][1]["depth"] for k in keep]),
+         maxdepth=outs[-1][1]["maxdepth"], depth_sha256=np.array([sha(o["depth"]) for _, o in outs]),
+         maxdepth_sha256=np.array([sha(o["maxdepth"]) for _, o in outs]),
+         iterations=np.array(iterations), successful=np.array(ok), batch=np.array(C1_BATCH))
+
+
 def inertial(precision, tag, mad=False):
     """F12: calculateInertialFlux table + ine_cacheDisabled trajectories (CLSchemeInertial.clc)."""
     real = np.float64 if precision == "f64" else np.float32
@@ -447,6 +487,7 @@ JOBS = [
     ("f11", lambda: [cell_boundary(p, p) for p in ("f64", "f32")]),
     ("f10", lambda: [newcastle("f64", "f64"), newcastle("f64", "f64_mad", mad=True),
                     newcastle("f64", "f64_libm", libm_pow=True)]),
+    ("f16", lambda: [newcastle_full("f64"), newcastle_full("f64_mad", mad=True), newcastle_full("f64_libm", libm_pow=True)]),
     ("f13", fixed_timestep),
     ("f14", no_friction),
     ("f15", disabled_cells),

@@ -40,3 +40,22 @@ def test_strips_without_the_tail_block(peer_max):
                          capture_output=True, text=True, timeout=600, env=dict(os.environ, HP_LAUNCH_TAIL="0"))
     assert res.returncode == 0, res.stdout + res.stderr
     assert "bit-identical True" in res.stdout
+
+
+def test_tail_block_gives_up_instead_of_hanging():
+    """The tail block's wait for the flux blocks' words is bounded: with one word that nobody writes
+    (HP_DEBUG_TAIL_EXTRA_WORD=1) and a 100 ms limit the batch ends, hp_sync / hp_read_scalars / hp_step_batch / downloads fail
+    with HP_ERR_STATE, and the process is not left with a spinning GPU."""
+    worker = os.path.join(os.path.dirname(__file__), "tail_timeout_worker.py")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, HP_DEBUG_TAIL_EXTRA_WORD="1", HP_TAIL_TIMEOUT_MS="100"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "tail time-out ok" in r.stdout
+
+
+def test_tail_timeout_is_off_the_default_path():
+    """... and with a (short) limit but nothing missing, the default path runs as ever: the clock is only read for a word found
+    empty, and a word that arrives late but in time is still folded."""
+    r = subprocess.run([sys.executable, WORKER], capture_output=True, text=True, timeout=600, env=dict(os.environ, HP_TAIL_TIMEOUT_MS="2000"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fallback paths bit-identical" in r.stdout

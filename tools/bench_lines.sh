@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-lines}
 for args in "--scheme godunov" "--scheme godunov --evolve-steps 1500" "--scheme muscl" "--scheme muscl --evolve-steps 1500" "--scheme inertial" "--scheme godunov --precision f32" "--scheme muscl --precision f32" "--workload s-rain" "--workload s-rain --precision f32"; do
-  line=$(timeout 600 python3 bench.py --no-cpu-baseline --no-manning-leg --steps 200 --warmup 20 $args 2>&1 | grep '^{' | tail -1)
+  line=$(timeout 600 python3 bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --steps 200 --warmup 20 $args 2>&1 | grep '^{' | tail -1)
   python3 - "$args" "$line" <<'PY'
 import json, sys
 a, l = sys.argv[1:3]

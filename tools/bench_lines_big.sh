@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-big}
 for args in "--cols 8192 --rows 8192 --scheme godunov" "--cols 8192 --rows 8192 --scheme muscl" "--cols 8192 --rows 8192 --workload s-rain --precision f32" "--cols 8192 --rows 8192 --workload s-rain" "--cols 16384 --rows 8192 --scheme godunov" "--cols 16384 --rows 1026 --scheme godunov"; do
-  line=$(timeout 900 python3 bench.py --no-cpu-baseline --no-manning-leg --steps 100 --warmup 10 $args 2>&1 | grep '^{' | tail -1)
+  line=$(timeout 900 python3 bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --steps 100 --warmup 10 $args 2>&1 | grep '^{' | tail -1)
   python3 - "$args" "$line" <<'PY'
 import json, sys
 a, l = sys.argv[1:3]

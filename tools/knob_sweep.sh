@@ -3,7 +3,7 @@
 OUT=$1; ARGS=$2; shift 2
 : > "$OUT"
 for envset in "$@"; do
-  line=$(env $envset timeout 300 python3 bench.py --no-cpu-baseline --no-manning-leg $ARGS 2>&1 | grep '^{' | tail -1)
+  line=$(env $envset timeout 300 python3 bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg $ARGS 2>&1 | grep '^{' | tail -1)
   echo "{\"env\": \"$envset\", \"bench\": ${line:-null}}" >> "$OUT"
 done
 python3 - "$OUT" <<'PY'

@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=$1; shift
 OUT=gpurun_out/quick_$TAG; rm -rf $OUT; mkdir -p $OUT
-python3 bench.py --no-cpu-baseline --no-manning-leg --steps 200 --warmup 20 $* > $OUT/bench.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $OUT/pmc -- python3 bench.py --no-cpu-baseline --no-manning-leg --steps 20 --warmup 5 --prewarm-s 0.1 --repeats 1 $* > $OUT/pmc.log 2>&1
+python3 bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --steps 200 --warmup 20 $* > $OUT/bench.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $OUT/pmc -- python3 bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --steps 20 --warmup 5 --prewarm-s 0.1 --repeats 1 $* > $OUT/pmc.log 2>&1
 python3 - $OUT "$TAG $*" <<'PY'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1:3]

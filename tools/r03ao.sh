@@ -8,6 +8,6 @@ for lib in libhipims_mi.so libhipims_mi_f32r.so; do
 done > $OUT/survey.txt 2>&1
 for rep in 1 2; do for lib in libhipims_mi.so libhipims_mi_f32r.so; do
   for args in "--precision f32" "--precision f32 --workload s-rain" "--precision f32 --workload s-rain --cols 8192 --rows 8192 --steps 100" "--precision f32 --scheme muscl --workload s-rough"; do
-    HIPIMS_MI_LIB=$PWD/hipims-ocl_amd/lib/$lib python bench.py --no-cpu-baseline --no-manning-leg --repeats 2 $args | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib [$args]', round(d['roofline']['avg_launch_ms'],4), round(d['value']))"
+    HIPIMS_MI_LIB=$PWD/hipims-ocl_amd/lib/$lib python bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --repeats 2 $args | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib [$args]', round(d['roofline']['avg_launch_ms'],4), round(d['value']))"
   done; done; done > $OUT/ab.txt 2>&1
 cat $OUT/survey.txt; sort $OUT/ab.txt

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/$1; mkdir -p $OUT
 for w in "s-rough muscl" "s-rain godunov" "s-rough godunov"; do set -- $w
-  ARGS="--workload $1 --scheme $2 --no-cpu-baseline --no-manning-leg --steps 20 --warmup 5 --prewarm-s 0.1 --repeats 1"
+  ARGS="--workload $1 --scheme $2 --no-cpu-baseline --no-manning-leg --no-moving-leg --steps 20 --warmup 5 --prewarm-s 0.1 --repeats 1"
   D=$OUT/$1_$2; mkdir -p $D
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $D/a -- python3 bench.py $ARGS > $D/a.log 2>&1
   rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS_F64 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $D/b -- python3 bench.py $ARGS > $D/b.log 2>&1

@@ -10,7 +10,7 @@ for rep in 1 2 3; do
    HP_MARCH_RSEG=$r HIPIMS_MI_LIB=$PWD/hipims-ocl_amd/lib/$lib python bench.py --no-cpu-baseline --repeats 2 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib rseg $r default', round(d['roofline']['avg_launch_ms'],4), 'manning', round(d['roofline_manning_array']['avg_launch_ms'],4))"
   done
   for w in s-rain s-rough; do
-   HIPIMS_MI_LIB=$PWD/hipims-ocl_amd/lib/$lib python bench.py --no-cpu-baseline --no-manning-leg --repeats 2 --workload $w | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib $w', round(d['roofline']['avg_launch_ms'],4))"
+   HIPIMS_MI_LIB=$PWD/hipims-ocl_amd/lib/$lib python bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --repeats 2 --workload $w | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib $w', round(d['roofline']['avg_launch_ms'],4))"
   done
  done
 done 2>&1 | tee $OUT/ab.txt

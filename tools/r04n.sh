@@ -6,7 +6,7 @@ OUT=gpurun_out
 python tools/pathbench/snap.py > $OUT/r04n_snap.txt 2>&1
 for v in fast strict; do tools/pathbench/pathbench_$v --iters 1000 /tmp/pathbench_sdam.bin /tmp/pathbench_srough.bin /tmp/pathbench_srain.bin > $OUT/r04n_pathbench_$v.txt 2>&1; done
 paste -d'|' $OUT/r04n_pathbench_fast.txt $OUT/r04n_pathbench_strict.txt | cut -c1-70,97-165 > $OUT/r04n_pathbench_fast_vs_strict.txt
-B="python bench.py --no-cpu-baseline --no-manning-leg --no-strict-leg --repeats 2"
+B="python bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --no-strict-leg --repeats 2"
 L() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s %9.1f Mcell-steps/s  %.4f ms/step  frac %.3f' % ('$1', d['value'], d['ms_per_step'], d['roofline']['frac']))"; }
 {
 $B | L "S-DAM 4096^2 godunov f64 [20,220)"

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=$1; SHORT=${2:-}
-B="python bench.py --no-cpu-baseline --no-manning-leg --no-strict-leg --repeats 2"
+B="python bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --no-strict-leg --repeats 2"
 L() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s %9.1f Mcell-steps/s  %.4f ms/step  frac %.3f' % ('$1', d['value'], d['ms_per_step'], d['roofline']['frac']))"; }
 {
 $B | L "S-DAM 4096^2 godunov f64 [20,220)"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: fp32 lines with the tile-height rule (default), against forced 32-row tiles (what round 3 shipped)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-B="python bench.py --no-cpu-baseline --no-manning-leg --no-strict-leg --repeats 2 --precision f32"
+B="python bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --no-strict-leg --repeats 2 --precision f32"
 P() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-60s %-10s %.4f ms  frac %.3f' % ('$1', '$2', d['ms_per_step'], d['roofline']['frac']))"; }
 for a in "" "--workload s-rain" "--workload s-rough" "--workload s-rain --cols 8192 --rows 8192 --steps 100" "--workload s-rain --cols 8192 --rows 1026" "--workload s-rain --cols 8192 --rows 2050" "--scheme inertial" "--cols 2048 --rows 2048" "--cols 1024 --rows 1024"; do
   HP_MARCH_RSEG=32 HP_INERTIAL_RSEG=32 $B $a 2>/dev/null | P "f32 $a" "32 rows"

@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-run}
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_pytest.log | tail -2
 for args in "--scheme godunov" "--scheme muscl" "--scheme inertial" "--scheme godunov --precision f32" "--scheme muscl --precision f32" "--workload s-rain" "--workload s-rain --precision f32"; do
-  line=$(timeout 300 python3 bench.py --no-cpu-baseline --no-manning-leg --steps 200 --warmup 20 $args 2>&1 | grep '^{' | tail -1)
+  line=$(timeout 300 python3 bench.py --no-cpu-baseline --no-manning-leg --no-moving-leg --steps 200 --warmup 20 $args 2>&1 | grep '^{' | tail -1)
   python3 - "$args" "$line" <<'PY'
 import json, sys
 a, l = sys.argv[1:3]
