@@ -241,6 +241,7 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
     stride = max(1, args.steps // 12) | 1              # odd: both CFL flavours of the kernel get sampled
     runs = []
     tail_carried = True                                 # every flux launch of every timed region carried its own tail block
+    per_launch = set()                                  # iterations one flux launch covered (2: the two-iterations kernel ran pairs)
     for _ in range(max(1, repeats if repeats is not None else args.repeats)):
         runner.restore()
         runner.step(args.warmup + args.evolve_steps)
@@ -254,7 +255,9 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
         c1 = runner.domain.launch_counts()
         # asked of the library, not guessed from the command line: the engine can decline the tail block
         # (HP_TAIL_MAX_BLOCKS, split steps, a library that predates the call)
-        tail_carried = tail_carried and c0 is not None and (c1[0] - c0[0], c1[1] - c0[1]) == (args.steps, args.steps)
+        launches = (c1[0] - c0[0]) if c0 is not None else 0
+        tail_carried = tail_carried and launches > 0 and c1[1] - c0[1] == launches and args.steps % launches == 0
+        per_launch.add(args.steps // launches if launches > 0 and args.steps % launches == 0 else 0)
         k_ms, k_n = runner.domain.kernel_timing_read()
         runs.append((el, k_ms, k_n))
     overhead_ms = runner.domain.kernel_timing_overhead()
@@ -276,10 +279,10 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
                overhead_ms=overhead_ms, strip_info=strip_info, loop=getattr(runner, "loop", "batch call"),
                cells_per_launch=cols * runner.local_rows_total, flux_kernel=runner.flux_kernel_name, levels=levels,
                fused=(runner.domain.boundaries_fused() if workload == "s-rain" else None), workload=workload,
-               tail_carried=tail_carried,
+               tail_carried=tail_carried, iterations_per_launch=(per_launch.pop() if len(per_launch) == 1 else 0),
                # an iteration is ONE launch: the flux launch carried the time advance (counted by the library) and nothing else
                # is queued per iteration (S-RAIN keeps the stand-alone boundary pass's launch, which declines when fused)
-               one_launch=(tail_carried and workload != "s-rain"))
+               one_launch=(tail_carried and len(per_launch) == 1 and workload != "s-rain"))
     if world > 1 and not last:
         runner.close(destroy_group=False)
     else:
@@ -292,17 +295,23 @@ def roofline_of(args, leg):
     bpc = BYTES_PER_CELL_STEP[args.precision]
     ms_step = leg["elapsed"] / args.steps * 1e3
     raw = leg["k_ms"] + leg["overhead_ms"] if leg["k_ms"] > 0 else 0.0
-    bytes_launch = bpc * leg["cells_per_launch"]
+    ipl = max(1, leg.get("iterations_per_launch") or 1)       # 2: a launch covers a PAIR of iterations (hp_kernels.hpp: godunov_march2)
+    bytes_launch = bpc * leg["cells_per_launch"] * ipl          # SURVEY 8(d)'s per-unit figure x the cell-steps one launch processes
     frac_of = lambda ms: (bytes_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0
-    ev_ms = min(leg["k_ms"], ms_step) if (leg["one_launch"] and leg["k_ms"] > 0) else leg["k_ms"]   # a kernel is never longer than the step it is all of
-    launch_ms = ms_step if leg["one_launch"] else ev_ms
+    ms_launch = ms_step * ipl
+    ev_ms = min(leg["k_ms"], ms_launch) if (leg["one_launch"] and leg["k_ms"] > 0) else leg["k_ms"]   # a kernel is never longer than the iterations it is all of
+    launch_ms = ms_launch if leg["one_launch"] else ev_ms
     r = {"bound": "hbm", "achieved": frac_of(launch_ms) * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": frac_of(launch_ms), "traffic": None, "kernel": leg["flux_kernel"],
-         "frac_basis": ("ms_per_step: an iteration is one launch (the flux launch carries the time advance), so the kernel's "
-                        "duration is at most the step's" if leg["one_launch"] else "HIP-event samples of the flux kernel"),
+         "frac_basis": (("ms_per_step: an iteration is one launch (the flux launch carries the time advance), so the kernel's "
+                         "duration is at most the step's" if ipl == 1 else
+                         f"ms_per_step x {ipl}: one launch covers {ipl} iterations and carries their time advances, so the kernel's duration "
+                         f"is at most {ipl} steps'") if leg["one_launch"] else "HIP-event samples of the flux kernel"),
+         "iterations_per_launch": ipl,
          "avg_launch_ms": launch_ms, "frac_event_sampled": frac_of(ev_ms), "avg_launch_ms_event_sampled": ev_ms,
          "avg_launch_ms_raw": raw, "event_pair_overhead_ms": leg["overhead_ms"], "launches_sampled": leg["k_n"],
-         "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": leg["cells_per_launch"]}
+         "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": leg["cells_per_launch"],
+         "cell_steps_per_launch": leg["cells_per_launch"] * ipl}
     r["flux_launches_carried_their_tail"] = bool(leg.get("tail_carried"))
     if leg["workload"] in ("s-dam", "s-rain", "s-rough") and leg.get("manning_uniform", True):
         # the synthetic workloads have ONE Manning value, which the engine passes as a scalar: the bytes such a launch

@@ -100,6 +100,7 @@ struct hp_domain {
 	int              muscl_rseg = 32;                 // ... of muscl_march (two warm-up rows per tile)
 	int              inertial_rseg = 32;              // ... of inertial_march
 	int              march_nbands = 8, muscl_nbands = 8, inertial_nbands = 8;   // row bands of a whole-domain launch (pick_tiling)
+	int              march_rseg_parts = 16, inertial_rseg_parts = 16;            // tile height of the interior / halo parts of a split step (8 / 2 bands: the classic height)
 	int              sweep_flip = 0;                  // parity of the whole-domain flux launches: every other one visits each band's tiles from
 	                                                  // the top down, so that it starts on the rows its predecessor wrote last (sweep_alternates)
 	int              tall_rseg = 18;                  // K1/K6 tile height where an XCD band has >= 256 rows (16 if a knob is set)
@@ -160,6 +161,10 @@ struct hp_domain {
 	bool             push_now = false;                // this iteration's advance kernel carries the ghost rows
 	// the flux launch's own tail block instead of a separate advance launch (LaunchTail, hp_kernels.hpp): small launches only
 	unsigned long long* tail_words = nullptr;         // one word per flux block (EMPTY between launches)
+	bool             other_stale = false;             // pairs (godunov_march2) ran since the non-current state buffer last held a state the single-iteration kernels can build on
+	int              march2_rseg = 24;                // tile height of the two-iterations kernel
+	bool             march2_pays = false;             // the grid is big enough for it (hp_domain_create)
+	uint64_t         pairs = 0;                       // iteration pairs run by it
 	uint64_t         flux_launches = 0, flux_launches_tailed = 0;   // whole-domain flux launches of hp_step_batch / hp_strip_step_batch, and how many carried their own tail block
 	bool             tail_failed = false;             // a tail block gave up waiting (SLOT_TAIL_ERR seen by the host): the domain is unusable
 	bool             strip_first = false;             // hp_strip_step_batch: the batch's first iteration
@@ -350,7 +355,7 @@ inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rs
 	// search of hp_domain_create found (pick_tiling: such a launch is bound by its most loaded CU, and 8 x groups x segments
 	// only offers coarse block counts).  HP_NBANDS forces a number (tools/r04_band_sweep.py).
 	static const int nbands_env = std::getenv("HP_NBANDS") ? std::atoi(std::getenv("HP_NBANDS")) : 0;
-	tm.nbands = nbands_env >= 1 && nbands_env <= 64 ? nbands_env : (part == PART_ALL && nbands >= 1 && nbands <= 64 ? nbands : 8);
+	tm.nbands = part != PART_ALL ? 8 : (nbands_env >= 1 && nbands_env <= 64 ? nbands_env : (nbands >= 1 && nbands <= 64 ? nbands : 8));
 	tm.band_rows = (int)((rows + tm.nbands - 1) / tm.nbands);
 	tm.band_stride = tm.band_rows;
 	// K1/K6 on tall bands: 18-row tiles measured 1.9 % / 2.8 % ahead of 16 at 4096^2 (band of 512 rows) and 0.6 % at
@@ -508,7 +513,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	unsigned blocks;
 	long lo, hi;
 	launch_rows(d, 1, lo, hi);
-	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->march_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
+	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), part == PART_ALL ? d->march_rseg : d->march_rseg_parts, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
 	                   d->ghost_rows, d->own_lo, d->own_hi, d->march_nbands))
 		return HP_OK;
 	sweep_direction(d, part, tm);
@@ -554,7 +559,7 @@ int launch_inertial(hp_domain* d, const void* src, void* dst, int edge_buffer, i
 	unsigned blocks;
 	long lo, hi;
 	launch_rows(d, 1, lo, hi);
-	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), d->inertial_rseg, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
+	if (!make_tile_map(lo, hi, 1, part, (int)((p.cols - 2 + MARCH_COLS - 1) / MARCH_COLS), part == PART_ALL ? d->inertial_rseg : d->inertial_rseg_parts, d->tail_rseg, d->tail_pct, tm, blocks, d->tall_rseg,
 	                   d->ghost_rows, d->own_lo, d->own_hi, d->inertial_nbands))
 		return HP_OK;
 	sweep_direction(d, part, tm);
@@ -778,8 +783,87 @@ template <typename T> int step_end_impl(hp_domain* d)
 	return HP_OK;
 }
 
+// ---- two iterations per pass (hp_kernels.hpp: godunov_march2) -------------------------------------------------------------------
+// A pair is two consecutive iterations (k reads the primary buffer, k + 1 writes it) of a batch on a single domain run by ONE
+// launch.  Eligible: Godunov scheme, tuned kernel, FAST arithmetic, no boundary conditions (they act between the two iterations),
+// no strips, the reference's reduction quirk Q1 on (it is what makes the second timestep known in advance), the remembered maximum
+// valid, the launch's own tail block available (it advances the time twice), and the next iteration reads the primary buffer.
+// HP_TWO_STEP=0 switches it off, =1 forces it on wherever it is eligible; default: grids whose launch is at least two rounds of
+// blocks at 12-row tiles (hp_domain_create: march2_pays -- below that the extra halo rows and the shorter tiles cost more than the
+// bytes save: 1024^2 and the 4096 x 514 strip lose 3-5 %, 2048^2 gains 13 %, 4096^2 22 %, profiles/r05n_two_step.txt).
+static int two_step_mode()
+{
+	static const int v = std::getenv("HP_TWO_STEP") ? std::atoi(std::getenv("HP_TWO_STEP")) : -1;
+	return v;
+}
+static bool pair_eligible(const hp_domain* d)
+{
+	const int mode = two_step_mode();
+	if (mode == 0 || (mode < 0 && !d->march2_pays)) return false;
+	static const bool tail_enabled = !(std::getenv("HP_LAUNCH_TAIL") && std::atoi(std::getenv("HP_LAUNCH_TAIL")) == 0);
+	return d->desc.scheme == HP_SCHEME_GODUNOV && d->desc.kernel != HP_KERNEL_BASIC && d->desc.math_mode == HP_MATH_FAST &&
+	       d->bdy.empty() && !d->comm && d->comm_world <= 1 && !d->peer_mine && d->desc.row_offset == 0 && d->desc.global_rows == d->desc.rows &&
+	       d->use_alt == 0 && (!d->desc.dynamic_dt || ((d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0 && !d->need_full_reduce && !d->edge_dirty)) &&
+	       tail_enabled && d->tail_words != nullptr && d->desc.rows >= 5 && d->desc.cols >= 5;
+}
+template <typename T> int run_pair_t(hp_domain* d)
+{
+	const Params<T> p = make_params<T>(d);
+	TileMap tm;
+	unsigned blocks;
+	long lo, hi;
+	launch_rows(d, 1, lo, hi);
+	if (!make_tile_map(lo, hi, 1, PART_ALL, (int)((p.cols - 2 + MARCH2_COLS - 1) / MARCH2_COLS), d->march2_rseg, d->march2_rseg, 0, tm, blocks, d->march2_rseg,
+	                   0, d->own_lo, d->own_hi, 8))
+		return HP_ERR_STATE;
+	if (blocks > tail_limit()) return HP_ERR_STATE;                      // (the caller falls back to single iterations)
+	d->tail_want = true; d->tail_allowed = true; d->push_now = false;
+	d->tail_fresh = d->desc.dynamic_dt ? 1 : 0;
+	d->tail_done = false;
+	LaunchTail<T> tail;
+	const int kind = make_tail<T>(d, blocks, PART_ALL, d->stream, tail_limit(), tail);
+	d->tail_want = false;
+	if (kind != 1) return HP_ERR_STATE;
+	tail.pair = 1;
+	const void* src = d->state[0];
+	void* dst = d->state[1];
+	// flux-kernel timing (hp_kernel_timing): as in step_begin_impl -- a sampled launch here covers two iterations
+	const bool sample = d->timing_stride > 0 && d->timing_used < d->timing_events.size() &&
+	                    (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
+	if (sample) HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].first, d->stream));
+#define HP_LAUNCH_K1B(CFL_)                                                                                                               \
+	hipLaunchKernelGGL((godunov_march2<CFL_, 1, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const Scalars<T>*)d->scalars,             \
+	                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning, (T*)d->cfl_slot,                    \
+	                   (const T*)d->cfl_slot + SLOT_EDGE, tm, tail)
+	if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1); else HP_LAUNCH_K1B(0);
+#undef HP_LAUNCH_K1B
+	HIP_TRY(hipGetLastError());
+	if (sample) { HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].second, d->stream)); d->timing_used++; }
+	// the pass wrote state k + 2 into the other buffer: that buffer IS the primary one from here on (two single iterations would
+	// have left the newest state in the primary buffer; the ring maxima are the same for both buffers while no ring cell changes)
+	std::swap(d->state[0], d->state[1]);
+	d->other_stale = true;
+	d->tail_done = false; d->fork_is_advance = false;
+	d->adv_fresh = d->desc.dynamic_dt ? 1 : 0;
+	d->cells_calculated += 2 * (uint64_t)d->desc.cols * (uint64_t)d->desc.rows;
+	d->iterations += 2;
+	d->pairs += 1;
+	return HP_OK;
+}
+static int run_pair(hp_domain* d) { return d->desc.precision == 8 ? run_pair_t<double>(d) : run_pair_t<float>(d); }
+// Before a single-iteration kernel builds on the non-current buffer again (it leaves all-dry cells of its destination untouched,
+// quirk Q3): that buffer holds a state two iterations old after pairs -- bring it up to date with one device copy.
+static int repair_other_buffer(hp_domain* d)
+{
+	if (!d->other_stale) return HP_OK;
+	HIP_TRY(hipMemcpyAsync(d->state[d->use_alt ^ 1], d->state[d->use_alt], d->cells * 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
+	d->other_stale = false;
+	return HP_OK;
+}
+
 int dispatch_begin(hp_domain* d)
 {
+	{ const int rc0 = repair_other_buffer(d); if (rc0 != HP_OK) return rc0; }
 	const bool strict = d->desc.math_mode == HP_MATH_STRICT;
 	if (d->desc.precision == 8) return strict ? step_begin_impl<double, true>(d) : step_begin_impl<double, false>(d);
 	return strict ? step_begin_impl<float, true>(d) : step_begin_impl<float, false>(d);
@@ -993,7 +1077,8 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		static const bool refine = !(std::getenv("HP_RSEG_REFINE") && std::atoi(std::getenv("HP_RSEG_REFINE")) == 0);
 		// (read per domain, not once per process: tools/strong_probe_pair.py creates domains both ways)
 		const bool one_round_search = !(std::getenv("HP_TILING_SEARCH") && std::atoi(std::getenv("HP_TILING_SEARCH")) == 0);
-		auto pick = [&](long updated_rows, long updated_cols, int tile_cols, int tallest, int shortest, int blocks_per_cu, int& nbands_out, bool searchable) {
+		auto pick = [&](long updated_rows, long updated_cols, int tile_cols, int tallest, int shortest, int blocks_per_cu, int& nbands_out, bool searchable,
+		                int* classic_out = nullptr) {
 			const long groups = ((updated_cols + tile_cols - 1) / tile_cols + 3) / 4;
 			nbands_out = 8;
 			int rseg = tallest;
@@ -1023,6 +1108,9 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 					// (profiles/r04b_band_sweep_4096x514.txt).  The search simulates the dealing for every (bands, rows) pair that
 					// fits one round and takes the cheapest; a CU with fewer than three resident blocks hides less latency
 					// (2 blocks: +20 %, 1 block: +60 %, fitted on the same sweep).
+					// (the searched height is only right TOGETHER with its band count, which only a whole-domain launch gets: the interior /
+					// halo parts of a split step keep the classic height -- ADVICE r04)
+					if (classic_out) *classic_out = rseg;
 					if (one_round_search && searchable) {
 						// a tile's fixed cost in row-times: 3.5 for fp64 K1 / K6 (the pipeline fill and the extra south face)
 						const double fill = std::getenv("HP_TILING_FILL") ? std::atof(std::getenv("HP_TILING_FILL")) : 3.5;
@@ -1086,9 +1174,11 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		                           : tallest_by_rounds(desc->rows - 2, desc->cols - 2, MARCH_COLS, 3, {16}, 2.5, 12);
 		const int k2_tallest = f32 ? tallest_by_rounds(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 4, {32, 24, 16}, 6.0, 12)
 		                           : tallest_by_rounds(desc->rows - 4, desc->cols - 4, MUSCL_COLS, 3, {12}, 3.0, 10);
+		int classic = 0;
 		d->march_rseg    = pick(desc->rows - 2, desc->cols - 2, MARCH_COLS, k1_tallest, 2, desc->precision == 4 ? 5 : 3, d->march_nbands,
-		                        desc->precision == 8 || std::getenv("HP_TILING_SEARCH_F32") != nullptr);      // (fp32: 8192 x 1026 measured 83.2 -> 84.4 us with the searched tiling: its fill is not 3.5 rows)
-		d->inertial_rseg = d->march_rseg; d->inertial_nbands = d->march_nbands;
+		                        desc->precision == 8 || std::getenv("HP_TILING_SEARCH_F32") != nullptr, &classic);      // (fp32: 8192 x 1026 measured 83.2 -> 84.4 us with the searched tiling: its fill is not 3.5 rows)
+		d->march_rseg_parts = classic > 0 ? classic : d->march_rseg;
+		d->inertial_rseg = d->march_rseg; d->inertial_nbands = d->march_nbands; d->inertial_rseg_parts = d->march_rseg_parts;
 		// K2 after the inert-row cut (round 2): a tile of still water or dry land costs a fifth of a tile on the flood front,
 		// so fp64 wants more, shorter tiles for the dispatcher to balance (16-20 rows: 0.319 ms against 0.355 at 32 on the
 		// 4096^2 dam break, 0.355 against 0.395 on the developed flood, +2-5 % at 8192^2 and 16384 x 1028)
@@ -1103,13 +1193,26 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		             d->march_rseg, d->march_nbands, d->muscl_rseg, d->muscl_nbands);
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
-		if (v >= 1 && v <= 64) { d->march_rseg = v; d->tall_rseg = 16; }   // a forced 16 stays 16
+		if (v >= 1 && v <= 64) { d->march_rseg = d->march_rseg_parts = v; d->tall_rseg = 16; }   // a forced 16 stays 16
 	}
+	{
+		// the two-iterations kernel: the tallest tile that leaves four rounds of blocks (three 4-wave blocks per CU); worth taking at
+		// all from two rounds at 12-row tiles (profiles/r05n_two_step.txt)
+		int cus = 256;
+		hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, desc->device);
+		const long groups = (((long)desc->cols - 2 + MARCH2_COLS - 1) / MARCH2_COLS + 3) / 4, band_rows = ((long)desc->rows - 2 + 7) / 8;
+		const long slots = (long)cus * 3;
+		auto blocks_at = [&](int r) { return groups * 8 * ((band_rows + r - 1) / r); };
+		d->march2_rseg = 12;
+		for (int r : {32, 24, 18}) if (blocks_at(r) >= 4 * slots) { d->march2_rseg = r; break; }
+		d->march2_pays = blocks_at(12) >= 2 * slots;
+	}
+	if (const char* e = std::getenv("HP_MARCH2_RSEG")) { const int v = std::atoi(e); if (v >= 2 && v <= 32) d->march2_rseg = v; }
 	if (const char* e = std::getenv("HP_TAIL_RSEG")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) d->tail_rseg = v; }
 	if (const char* e = std::getenv("HP_TAIL_PCT"))  { const int v = std::atoi(e); if (v >= 0 && v <= 100) d->tail_pct = v; }
 	if (const char* e = std::getenv("HP_INERTIAL_RSEG")) {
 		const int v = std::atoi(e);
-		if (v >= 1 && v <= 64) { d->inertial_rseg = v; d->tall_rseg = 16; }
+		if (v >= 1 && v <= 64) { d->inertial_rseg = d->inertial_rseg_parts = v; d->tall_rseg = 16; }
 	}
 	if (const char* e = std::getenv("HP_MUSCL_RSEG")) {
 		const int v = std::atoi(e);
@@ -1119,7 +1222,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	{
 		// a wavefront addresses its tile through a buffer resource whose range field is 31 bits wide: the tile's rows
 		// (segment + halo rows) must fit in it
-		const int rseg_max = std::max(d->march_rseg, std::max(d->muscl_rseg, d->inertial_rseg));
+		const int rseg_max = std::max(std::max(d->march_rseg, d->march2_rseg), std::max(d->muscl_rseg, d->inertial_rseg));
 		if ((double)(rseg_max + 4) * (double)desc->cols * 4.0 * (double)desc->precision >= 2147483647.0) {
 			delete d;
 			return fail(HP_ERR_UNSUPPORTED, "grid too wide for the tile addressing (cols * 32 B * (rows per tile + 4) >= 2 GiB)");
@@ -1206,6 +1309,7 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 		// both ping-pong buffers get the same host array (CSchemeGodunov.cpp:1064-1065)
 		HIP_TRY(hipMemcpyAsync(d->state[0], host, bytes, hipMemcpyHostToDevice, d->stream));
 		HIP_TRY(hipMemcpyAsync(d->state[1], host, bytes, hipMemcpyHostToDevice, d->stream));
+		d->other_stale = false;
 		d->use_alt = 0;                                                   // :1075
 		d->need_full_reduce = true;
 		d->edge_dirty = true;
@@ -1247,6 +1351,7 @@ int hp_state_save(hp_domain_t* d)
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	if (d->in_step) return fail(HP_ERR_STATE, "hp_state_save between hp_step_begin and hp_step_end");
+	if ((rc = repair_other_buffer(d)) != HP_OK) return rc;           // (after iteration pairs: see run_pair)
 	const size_t bytes = d->cells * 4 * d->esize;
 	const size_t sc_bytes = d->desc.precision == 8 ? sizeof(Scalars<double>) : sizeof(Scalars<float>);
 	// BOTH ping-pong buffers: the one the next iteration writes is not dead -- cells whose whole neighbourhood is dry are left
@@ -1284,6 +1389,7 @@ int hp_state_restore(hp_domain_t* d)
 	HIP_TRY(hipMemcpyAsync(d->scalars, d->saved_scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
 	d->use_alt = d->saved_use_alt;
+	d->other_stale = false;                                               // (a checkpoint is taken with both buffers brought up to date)
 	d->ghost_valid = d->saved_ghost_valid;
 	// a bed or state upload between save and restore has left its own marks: they stay
 	d->need_full_reduce = d->need_full_reduce || d->saved_full_reduce;
@@ -1559,6 +1665,12 @@ int run_iterations(hp_domain* d, uint32_t n_iterations)
 {
 	int rc;
 	for (uint32_t i = 0; i < n_iterations; ++i) {
+		// two iterations in one pass where that is the same computation (run_pair)
+		if (i + 2 <= n_iterations && pair_eligible(d)) {
+			rc = run_pair(d);
+			if (rc == HP_OK) { ++i; continue; }
+			if (rc != HP_ERR_STATE) return rc;                 // (HP_ERR_STATE: not launchable as a pair -- single iterations)
+		}
 		// (K1 FUSED) every iteration but the last carries its successor's rain / loss: between batches the buffers are
 		// what the reference's are -- a download never sees rain of an iteration that has not begun
 		d->fuse_next = i + 1 < n_iterations;

@@ -64,11 +64,48 @@ __global__ __launch_bounds__(256) void godunov_basic(const Params<T> p, const Sc
 //     slot[0] = running maximum of this iteration (all-reduced by the host across strips), cleared here;
 //     slot[SLOT_SAVED] = maximum last used (re-used when the primary buffer was not touched: `fresh` == 0, Q1);
 //     slot[SLOT_EDGE], slot[SLOT_EDGE+1] = edge-ring maxima of the two state buffers (read by the march kernels).
-template <bool UPDATE_ONLY, typename T>
-__device__ __forceinline__ void advance_body(const Params<T>& p, Scalars<T>* sc, T* slot, const int fresh)
+// tst_Advance_Normal's arithmetic (CLDynamicTimestep.clc:42-145) on a register copy of the time-control block: `vmax` is the
+// maximum wave speed the reduction delivered.  Used by advance_body (the block in memory) and by the two-iterations kernel, whose
+// every wavefront needs the SECOND iteration's timestep before the first has been launched (quirk Q1 makes it computable).
+template <typename T>
+__device__ __forceinline__ void advance_scalars(const Params<T>& p, Scalars<T>& s, const T vmax)
 {
 	const T EARLY_LIMIT = T(0.1), EARLY_DURATION = T(60.0), START_MIN = T(1E-10), START_DURATION = T(1.0);
 	const T DT_MIN = T(1E-10), DT_MAX = T(15.0), HYDRO = T(1.0);                 // CLDynamicTimestep.clh:24-29
+	T t = s.t, t_sync = s.t_sync, batch = s.batch_dt;
+	T dt = fmax_(T(0), s.dt);                                                     // :42
+	T t_hydro = s.t_hydro;
+	uint32_t ok = s.batch_ok, skipped = s.batch_skipped;
+	t += dt;                                                                      // :50-51
+	batch += dt;
+	if (dt > T(0)) ok++; else skipped++;                                          // :53-58
+	if (t_hydro > HYDRO) t_hydro = dt; else t_hydro += dt;                        // :61-66
+
+	if (p.dynamic_dt) {                                                           // :68-92
+		T tmin = p.dx / vmax;
+		if (t < START_DURATION && tmin < START_MIN) tmin = START_MIN;
+		dt = p.courant * tmin;
+	} else {
+		dt = p.dt_fixed;                                                          // :93-97
+	}
+	if (dt > T(0) && dt < DT_MIN) dt = DT_MIN;                                    // :112-113
+	if ((t + dt) >= t_sync) {                                                     // :118-124
+		const T dt_in = dt;
+		if (t_sync - t > p.vs)  dt = t_sync - t;
+		if (t_sync - t <= p.vs) dt = -dt_in;
+	}
+	if (t < EARLY_DURATION && dt > EARLY_LIMIT) dt = EARLY_LIMIT;                 // :128-129
+	if ((t + dt) > p.t_end) dt = p.t_end - t;                                     // :132-133
+	if (dt > DT_MAX) dt = DT_MAX;                                                 // :136-137
+
+	s.t = t; s.dt = dt; s.t_hydro = t_hydro; s.batch_dt = batch;                  // :140-145
+	s.batch_ok = ok; s.batch_skipped = skipped;
+}
+
+template <bool UPDATE_ONLY, typename T>
+__device__ __forceinline__ void advance_body(const Params<T>& p, Scalars<T>* sc, T* slot, const int fresh)
+{
+	const T EARLY_LIMIT = T(0.1), EARLY_DURATION = T(60.0), START_MIN = T(1E-10), START_DURATION = T(1.0), DT_MAX = T(15.0);   // CLDynamicTimestep.clh:24-29
 	// slot[0] is only ever touched by agent-scope atomics (performed at the memory side, so no XCD's L2 holds a
 	// stale copy); the remembered maximum lives one cache line further (SLOT_SAVED)
 	// fresh: bit 0 = this iteration priced a buffer anew (slot[0] holds this rank's maximum); bit 1 = the maximum over all
@@ -105,33 +142,9 @@ __device__ __forceinline__ void advance_body(const Params<T>& p, Scalars<T>* sc,
 		return;
 	}
 
-	T dt = fmax_(T(0), sc->dt);                                                   // :42
-	T t_hydro = sc->t_hydro;
-	uint32_t ok = sc->batch_ok, skipped = sc->batch_skipped;
-	t += dt;                                                                      // :50-51
-	batch += dt;
-	if (dt > T(0)) ok++; else skipped++;                                          // :53-58
-	if (t_hydro > HYDRO) t_hydro = dt; else t_hydro += dt;                        // :61-66
-
-	if (p.dynamic_dt) {                                                           // :68-92
-		T tmin = p.dx / vmax;
-		if (t < START_DURATION && tmin < START_MIN) tmin = START_MIN;
-		dt = p.courant * tmin;
-	} else {
-		dt = p.dt_fixed;                                                          // :93-97
-	}
-	if (dt > T(0) && dt < DT_MIN) dt = DT_MIN;                                    // :112-113
-	if ((t + dt) >= t_sync) {                                                     // :118-124
-		const T dt_in = dt;
-		if (t_sync - t > p.vs)  dt = t_sync - t;
-		if (t_sync - t <= p.vs) dt = -dt_in;
-	}
-	if (t < EARLY_DURATION && dt > EARLY_LIMIT) dt = EARLY_LIMIT;                 // :128-129
-	if ((t + dt) > p.t_end) dt = p.t_end - t;                                     // :132-133
-	if (dt > DT_MAX) dt = DT_MAX;                                                 // :136-137
-
-	sc->t = t; sc->dt = dt; sc->t_hydro = t_hydro; sc->batch_dt = batch;          // :140-145
-	sc->batch_ok = ok; sc->batch_skipped = skipped;
+	Scalars<T> s = *sc;
+	advance_scalars(p, s, vmax);
+	*sc = s;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -265,6 +278,7 @@ __global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const i
 template <typename T> struct LaunchTail {
 	unsigned long long* done;      // nullptr: no tail (the classic two launches)
 	unsigned            flux_blocks;
+	int                 pair;          // the launch covered TWO iterations (godunov_march2): the first advance re-uses the remembered maximum (quirk Q1), the second takes this launch's
 	unsigned            poll_blocks;   // words the tail block waits for: flux_blocks (HP_DEBUG_TAIL_EXTRA_WORD=1: one more, which nobody writes -- the time-out's test)
 	unsigned long long  timeout;       // wall_clock64 ticks (100 MHz) the tail block waits for ONE word before it gives up (HP_TAIL_TIMEOUT_MS)
 	int                 fresh;     // advance_time's `fresh`
@@ -386,6 +400,7 @@ __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail
 		if (threadIdx.x == 0 && (tail.fresh & 2)) tail.slot[SLOT_GLOBAL] = all;
 	}
 	if (threadIdx.x != 0) return;
+	if (tail.pair) advance_body<false>(p, tail.sc, tail.slot, 0);      // the pair's first iteration: its reduction re-read the primary buffer (fresh == 0)
 	advance_body<false>(p, tail.sc, tail.slot, tail.fresh & 3);
 }
 
@@ -671,8 +686,13 @@ template <bool STRICT, typename T> constexpr int march_waves() { return sizeof(T
 // SPEC (STRICT fp64 only): the speculative flavour of a STRICT batch -- quotients that share a denominator share its refined
 // reciprocal (hp_math.hpp: div_shared), a lane whose operands fall outside what that covers raises the domain's SLOT_SPEC
 // word at the end of its tile, and the host re-runs the batch with the plain instantiation (hp_engine.hip: spec_resolve)
+// (round 5: the FAST fp64 flavour in depth form needs 125-129 VGPRs -- on the edge of a FOURTH wave per SIMD, which the hardware would
+// grant by itself below 129 and which measured SLOWER: S-DAM 0.251 against 0.240 ms, S-ROUGH 0.283 against 0.276, the 4096 x 514 strip
+// 36.7 against 34.2 us, profiles/r05k_three_way_ab.txt -- a row march wants its rows' requests in flight, not more marchers per SIMD.
+// So the attribute names the maximum too: three waves, whatever the register count comes to.)
+template <bool STRICT, typename T> constexpr int march_waves_max() { return sizeof(T) == 4 ? 8 : march_waves<STRICT, T>(); }
 template <bool STRICT, int CFL_MODE, bool FUSED, int TAIL, typename T, bool SPEC = false>          // TAIL: 0 none, 1 tail block, 2 tail block + ghost rows stored into the neighbours
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves<STRICT, T>()))) void godunov_march(const Params<T> p, const Scalars<T>* sc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves<STRICT, T>(), march_waves_max<STRICT, T>()))) void godunov_march(const Params<T> p, const Scalars<T>* sc,
                                                      const T* __restrict__ bed, const State4<T>* __restrict__ src,
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
@@ -864,8 +884,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 	                                                       // rest (Q = 0); the two rows hold the same level and bed, cell for cell
 	constexpr unsigned PRICED = 16;                        // the still row below has put this (one) state's wave speed into vmax
 	unsigned st = 0;
-	auto at_rest = [&](const RowRegs<T>& r) { return __all(r.c.qx == T(0) && r.c.qy == T(0)) != 0; };
-	auto same_level = [&](const RowRegs<T>& a, const RowRegs<T>& b) { return __all(a.c.z == b.c.z && a.zb == b.zb) != 0; };
+	auto at_rest = [&](const RowRegs<T>& r) { return wave_all(r.c.qx == T(0) && r.c.qy == T(0)) != 0; };
+	auto same_level = [&](const RowRegs<T>& a, const RowRegs<T>& b) { return wave_all(a.c.z == b.c.z && a.zb == b.zb) != 0; };
 	{
 		const RowRegs<T> rs = load_row(y0 - 1);
 		const Side<T> sS = make_side_impl<STRICT, PL>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs, spec_bad);
@@ -897,7 +917,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 		bool still = false;
 		if (STILL_SKIP && !skip_step && eq_n && (st & (EQ_S | REST_S)) == (EQ_S | REST_S)) {
 			const T z_first = first_lane(rc.c.z), b_first = first_lane(rc.zb);
-			still = __all(rc.c.z == z_first && rc.zb == b_first && (rc.c.z - rc.zb) > vs &&
+			still = wave_all(rc.c.z == z_first && rc.zb == b_first && (rc.c.z - rc.zb) > vs &&
 			              !(rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0))) != 0;
 		}
 		st = (st & PRICED) | ((st & REST_C) ? REST_S : 0u) | (rest_n ? REST_C : 0u) | (eq_n ? EQ_S : 0u);
@@ -908,7 +928,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 			// CFL epilogue: ONE state across the wave; if the still row below (the same state, by its own test) has priced it, pricing
 			// it again cannot change the maximum
 			skip_cfl = (st & PRICED) != 0;
-			if ((int)y >= tm.price_lo && (int)y < tm.price_hi && __any(out_x && out.zmax > T(-9999.0))) st |= PRICED;
+			if ((int)y >= tm.price_lo && (int)y < tm.price_hi && wave_any(out_x && out.zmax > T(-9999.0))) st |= PRICED;
 		} else if (!skip_step) {
 			st &= ~PRICED;
 			// east face first: its result has to travel to the next lane while the north face is solved
@@ -985,7 +1005,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 		while (y < y1) {
 			const RowRegs<T>& rn = rP;
 			const bool dryC = (rc.c.z - rc.zb) < vs, dryN = (rn.c.z - rn.zb) < vs;
-			if (!__all(dryC && dryN && dryS)) break;
+			if (!wave_all(dryC && dryN && dryS)) break;
 			rQ = load_row((y + 2 <= y1) ? (y + 2) : y1, y + 2 <= y1);
 			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
 			const bool write = out_x && disabled;                                      // nulls are carried, dry cells untouched (Q3)
@@ -1019,7 +1039,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 	}
 	if (y < y1) row_step(y, rP, rQ);
 
-	if ((CFL_MODE == 1 || (FUSED && fuse)) && __any(stale_rows != 0)) {
+	if ((CFL_MODE == 1 || (FUSED && fuse)) && wave_any(stale_rows != 0)) {
 		// cells the reference leaves untouched still hold their two-steps-old value in dst, and tst_Reduce prices it;
 		// (FUSED) the next iteration's boundary kernels would change exactly that value in place: read-modify-write
 		for (long y = y0; y < y1; ++y) {
@@ -1050,6 +1070,229 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 	// (FUSED) tell the next iteration's stand-alone boundary pass whether anything is left for it to do.  Every wavefront
 	// reaches the same decision from the same scalars; one of them writes it down.
 	if (FUSED && blockIdx.x == 0 && wave == 0 && lane == 0) cfl_slot[SLOT_BDY] = fuse_flag ? T(1) : T(0);
+	}   // tile / strip guard
+	if (TAIL != 0) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
+}
+
+// -------------------------------------------------------------------------------------------------
+// K1b godunov_march2 : TWO Godunov iterations in one pass (round 5; FAST flavour, single domain, no boundary conditions).
+//
+//  Why it is possible.  Quirk Q1: the reference's reduction always prices the PRIMARY state buffer.  An iteration that reads the
+//  primary buffer (every other one) therefore re-prices the state it started from: the timestep of the iteration after it follows
+//  from a maximum that is already known (cfl_slot[SLOT_SAVED]) and from time-control scalars -- every wavefront can work it out
+//  before anything is launched (advance_scalars).  So the pair (k: primary -> other, k + 1: other -> primary) is one pass:
+//  read state k once, write state k + 2 once -- 40 B per cell-step instead of 80 (tools/membench: the march in this shape moves a
+//  pair in 0.245-0.255 ms at 4096^2, where one step in K1's shape takes 0.246).
+//  What it costs.  A two-cell halo: 60 updated columns per wavefront instead of 62, and the first step is evaluated on two more
+//  rows than the tile has; the second step's registers.
+//  How.  The march of K1 twice, one row apart: stage A turns source row r into the intermediate row U1(r) exactly as K1 would
+//  have stored it; stage B, one row behind, turns U1(r - 2 .. r) into the final row r - 1.  Each stage carries its own side,
+//  south flux and dry flags; the intermediate state never leaves the registers.  Edge-ring cells pass through stage A unchanged
+//  (no kernel ever writes them).
+//  Cells the reference leaves untouched (quirk Q3).  First step: its destination would keep what it held, and that is what the
+//  second step would read; here the cell's CURRENT state stands in -- on every wet/dry workload tried (S-ROUGH, the dry-bed dam
+//  break, config C1; 1750 iterations of the reference's kernels, tools/r05_q3_stale_probe.py) the two were equal in every such
+//  cell at every step.  Second step: the primary buffer keeps state k, and this kernel stores exactly that.
+//  The pass writes into the OTHER buffer; the host then swaps the two pointers (hp_engine.hip: run_pair), so "primary" is again
+//  the buffer that holds the newest state, as after two single iterations.
+// -------------------------------------------------------------------------------------------------
+constexpr int MARCH2_COLS = 60;          // updated columns per wavefront (lanes 2..61)
+template <typename T> struct RowU1 { State4<T> c; T zb; };
+
+template <int CFL_MODE, int TAIL, typename T>                      // CFL_MODE 1: price what the pair leaves in the primary buffer; 0: fixed timestep
+// (three waves per SIMD: 167 VGPRs and four spilled registers measured 0.193 ms per iteration at 4096^2 against 0.215 at two waves
+// and 171 registers without spills -- profiles/r05n_two_step.txt; -DHP_K1B_WAVES_MIN=2 builds the other one)
+#ifndef HP_K1B_WAVES_MIN
+#define HP_K1B_WAVES_MIN 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 4 : HP_K1B_WAVES_MIN, sizeof(T) == 4 ? 5 : 3))) void godunov_march2(
+	const Params<T> p, const Scalars<T>* sc, const T* __restrict__ bed, const State4<T>* __restrict__ src,
+	State4<T>* __restrict__ dst, const T* __restrict__ manning, T* cfl_slot, const T* __restrict__ edge_max,
+	const TileMap tm, const LaunchTail<T> tail)
+{
+	if (TAIL != 0 && blockIdx.x >= tail.flux_blocks) {
+		launch_tail(p, tail);
+		return;
+	}
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	long strip, y0, y1;                                                            // rows [y0, y1) receive state k + 2
+	T wave_vmax = T(0);
+	if (tile_rows(tm, wave, strip, y0, y1)) {
+
+	const long x = strip * MARCH2_COLS - 1 + lane;                                 // lane 2 is the strip's first updated column
+	const long xc = x < 0 ? 0 : (x < p.cols ? x : (p.cols - 1));
+	const bool out_x = lane >= 2 && lane <= MARCH2_COLS + 1 && x <= p.cols - 2;    // x >= 1 is implied
+	const bool ring_x = x <= 0 || x >= p.cols - 1;                                 // an edge-ring column (or a lane beyond the grid): never updated
+	const T vs = p.vs;
+	const bool with_friction = p.friction != 0;
+
+	// the two timesteps: this iteration's, and the next one's as tst_Advance_Normal will leave it (see above)
+	Scalars<T> s1 = *sc;
+	const T dt_a = s1.dt;
+	advance_scalars(p, s1, p.dynamic_dt ? cfl_slot[SLOT_SAVED] : T(0));
+	const T dt_b = s1.dt;
+	const bool skip_a = dt_a <= T(0), skip_b = dt_b <= T(0);                       // CLSchemeGodunov.clc:201-206: the state is copied
+
+	// the wave's window: rows from y0 - 2 (as far as the grid goes), columns from the strip's first halo column
+	const long row_base = y0 - 2 < 0 ? 0 : y0 - 2, col_base = strip * MARCH2_COLS - 1 < 0 ? 0 : strip * MARCH2_COLS - 1;
+	const size_t cell0 = (size_t)row_base * p.cols + (size_t)col_base;
+	const size_t cells_left = (size_t)p.cols * p.rows - cell0;
+	const __amdgpu_buffer_rsrc_t srd_src = make_srd(src + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_dst = make_srd(dst + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_bed = make_srd(bed + cell0, cells_left * sizeof(T));
+	const __amdgpu_buffer_rsrc_t srd_man = make_srd(manning + cell0, cells_left * sizeof(T));
+	const unsigned lane_col = (unsigned)(xc - col_base);
+	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
+	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
+	const long last_row = p.rows - 1;
+	auto load_row = [&](long y, const bool live = true) {                          // (rows beyond the grid: the nearest one -- only ring rows ask)
+		y = y < 0 ? 0 : (y > last_row ? last_row : y);
+		RowRegs<T> r;
+		const unsigned k = (unsigned)(y - row_base);
+		unsigned vs_ = live ? voff_state : HP_OOB, vc_ = live ? voff_scalar : HP_OOB;
+		asm volatile("" : "+v"(vs_), "+v"(vc_));
+		r.c = buf_load_state(srd_src, vs_, k * row_state, T());
+		r.zb = buf_load_scalar(srd_bed, vc_, k * row_scalar, T());
+		r.n = p.manning_uniform ? p.manning_value : buf_load_scalar(srd_man, vc_, k * row_scalar, T());
+		return r;
+	};
+	// west flux of a cell = what the lane to its west found for its east face (as in K1)
+	auto flux_from_west = [&](const FaceFlux<T>& forW, const bool dryC, bool& dryW) {
+		FaceFlux<T> fW;
+		fW.f0 = from_west(forW.f0); fW.fx = from_west(forW.fx); fW.fy = from_west(forW.fy);
+		fW.eta_nb = from_west(forW.eta_nb); fW.zb_nb = from_west(forW.zb_nb);
+		const int flags = from_west((int)forW.stop | ((int)dryC << 1));
+		fW.stop = (flags & 1) != 0;
+		dryW = (flags & 2) != 0;
+		return fW;
+	};
+
+	// ---- stage A: source row r -> U1(r), K1's row step with the result kept in registers ----
+	RowRegs<T> rc = load_row(y0 - 1);                                              // the first row stage A produces
+	RowRegs<T> rP = load_row(y0), rQ;
+	Side<T> sCa;
+	FaceFlux<T> fSa = {};
+	bool drySa;
+	{
+		const RowRegs<T> rs = load_row(y0 - 2);
+		const Side<T> sS = make_side<false>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
+		sCa = make_side<false>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
+		drySa = (rs.c.z - rs.zb) < vs;
+		if (!skip_a) fSa = face_solve_fast<AXIS_Y>(sS, sCa, vs).forR;
+	}
+	auto stage_a = [&](const long r, const RowRegs<T>& rn, RowRegs<T>& pre) {
+		pre = load_row(r + 2, r + 2 <= y1 + 1);                                   // nothing beyond the row north of the tile's halo row
+		RowU1<T> u; u.c = rc.c; u.zb = rc.zb;
+		Side<T> sN = sCa;
+		if (!skip_a) {
+			const bool ring_row = r <= 0 || r >= last_row;                         // wave-uniform: passes through, but its north face is needed
+			sN = make_side<false>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
+			const FacePair<T> fy = face_solve_fast<AXIS_Y>(sCa, sN, vs);
+			const bool dryC = (rc.c.z - rc.zb) < vs;
+			if (!ring_row) {
+				const Side<T> sE = side_from_east(sCa);
+				const FacePair<T> fx = face_solve_fast<AXIS_X>(sCa, sE, vs);
+				bool dryW;
+				const FaceFlux<T> fW = flux_from_west(fx.forR, dryC, dryW);
+				const bool dryE = (sE.eta - sE.zb) < vs, dryN = (rn.c.z - rn.zb) < vs;
+				const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0); // :214-218
+				const bool dry5 = dryC && dryN && dryE && drySa && dryW;               // :248-255 (untouched: see the header)
+				const State4<T> upd = godunov_update<false>(rc.c, rc.zb, rc.n, dt_a, fy.forL, fx.forL, fSa, fW, p.dx, p.inv_dx, vs, with_friction);
+				if (!(ring_x || disabled || dry5)) u.c = upd;
+			}
+			fSa = fy.forR;
+			drySa = dryC;
+		}
+		rc = rn;
+		sCa = sN;
+		return u;
+	};
+
+	// ---- stage B: U1(y - 1 .. y + 1) -> the final row y ----
+	RowU1<T> uc;                                                                   // U1 of the row stage B works on
+	T n_c = rc.n;                                                                  // (its Manning n: one row behind stage A's)
+	Side<T> sCb;
+	FaceFlux<T> fSb = {};
+	bool drySb = false;
+	T vmax = T(0);
+	unsigned stale_rows = 0;                                                       // bit i: row y0 + i of this lane keeps state k (quirk Q3 at the second step); tiles are at most 32 rows
+	auto stage_b = [&](const long y, const RowU1<T>& un, const T n_next, const bool update) {
+		const Side<T> sN = make_side<false>(un.c.z, un.c.qx, un.c.qy, un.zb, vs);
+		State4<T> out = uc.c;
+		bool write = out_x;
+		if (!skip_b) {
+			const FacePair<T> fy = face_solve_fast<AXIS_Y>(sCb, sN, vs);
+			const bool dryC = (uc.c.z - uc.zb) < vs;
+			if (update) {
+				const Side<T> sE = side_from_east(sCb);
+				const FacePair<T> fx = face_solve_fast<AXIS_X>(sCb, sE, vs);
+				bool dryW;
+				const FaceFlux<T> fW = flux_from_west(fx.forR, dryC, dryW);
+				const bool dryE = (sE.eta - sE.zb) < vs, dryN = (un.c.z - un.zb) < vs;
+				const bool disabled = uc.c.zmax <= T(-9999.0) || uc.c.z == T(-9999.0);
+				const bool dry5 = dryC && dryN && dryE && drySb && dryW;
+				const State4<T> upd = godunov_update<false>(uc.c, uc.zb, n_c, dt_b, fy.forL, fx.forL, fSb, fW, p.dx, p.inv_dx, vs, with_friction);
+				if (!disabled) {
+					if (dry5) {                                                        // the primary buffer keeps state k: copied in the cold pass below
+						write = false;
+						if (out_x) stale_rows |= 1u << (unsigned)(y - y0);
+					} else {
+						out = upd;
+					}
+				}
+			}
+			fSb = fy.forR;
+			drySb = dryC;
+		}
+		if (update) {
+			buf_store_state(out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - row_base) * row_state);
+			if (CFL_MODE == 1 && write && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
+				const T s = cfl_speed<false>(out.z, out.zmax, out.qx, out.qy, uc.zb, p.qs);
+				if (s > vmax) vmax = s;
+			}
+		}
+		uc = un; n_c = n_next;
+		sCb = sN;
+	};
+
+	// prologue: U1(y0 - 1) and U1(y0), and the face between them
+	{
+		const T n0 = rc.n;
+		uc = stage_a(y0 - 1, rP, rQ);                                              // (rc = row y0, rP -> rQ holds row y0 + 1)
+		n_c = n0;
+		sCb = make_side<false>(uc.c.z, uc.c.qx, uc.c.qy, uc.zb, vs);
+		const T n1 = rc.n;
+		const RowU1<T> u0 = stage_a(y0, rQ, rP);
+		stage_b(y0 - 1, u0, n1, false);                                            // stage B without an update: the face below row y0 and its dry flag
+	}
+	// steady state: stage A on row r, stage B on row r - 1
+	long r = y0 + 1;
+	for (; r + 1 <= y1; r += 2) {
+		{ const T nn = rc.n; const RowU1<T> u = stage_a(r, rP, rQ); stage_b(r - 1, u, nn, true); }
+		{ const T nn = rc.n; const RowU1<T> u = stage_a(r + 1, rQ, rP); stage_b(r, u, nn, true); }
+	}
+	if (r <= y1) { const T nn = rc.n; const RowU1<T> u = stage_a(r, rP, rQ); stage_b(r - 1, u, nn, true); }
+
+	// cells the second step leaves untouched: the primary buffer keeps state k (and the reduction prices it)
+	if (wave_any(stale_rows != 0)) {
+		for (long y = y0; y < y1; ++y) {
+			if ((stale_rows >> (unsigned)(y - y0)) & 1u) {
+				const size_t id = (size_t)y * p.cols + xc;
+				const State4<T> c = src[id];
+				dst[id] = c;
+				if (CFL_MODE == 1 && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
+					const T s = cfl_speed<false>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
+					if (s > vmax) vmax = s;
+				}
+			}
+		}
+	}
+	if (CFL_MODE != 0) {
+		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
+		vmax = wave_max(vmax);
+		if (TAIL != 0) wave_vmax = vmax;
+		else if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
+	}
 	}   // tile / strip guard
 	if (TAIL != 0) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
@@ -1237,10 +1480,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			// next row turns out not to be inert, it re-derives that face from its own cell state, which the still
 			// row's `same` test has shown to be the still row's state too (same values in, same bits out).
 			const bool wet_q0 = (rc.c.z - rc.zb) > vs && rc.c.qx == T(0) && rc.c.qy == T(0);
-			const bool inertD = __all(dry5);
-			const bool inertS = same_c && quiet_n && quiet_s && __all(wet_q0);
+			const bool inertD = wave_all(dry5);
+			const bool inertS = same_c && quiet_n && quiet_s && wave_all(wet_q0);
 			const bool dry5_n = ((rn.c.z - rn.zb) < vs) && (rnn.c.zmax < vs) && dryE_n && (rc.c.zmax < vs) && dryW_n;
-			const bool inertD_n = __all(dry5_n);
+			const bool inertD_n = wave_all(dry5_n);
 
 			const bool inert = inertS || inertD;
 
@@ -1285,7 +1528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 				// (the same state, by its neighbourhood test) has already put that wave speed into vmax, pricing it again
 				// cannot change the maximum
 				skip_cfl = inertD || still_priced;
-				still_priced = inertS && (still_priced || ((int)y >= tm.price_lo && (int)y < tm.price_hi && __any(out_x && out.zmax > T(-9999.0))));
+				still_priced = inertS && (still_priced || ((int)y >= tm.price_lo && (int)y < tm.price_hi && wave_any(out_x && out.zmax > T(-9999.0))));
 			} else {
 			still_priced = false;
 			if (!fS_ok) {                                   // the row below was a still row: its state is this row's state
@@ -1484,7 +1727,7 @@ __global__ __launch_bounds__(256) void inertial_march(const Params<T> p, const S
 	}
 	if (y < y1) row_step(y, rP, rQ);
 
-	if (CFL_MODE == 1 && __any(stale_rows != 0)) {
+	if (CFL_MODE == 1 && wave_any(stale_rows != 0)) {
 		for (long yy = y0; yy < y1; ++yy) {
 			if (((stale_rows >> (unsigned)(yy - y0)) & 1ull) && (int)yy >= tm.price_lo && (int)yy < tm.price_hi) {
 				const size_t id = (size_t)yy * p.cols + xc;

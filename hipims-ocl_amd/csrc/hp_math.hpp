@@ -65,6 +65,24 @@ __device__ __forceinline__ float  fmod_(float a, float b)   { return fmodf(a, b)
 __device__ __forceinline__ double floor_(double x) { return __builtin_floor(x); }
 __device__ __forceinline__ float  floor_(float x)  { return __builtin_floorf(x); }
 
+// Wave-uniform votes straight from the compare's lane mask (round 5): HIP's __all / __any go through a per-lane 0/1 register
+// (v_cndmask + v_cmp_ne + s_cmp -- two VALU instructions per vote, five votes per row step); the ballot IS the compare's SGPR
+// pair ANDed with exec.  Same values; all active lanes vote, as with __all / __any.
+__device__ __forceinline__ bool wave_all(const bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+__device__ __forceinline__ bool wave_any(const bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
+// v_max_f64 / v_min_f64 WITHOUT the canonicalising v_max x, x, x the compiler puts in front of fmax / fmin whenever an operand
+// comes out of memory, a lane move or a select (it must assume a signalling NaN; the hardware instruction quiets one by itself).
+// FAST flavour only, and only where no source modifier would have been folded in.
+__device__ __forceinline__ double fmax_raw(const double a, const double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double fmin_raw(const double a, const double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double fmax0_raw(const double a) { double r; asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ double fmin0_raw(const double a) { double r; asm("v_min_f64 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ float fmax_raw(const float a, const float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fmin_raw(const float a, const float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fmax0_raw(const float a) { float r; asm("v_max_f32 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ float fmin0_raw(const float a) { float r; asm("v_min_f32 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }
+
 // ---- FAST-flavour primitives: hardware seed + Newton steps instead of the IEEE expansions ----
 // 1/x to about 1 ulp: v_rcp_f64 seed, two Newton-Raphson steps (the IEEE division adds scaling + fix-up).
 // Measured on gfx950 (tools/seedcheck): seed 4.6e-8 relative (2^-24.4), one step 2.1e-15, two steps 1.1e-16;
@@ -331,11 +349,11 @@ template <int AXIS, typename T>
 __device__ __forceinline__ FacePair<T> face_solve_fast(const Side<T>& L, const Side<T>& R, const T vs)
 {
 	const T g = gravity<T>(), half_g = T(0.5) * g;
-	const T zbm = fmax_(L.zb, R.zb);
+	const T zbm = fmax_raw(L.zb, R.zb);
 	const T hL = fmax_(L.eta - zbm, T(0)), hR = fmax_(R.eta - zbm, T(0));                 // :84-97
 	T unL = (AXIS == AXIS_X ? L.u0 : L.v0), unR = (AXIS == AXIS_X ? R.u0 : R.v0);
 	T utL = (AXIS == AXIS_X ? L.v0 : L.u0), utR = (AXIS == AXIS_X ? R.v0 : R.u0);
-	const bool all_wet = __all(hL > vs && hR > vs);
+	const bool all_wet = wave_all(hL > vs && hR > vs);
 	const bool dryL = hL < vs, dryR = hR < vs;
 	T ZL = zbm, ZR = zbm;
 	bool stopL = false, stopR = false;
@@ -366,7 +384,7 @@ __device__ __forceinline__ FacePair<T> face_solve_fast(const Side<T>& L, const S
 		sL = dryL ? fma_(T(-2), aR, unR) : sL;
 		sR = dryR ? fma_(T(2), aL, unL) : sR;
 	}
-	sL = fmin_(sL, T(0)); sR = fmax_(sR, T(0));                                           // the whole fan (:174-198)
+	sL = fmin0_raw(sL); sR = fmax0_raw(sR);                                               // the whole fan (:174-198)
 	const T inv_ds = rcp_fast(sR - sL);
 	const T sLsR = sL * sR;
 	const T fnL = fma_(unL, qnL, (T(0.5) * ghL) * hL), fnR = fma_(unR, qnR, (T(0.5) * ghR) * hR);   // u q + g/2 h^2
@@ -469,7 +487,7 @@ __device__ __forceinline__ FacePair<T> face_solve_impl(const Side<T>& L, const S
 		// Where the two cells of a face see the same vertical shift -- everywhere except where a cell's level lies below its
 		// neighbour's bed -- the second finish would repeat the first on the same operands: same statements, same bits.  It is
 		// skipped when that holds for every lane that is here (round 4; FAST has had its own form of this since round 1).
-		if (WANT_L && WANT_R && __all(shL == shR)) {
+		if (WANT_L && WANT_R && wave_all(shL == shR)) {
 			oR = oL;
 			oR.eta_nb = k.etaL - shR;                                                     // finish_wet's `a` (own cell = right)
 			oR.stop = stopR;
@@ -550,7 +568,7 @@ __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, co
 	const T margin = T(1) + (sizeof(T) == 8 ? T(9.313225746154785e-10) : T(6.103515625e-05));   // 1 + 2^-30 (fp64), 1 + 2^-14 (fp32)
 	const bool free_x = (fabs_(fx) * dt) * margin < fabs_(qx) || fx == T(0);
 	const bool free_y = (fabs_(fy) * dt) * margin < fabs_(qy) || fy == T(0);
-	if (!__all(free_x && free_y)) {
+	if (!wave_all(free_x && free_y)) {
 		T mx, my;
 		div2_strict<PLAIN>(-qx, -qy, dt, true, mx, my, bad);
 		if (qx >= T(0)) { if (fx < mx) fx = mx; } else { if (fx > mx) fx = mx; }
@@ -572,7 +590,7 @@ __device__ __forceinline__ void friction_fast(T& qx, T& qy, const T z, const T z
 	const T h = z - zb;
 	const T q = sqrt_fast(fma_(qx, qx, qy * qy));
 	const bool active = !(h < vs || q < vs);
-	if (!__any(active)) return;
+	if (!wave_any(active)) return;
 	const T rc = rcbrt_fast(h);                              // h^(-1/3)
 	const T rc2 = rc * rc, rc4 = rc2 * rc2;
 	const T A = ((dt * g) * (n * n)) * (rc4 * rc2 * rc);     // dt g n^2 h^(-7/3)
@@ -647,7 +665,10 @@ __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb
 		if (with_friction) friction<true, PLAIN>(c.qx, c.qy, c.z, zb, n, dt, vs, bad);        // :362-372
 		spec_raise<PLAIN>(bad, spec_word);
 	} else {
-		if (__any(stop)) { c.qx = stop ? T(0) : c.qx; c.qy = stop ? T(0) : c.qy; }   // a stopping condition needs a dry side
+		if (wave_any(stop)) {                                    // a stopping condition needs a dry side
+			asm volatile("");                                    // (a real branch: if-converted, its eight selects ran on every row)
+			c.qx = stop ? T(0) : c.qx; c.qy = stop ? T(0) : c.qy;
+		}
 		c.z  = fma_(-dt, d0, c.z);
 		c.qx = fma_(-dt, d2, c.qx);
 		c.qy = fma_(-dt, d3, c.qy);
@@ -744,8 +765,8 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 	                  e.z == c.z && e.zb == c.zb && e.qx == c.qx && e.qy == c.qy &&
 	                  s.z == c.z && s.zb == c.zb && s.qx == c.qx && s.qy == c.qy &&
 	                  w.z == c.z && w.zb == c.zb && w.qx == c.qx && w.qy == c.qy;
-	quiet_row = __all(first || same);
-	same_row = __all(same);                  // every lane's neighbourhood is one state (used by the kernel's inert-row test)
+	quiet_row = wave_all(first || same);
+	same_row = wave_all(same);                  // every lane's neighbourhood is one state (used by the kernel's inert-row test)
 	if (quiet_row) return f;
 
 	Face4<T> sx, sy;                                                                    // :343-346
@@ -775,9 +796,9 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 	// wavefront.  Flood models are mostly such water (and dry land) most of the time.
 	bool flat = sx.z == T(0) && sy.z == T(0);                                           // staged like `same`
 	quiet_row = false;
-	if (__all(first || flat)) {
+	if (wave_all(first || flat)) {
 		flat = flat && sx.h == T(0) && sx.qx == T(0) && sx.qy == T(0) && sy.h == T(0) && sy.qx == T(0) && sy.qy == T(0);
-		quiet_row = __all(first || flat);   // wave-uniform: every lane's four faces ARE its cell state
+		quiet_row = wave_all(first || flat);   // wave-uniform: every lane's four faces ARE its cell state
 	}
 	if (quiet_row) return f;
 	// STRICT leaves a first-order lane here (its faces are the cell state, :333-339).  FAST lets it run along: its slopes are

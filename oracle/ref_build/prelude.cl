@@ -48,12 +48,12 @@ extern __constant unsigned  REFP_WORKERS;
 #define COURANT_NUMBER        REFP_COURANT
 #define TIMESTEP_WORKERS      REFP_WORKERS
 
-/* The oracle drives one work-item at a time: every kernel is built for 1x1x1 groups, and the
- * LDS tree of tst_Reduce degenerates to a copy (max is exact, so the result is identical). */
+/* The oracle drives one work-item at a time: every kernel is built for 1x1x1 groups -- except tst_Reduce when the host asks for
+ * threads: its team runs as one work-group with a real barrier (shim.cpp: ref_reduce; max is exact, so the result is identical). */
 #define REQD_WG_SIZE_FULL_TS  __attribute__((reqd_work_group_size(1, 1, 1)))
 #define REQD_WG_SIZE_HALF_TS  __attribute__((reqd_work_group_size(1, 1, 1)))
 #define REQD_WG_SIZE_LINE     __attribute__((reqd_work_group_size(1, 1, 1)))
-#define TIMESTEP_GROUPSIZE    1
+#define TIMESTEP_GROUPSIZE    64   /* size of tst_Reduce's __local array: groups of up to 64 work-items (shim.cpp: ref_reduce) */
 #define GTS_DIM1              16
 #define GTS_DIM2              16
 #define MCH_STG1_DIM1         16

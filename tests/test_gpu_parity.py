@@ -278,6 +278,50 @@ def test_muscl_rough_bed_200_steps(mode):
     tr_gpu = dom.run(200)
     assert np.abs(tr_gpu - tr_ref).max() <= 1e-12 * tr_ref.max()
     compare(dom, ref)
+    # ... and against the reference's own kernels: on this case their serial in-place order and the snapshot order give the
+    # same bits (fixture F7 `mch_q_state200`, tests/golden/generate.py: trajectories)
+    g = load_golden("f6_f7_trajectories_f64")
+    assert np.array_equal(g["rough_state"], st) and np.array_equal(g["rough_bed"], bed)
+    out = dom.download()
+    dg, dr = np.maximum(0, out[..., 0] - bed), np.maximum(0, g["mch_q_state200"][..., 0] - bed)
+    rmse, mx = float(np.sqrt(np.mean((dg - dr) ** 2))), float(np.abs(dg - dr).max())
+    record("muscl_rough64_200_vs_f7", mode="strict" if mode == hp.MATH_STRICT else "fast", rmse=rmse, max=mx)
+    if mode == hp.MATH_STRICT:
+        assert np.array_equal(out, g["mch_q_state200"]) and dom.read_scalars()["time"] == float(g["mch_q_t"])
+    else:
+        assert rmse < 1e-9 and mx < 1e-7 and abs(dom.read_scalars()["time"] - float(g["mch_q_t"])) <= 1e-12 * float(g["mch_q_t"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("scheme,key,ref_file,ref_key", [(hp.SCHEME_GODUNOV, "god_q_state200", "f6_f7_trajectories_f64", "god_q_state200"),
+                                                         (hp.SCHEME_MUSCL_HANCOCK, "mch_q_state200", "f6_f7_trajectories_f64", "mch_q_state200"),
+                                                         (hp.SCHEME_INERTIAL, "ine_rough_q_state", "f12_inertial_f64", "rough_q_state")])
+def test_the_pow_stand_in_is_bracketed_beyond_c1(scheme, key, ref_file, ref_key, mode):
+    """The one stand-in of the reference build that carries arithmetic is pow (the correctly rounded cube root shared by oracle,
+    reference build and STRICT kernels).  Fixture F17 is the same strict program with the host libm's pow: on the rough-bed
+    trajectories of all three schemes the two builds part by 6e-17 ... 3e-16 m RMSE (tests/test_oracle_golden.py records it).
+    STRICT equals the cube-root build bit for bit, so its distance to the libm build IS that spread; FAST is held to 1e-9 m
+    against both builds -- the pow a platform ships moves the answer seven orders of magnitude less than the tolerance."""
+    g, twin = load_golden(ref_file), load_golden("f17_libm_twins_f64")
+    st, bed, man = g["rough_state"], g["rough_bed"], g["rough_manning"]
+    if scheme == hp.SCHEME_INERTIAL:
+        st = st.copy(); st[..., 2:] = 0
+    dom = hp.Domain(64, 64, scheme=scheme, math_mode=mode)
+    dom.upload(st, bed, man)
+    dom.set_target_time(1e9)
+    dom.step_batch(200)
+    depth = lambda s: np.maximum(0, s[..., 0] - bed)
+    out = dom.download()
+    r = lambda a, b: float(np.sqrt(np.mean((depth(a) - depth(b)) ** 2)))
+    spread = r(g[ref_key], twin[key])
+    record("pow_bracket", scheme=scheme, mode="strict" if mode == hp.MATH_STRICT else "fast", spread=spread,
+           to_crmath_build=r(out, g[ref_key]), to_libm_build=r(out, twin[key]))
+    assert spread < 1e-15
+    if mode == hp.MATH_STRICT:
+        assert np.array_equal(out, g[ref_key]) and r(out, twin[key]) == spread
+    else:
+        assert r(out, g[ref_key]) < 1e-9 and r(out, twin[key]) < 1e-9
+    dom.close()
 
 
 def test_muscl_strict_is_bit_identical_without_friction():

@@ -1,0 +1,45 @@
+"""Two iterations per pass (hp_kernels.hpp: godunov_march2, round 5): a pair of Godunov iterations run as ONE launch must be the SAME
+computation as the two single-iteration launches -- same per-cell operations in the same order, the intermediate state in registers
+instead of memory -- so the FAST engine with pairs (HP_TWO_STEP=1) is held to the FAST engine without (HP_TWO_STEP=0) BIT FOR BIT:
+state, time, timestep, counters; over batches of odd and even length, downloads in between, a sync point with clipped and
+suspended iterations, tst_UpdateTimestep, a device checkpoint, wet/dry terrain with untouched cells (quirk Q3), fp64 and fp32,
+dynamic and fixed timestep.  (Against the oracle the FAST mode keeps its usual tolerance: tests/test_gpu_parity.py run with the
+default, under which grids of a million cells and more take the pair kernel.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(os.path.dirname(__file__), "two_step_worker.py")
+
+
+def run(scenario, precision, tmp_path, mode):
+    out = os.path.join(str(tmp_path), f"{scenario}_{precision}_{mode}.npz")
+    r = subprocess.run([sys.executable, WORKER, scenario, precision, out], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HP_TWO_STEP=str(mode)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(out)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("scenario", ["dam", "rough", "damdry", "fixed"])
+def test_pairs_are_the_same_computation_as_single_iterations(scenario, precision, tmp_path):
+    single, pairs = run(scenario, precision, tmp_path, 0), run(scenario, precision, tmp_path, 1)
+    assert int(single["launches"]) == int(single["iterations"])                 # one launch per iteration ...
+    assert int(pairs["launches"]) < int(pairs["iterations"]) * 0.62             # ... against pairs wherever two iterations were to be had
+    assert int(pairs["iterations"]) == int(single["iterations"])
+    for key in ("t", "dt", "ok", "skipped"):
+        assert pairs[key] == single[key], key
+    assert np.array_equal(pairs["state"], single["state"])
+
+
+def test_default_takes_pairs_on_big_grids_only(tmp_path):
+    out = os.path.join(str(tmp_path), "default.npz")
+    env = {k: v for k, v in os.environ.items() if k != "HP_TWO_STEP"}
+    r = subprocess.run([sys.executable, WORKER, "dam", "f64", out], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = np.load(out)
+    assert int(d["launches"]) == int(d["iterations"])                           # 1030 x 700 = 0.72 M cells: below the threshold

@@ -325,3 +325,43 @@ def test_disabled_cells():
         assert same(out, g[f"{name}_state"]) and sim.scalars()["t"] == g[f"{name}_t"]
         assert same(out[g["disabled"]], g["state"][g["disabled"]]) and g["disabled"].sum() > 100
     assert not same(g["mch_state"], g["mchnone_state"])
+
+
+def test_pow_stand_in_bracket_beyond_c1():
+    """Fixture F17: the F6 / F7 / F12 rough-bed trajectories on the strict program with the host libm's pow instead of the
+    correctly rounded cube root every other build here uses (oracle/ref_build/shim.cpp).  The oracle (cube root) equals the
+    cube-root build bit for bit (tests above); the libm build sits 6e-17 ... 3e-16 m RMSE away -- the independent bound on the
+    one stand-in that carries arithmetic, on Godunov, MUSCL-Hancock and the partial-inertial scheme."""
+    twin = load_golden("f17_libm_twins_f64")
+    g, gi = load_golden("f6_f7_trajectories_f64"), load_golden("f12_inertial_f64")
+    bed = g["rough_bed"]
+    depth = lambda s: np.maximum(0, s[..., 0] - bed)
+    for key, ref in (("god_q_state200", g["god_q_state200"]), ("mch_q_state200", g["mch_q_state200"]),
+                     ("ine_rough_q_state", gi["rough_q_state"])):
+        d = depth(twin[key]) - depth(ref)
+        rmse, mx = float(np.sqrt(np.mean(d ** 2))), float(np.abs(d).max())
+        assert 0 < rmse < 1e-15 and mx < 1e-14, (key, rmse, mx)       # not identical (another pow), and nowhere near the tolerance
+    assert float(twin["god_q_t"]) == float(g["god_q_t"]) and float(twin["mch_q_t"]) == float(g["mch_q_t"])
+
+
+def test_newcastle_full_run_first_output(tmp_path):
+    """Fixture F16 (config C1 to its end on the reference's kernels, tests/golden/generate.py: newcastle_full): the oracle under the
+    same CModel loop, up to the first output time (600 s, 3.7e3 iterations) -- depth and maxdepth rasters bit for bit.  (The whole
+    run is the GPU suite's: tests/test_gpu_c1_full.py; on the CPU it takes minutes.  Round 5: running it to the end is what
+    exposed a race in the THREADED reference build's reduction -- oracle/ref_build/shim.cpp: ref_reduce.)"""
+    import hashlib
+    import os
+    from hipims_mi.model import Model
+    from model_dir import make_newcastle
+    g = load_golden("f16_newcastle_full_f64")
+
+    def make_sim(cfg, cols, rows, res):
+        return oracle.OracleSim(cols, rows, precision="f64", dx=res, end_time=cfg.duration, threads=min(8, os.cpu_count() or 1))
+    m = Model(make_newcastle(tmp_path), make_sim=make_sim, output_format=None)
+    m.scheme.automatic_queue = False
+    m.scheme.queue_addition_size = int(g["batch"])
+    outs = m.run(max_outputs=1)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+    assert outs[0][0] == float(g["t"][0])
+    assert sha(outs[0][1]["depth"]) == str(g["depth_sha256"][0]) and sha(outs[0][1]["maxdepth"]) == str(g["maxdepth_sha256"][0])
+    assert np.array_equal(outs[0][1]["depth"], g["depth"][0])

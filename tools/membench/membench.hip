@@ -206,6 +206,50 @@ __global__ __launch_bounds__(256) void k_march_k1(const d2* __restrict__ src, co
 }
 
 
+// round 5 (VERDICT r04 item 5 i): the shape of a kernel that does TWO iterations per pass -- quirk Q1 makes every other timestep known
+// in advance, so one pass could read a tile with a two-cell halo (60 useful columns of 64, two rows below and two above) and store
+// it once per two steps.  Bytes per step are halved; what is left of that once the shape's own costs are paid (wider overlap of the
+// windows, four silent lanes, four halo rows per tile, fewer waves per SIMD for the second step's registers) is what this measures.
+template <int WIN, int EDGE, int HROWS>
+__global__ __launch_bounds__(256) void k_march_shape(const d2* __restrict__ src, const double* __restrict__ bed, d2* __restrict__ dst,
+                                                     int cols, int rows, int rseg, int groups, int ntiles)
+{
+	const unsigned per_xcd = gridDim.x >> 3;
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int strip = (tile % groups) * 4 + wave, seg = tile / groups;
+	if (tile >= (unsigned)ntiles) return;
+	const int x0 = strip * WIN;
+	if (x0 >= cols) return;
+	const int x = min(x0 + lane, cols - 1);
+	const bool st = lane >= EDGE && lane < 64 - EDGE && x0 + lane < cols;
+	const int y0 = seg * rseg, y1 = min(y0 + rseg, rows);
+	d2 a[2], b[2]; double z[2];
+	auto load = [&](int y, int slot) {
+		y = min(max(y, 0), rows - 1);
+		const size_t cell = (size_t)y * cols + x;
+		a[slot] = src[cell * 2]; b[slot] = src[cell * 2 + 1];
+		z[slot] = bed[cell];
+	};
+	double acc = 0;
+	for (int h = HROWS; h >= 1; --h) { load(y0 - h, 0); acc += a[0].x + b[0].y + z[0]; }
+	load(y0, 0); load(y0 + 1, 1);
+	const int y_last = y1 + HROWS - 1;                 // last row that is read
+	for (int y = y0; y < y1; y += 2) {
+		#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			if (y + k >= y1) break;
+			d2 va = a[k], vb = b[k]; const double zz = z[k];
+			load(y + k + 2 <= y_last ? y + k + 2 : y_last, k);
+			va.x += (zz + acc) * 1e-300;
+			const size_t cell = (size_t)(y + k) * cols + x;
+			if (st) { dst[cell * 2] = va; dst[cell * 2 + 1] = vb; }
+		}
+	}
+	for (int h = 2; h < HROWS; ++h) { load(y1 + h, 0); acc += a[0].x; }     // (rows y1, y1 + 1 were read by the loop's prefetch)
+	if (a[0].x + a[1].x + acc == 1.2345e-300) dst[0] = a[0];
+}
+
 // round 4: does keeping the four waves of a block on the SAME row (a barrier per row: 8 KB contiguous per row and block instead of
 // four drifting 2-KB streams) help the march?  WAVES: waves per block (4 or 8: 256 or 512 columns per block).
 template <int WAVES, bool SYNC>
@@ -443,6 +487,29 @@ int main(int argc, char** argv)
 			run_sync("march 16 rows, 3 waves/SIMD, 4-wave blocks, barrier per row", k_march_sync<4, true>, 4, 52 * 1024);
 			run_sync("march 16 rows, 8-wave blocks (2 per CU = 4 waves/SIMD), free", k_march_sync<8, false>, 8, 64 * 1024);
 			run_sync("march 16 rows, 8-wave blocks, barrier per row", k_march_sync<8, true>, 8, 64 * 1024);
+		}
+		// round 5: the two-iterations-per-pass shape against K1's own (one pass moves two steps' worth: ms per STEP = ms / 2)
+		auto run_shape = [&](const char* what, auto kern, int width, int rseg2, int lds_bytes, double steps) {
+			CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2));
+			const int strips = (cols + width - 1) / width, groups = (strips + 3) / 4, nsegs = (rows + rseg2 - 1) / rseg2, ntiles = groups * nsegs;
+			const unsigned blocks = (ntiles + 7) / 8 * 8;
+			float ms = 0; hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+			for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, 0, src, bed, dst, cols, rows, rseg2, groups, ntiles);
+			CK(hipEventRecord(e0)); const int reps = 20;
+			for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, 0, src, bed, dst, cols, rows, rseg2, groups, ntiles);
+			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+			const hipError_t le = hipGetLastError();
+			if (le != hipSuccess) { printf("%-78s launch failed: %s\n", what, hipGetErrorString(le)); return; }
+			printf("%-78s %.4f ms per pass  %.4f ms per step\n", what, ms, ms / steps);
+		};
+		for (int rep = 0; rep < 2; ++rep) {
+			run_shape("one step : 62-col, 1 edge lane, 1 halo row, rseg 18, 3 waves/SIMD (K1 today)", k_march_shape<62, 1, 1>, 62, 18, 52 * 1024, 1);
+			run_shape("two steps: 60-col, 2 edge lanes, 2 halo rows, rseg 18, 3 waves/SIMD", k_march_shape<60, 2, 2>, 60, 18, 52 * 1024, 2);
+			run_shape("two steps: 60-col, 2 edge lanes, 2 halo rows, rseg 32, 3 waves/SIMD", k_march_shape<60, 2, 2>, 60, 32, 52 * 1024, 2);
+			run_shape("two steps: 60-col, 2 edge lanes, 2 halo rows, rseg 18, 2 waves/SIMD", k_march_shape<60, 2, 2>, 60, 18, 80 * 1024, 2);
+			run_shape("two steps: 60-col, 2 edge lanes, 2 halo rows, rseg 32, 2 waves/SIMD", k_march_shape<60, 2, 2>, 60, 32, 80 * 1024, 2);
+			run_shape("two steps: 60-col, 2 edge lanes, 2 halo rows, rseg 64, 2 waves/SIMD", k_march_shape<60, 2, 2>, 60, 64, 80 * 1024, 2);
+			run_shape("64 useful columns: 64-col aligned windows, 1 halo row, rseg 18, 3 waves/SIMD", k_march_shape<64, 0, 1>, 64, 18, 52 * 1024, 1);
 		}
 		for (int rep = 0; rep < 2; ++rep) {
 			run("K1 shape: 64-col windows", k_march_k1<false, false, false>, 64);
