@@ -302,7 +302,7 @@ def roofline_of(args, leg):
     ev_ms = min(leg["k_ms"], ms_launch) if (leg["one_launch"] and leg["k_ms"] > 0) else leg["k_ms"]   # a kernel is never longer than the iterations it is all of
     launch_ms = ms_launch if leg["one_launch"] else ev_ms
     r = {"bound": "hbm", "achieved": frac_of(launch_ms) * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": frac_of(launch_ms), "traffic": None, "kernel": leg["flux_kernel"],
+         "frac": frac_of(launch_ms), "traffic": None, "kernel": leg["flux_kernel"] + ("2 (two iterations per launch)" if ipl == 2 else ""),
          "frac_basis": (("ms_per_step: an iteration is one launch (the flux launch carries the time advance), so the kernel's "
                          "duration is at most the step's" if ipl == 1 else
                          f"ms_per_step x {ipl}: one launch covers {ipl} iterations and carries their time advances, so the kernel's duration "
@@ -481,7 +481,8 @@ def main():
                                    "frac_basis": rw["frac_basis"], "frac_event_sampled": rw["frac_event_sampled"],
                                    "kernel": rw["kernel"], "sim_time_s": moving_leg["sc"]["time"]}
         if default_cfg:
-            tr = pmc_traffic(args.scheme + "_march<false", args.scheme)
+            # (the pair kernel's name when launches covered two iterations: hp::godunov_march2<...>)
+            tr = pmc_traffic("godunov_march2<" if out["roofline"]["iterations_per_launch"] == 2 else args.scheme + "_march<false", args.scheme)
             k_ms = out["roofline"]["avg_launch_ms"]
             if tr:
                 out["roofline"]["traffic"] = tr[0] / 1e9 / (k_ms * 1e-3) if k_ms > 0 else None   # GB/s, same unit as achieved

@@ -161,6 +161,8 @@ struct hp_domain {
 	bool             push_now = false;                // this iteration's advance kernel carries the ghost rows
 	// the flux launch's own tail block instead of a separate advance launch (LaunchTail, hp_kernels.hpp): small launches only
 	unsigned long long* tail_words = nullptr;         // one word per flux block (EMPTY between launches)
+	bool             rings_differ = false;            // a partial state upload went into ONE buffer: the edge rings of the two may differ (swap_edge_ring)
+	bool             saved_rings_differ = false;
 	bool             other_stale = false;             // pairs (godunov_march2) ran since the non-current state buffer last held a state the single-iteration kernels can build on
 	int              march2_rseg = 24;                // tile height of the two-iterations kernel
 	bool             march2_pays = false;             // the grid is big enough for it (hp_domain_create)
@@ -841,6 +843,9 @@ template <typename T> int run_pair_t(hp_domain* d)
 	if (sample) { HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].second, d->stream)); d->timing_used++; }
 	// the pass wrote state k + 2 into the other buffer: that buffer IS the primary one from here on (two single iterations would
 	// have left the newest state in the primary buffer; the ring maxima are the same for both buffers while no ring cell changes)
+	if (d->rings_differ)                                                  // (rare: only after partial uploads -- see swap_edge_ring)
+		hipLaunchKernelGGL((swap_edge_ring<T>), dim3(32), dim3(256), 0, d->stream, (State4<T>*)d->state[0], (State4<T>*)d->state[1],
+		                   (long)d->desc.cols, (long)d->desc.rows);
 	std::swap(d->state[0], d->state[1]);
 	d->other_stale = true;
 	d->tail_done = false; d->fork_is_advance = false;
@@ -856,7 +861,16 @@ static int run_pair(hp_domain* d) { return d->desc.precision == 8 ? run_pair_t<d
 static int repair_other_buffer(hp_domain* d)
 {
 	if (!d->other_stale) return HP_OK;
-	HIP_TRY(hipMemcpyAsync(d->state[d->use_alt ^ 1], d->state[d->use_alt], d->cells * 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
+	if (!d->rings_differ) {
+		HIP_TRY(hipMemcpyAsync(d->state[d->use_alt ^ 1], d->state[d->use_alt], d->cells * 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
+	} else if (d->desc.precision == 8) {                                  // (each buffer keeps its own edge ring)
+		hipLaunchKernelGGL((copy_interior<double>), dim3(2048), dim3(256), 0, d->stream, (const State4<double>*)d->state[d->use_alt],
+		                   (State4<double>*)d->state[d->use_alt ^ 1], (long)d->desc.cols, (long)d->desc.rows);
+	} else {
+		hipLaunchKernelGGL((copy_interior<float>), dim3(2048), dim3(256), 0, d->stream, (const State4<float>*)d->state[d->use_alt],
+		                   (State4<float>*)d->state[d->use_alt ^ 1], (long)d->desc.cols, (long)d->desc.rows);
+	}
+	HIP_TRY(hipGetLastError());
 	d->other_stale = false;
 	return HP_OK;
 }
@@ -1310,6 +1324,7 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 		HIP_TRY(hipMemcpyAsync(d->state[0], host, bytes, hipMemcpyHostToDevice, d->stream));
 		HIP_TRY(hipMemcpyAsync(d->state[1], host, bytes, hipMemcpyHostToDevice, d->stream));
 		d->other_stale = false;
+		d->rings_differ = false;
 		d->use_alt = 0;                                                   // :1075
 		d->need_full_reduce = true;
 		d->edge_dirty = true;
@@ -1368,6 +1383,7 @@ int hp_state_save(hp_domain_t* d)
 	d->saved_full_reduce = d->need_full_reduce;
 	d->saved_edge_dirty = d->edge_dirty;
 	d->saved_use_alt = d->use_alt;
+	d->saved_rings_differ = d->rings_differ;
 	d->saved_ghost_valid = d->ghost_valid;
 	d->saved_valid = true;
 	return HP_OK;
@@ -1390,6 +1406,7 @@ int hp_state_restore(hp_domain_t* d)
 	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
 	d->use_alt = d->saved_use_alt;
 	d->other_stale = false;                                               // (a checkpoint is taken with both buffers brought up to date)
+	d->rings_differ = d->saved_rings_differ;
 	d->ghost_valid = d->saved_ghost_valid;
 	// a bed or state upload between save and restore has left its own marks: they stay
 	d->need_full_reduce = d->need_full_reduce || d->saved_full_reduce;
@@ -1428,6 +1445,7 @@ int hp_domain_upload_rows(hp_domain_t* d, const void* host, int64_t row0, int64_
 	                       hipMemcpyHostToDevice, d->stream));
 	d->need_full_reduce = true;
 	d->edge_dirty = true;
+	d->rings_differ = true;
 	return HP_OK;
 }
 

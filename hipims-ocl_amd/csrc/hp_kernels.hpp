@@ -1297,6 +1297,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	if (TAIL != 0) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
 
+// The edge ring of the two state buffers, exchanged (godunov_march2's companion; launched only while the rings differ).  No flux
+// kernel writes ring cells, so each buffer keeps the ring it was given -- the same in both after a full upload, different after
+// a PARTIAL one (queueWritePartial goes to the current buffer only).  Two single iterations leave the newest state in the buffer
+// it started from; a pair leaves it in the other one, and the host swaps the pointers: the rings swap with them here, so that
+// every later download shows what the single iterations would have shown.
+template <typename T>
+__global__ __launch_bounds__(256) void swap_edge_ring(State4<T>* __restrict__ a, State4<T>* __restrict__ b, const long cols, const long rows)
+{
+	const long n = 2 * cols + 2 * (rows - 2);
+	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+		long x, y;
+		if (i < cols) { x = i; y = 0; }
+		else if (i < 2 * cols) { x = i - cols; y = rows - 1; }
+		else { const long j = i - 2 * cols; x = (j & 1) ? cols - 1 : 0; y = 1 + (j >> 1); }
+		const size_t id = (size_t)y * cols + x;
+		const State4<T> va = a[id], vb = b[id];
+		a[id] = vb; b[id] = va;
+	}
+}
+
+// ... and the interior of one buffer copied onto the other's (the rings stay as they are): what hipMemcpy does for run_pair's
+// repair of the non-current buffer while the rings are equal, for the rare domain whose rings differ
+template <typename T>
+__global__ __launch_bounds__(256) void copy_interior(const State4<T>* __restrict__ from, State4<T>* __restrict__ to, const long cols, const long rows)
+{
+	const size_t cells = (size_t)cols * rows;
+	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x) {
+		const long y = (long)(id / cols), x = (long)(id - (size_t)y * cols);
+		if (x >= 1 && x <= cols - 2 && y >= 1 && y <= rows - 2) to[id] = from[id];
+	}
+}
+
 // -------------------------------------------------------------------------------------------------
 // K2  muscl_march : MUSCL-Hancock (MINMOD) predictor + HLLC corrector in ONE pass, double buffered.
 //

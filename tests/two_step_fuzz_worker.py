@@ -1,0 +1,77 @@
+"""Worker of tests/test_gpu_two_step.py::test_pairs_fuzz and tools/r05_two_step_soak.sh: random single-domain Godunov configurations
+(shape, precision, workload, Manning array or not, friction, dx, Courant number, dynamic / fixed timestep, batch pattern with
+downloads, partial uploads, target-time changes, update-timestep calls and checkpoints in between) run on the FAST engine; prints one
+line per seed with a SHA-256 of everything observable.  Run twice (HP_TWO_STEP=0 / 1): the lines must be identical.
+usage: two_step_fuzz_worker.py <first seed> <count>"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hipims-ocl_amd")]
+import hipims_mi as hp  # noqa: E402
+from hipims_mi import synthetic as syn  # noqa: E402
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    precision = "f64" if rng.random() < 0.7 else "f32"
+    real = np.float64 if precision == "f64" else np.float32
+    cols, rows = int(rng.integers(5, 700)), int(rng.integers(5, 500))
+    if rng.random() < 0.25:
+        cols, rows = int(rng.integers(900, 1500)), int(rng.integers(700, 1100))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        st, bed, man = syn.s_dam(cols, rows, dtype=real)
+    elif kind == 1:
+        st, bed, man = syn.s_dam(cols, rows, dtype=real, wet_right=False)
+    else:
+        st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=(None if rng.random() < 0.5 else 0.03), seed=int(rng.integers(0, 1000)))
+    if rng.random() < 0.3:                                # a few null cells (DEM nodata and mask style)
+        for _ in range(int(rng.integers(1, 6))):
+            y, x = int(rng.integers(1, rows - 1)), int(rng.integers(1, cols - 1))
+            st[y, x, 1] = -9999.0
+            if rng.random() < 0.5:
+                st[y, x, 0] = -9999.0; bed[y, x] = -9999.0
+    kw = dict(dx=float(rng.choice([0.5, 1.0, 2.0, 3.0])), courant=float(rng.choice([0.3, 0.5])), friction=bool(rng.random() < 0.8))
+    if rng.random() < 0.2:
+        kw.update(dynamic_dt=False, dt_fixed=float(rng.choice([0.002, 0.01])))
+    dom = hp.Domain(cols, rows, precision=precision, math_mode=hp.MATH_FAST, **kw)
+    dom.upload(st, bed, man)
+    dom.set_target_time(float(rng.choice([1e9, 0.6, 2.0])))
+    h = hashlib.sha256()
+    dump = os.environ.get("FUZZ_DUMP")               # (diagnosis: every op, the scalars and the state behind it)
+    trace = []
+    for _ in range(int(rng.integers(3, 9))):
+        op = rng.integers(0, 10)
+        if dump:
+            trace.append((int(op), dom.read_scalars(), dom.download()))
+        if op <= 4:
+            dom.step_batch(int(rng.integers(1, 40)))
+        elif op == 5:
+            h.update(dom.download().tobytes())
+        elif op == 6:
+            dom.set_target_time(float(dom.read_scalars()["time"] + rng.choice([0.05, 0.5, 5.0])))
+            dom.update_timestep()
+        elif op == 7:
+            dom.state_save(); dom.step_batch(int(rng.integers(1, 12))); dom.state_restore()
+        elif op == 8:
+            y0 = int(rng.integers(0, rows - 2))
+            patch = dom.download(hp.ARRAY_STATE, y0, 2)
+            patch[..., 0] += real(0.01)
+            dom.upload_rows(patch, y0)
+        else:
+            dom.step_batch(int(rng.integers(1, 5)) * 2 + 1)
+    sc = dom.read_scalars()
+    h.update(dom.download().tobytes())
+    h.update(repr((sc["time"], sc["timestep"], sc["batch_successful"], sc["batch_skipped"], sc["iterations"])).encode())
+    counts = dom.launch_counts()
+    if dump:
+        trace.append((-1, sc, dom.download()))
+        np.savez(os.path.join(dump, f"seed{seed}_{os.environ.get('HP_TWO_STEP', 'x')}.npz"), ops=np.array([t[0] for t in trace]),
+                 times=np.array([t[1]["time"] for t in trace]), dts=np.array([t[1]["timestep"] for t in trace]),
+                 its=np.array([t[1]["iterations"] for t in trace]), states=np.stack([t[2] for t in trace]))
+    print(f"seed {seed} {precision} {cols}x{rows} kind {kind} iterations {sc['iterations']} t {sc['time']!r} {h.hexdigest()}  # launches {counts[0]}")
+    dom.close()
