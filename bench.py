@@ -241,6 +241,7 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
     stride = max(1, args.steps // 12) | 1              # odd: both CFL flavours of the kernel get sampled
     runs = []
     tail_carried = True                                 # every flux launch of every timed region carried its own tail block
+    pair_counts = (0, 0)
     per_launch = set()                                  # iterations one flux launch covered (2: the two-iterations kernel ran pairs)
     for _ in range(max(1, repeats if repeats is not None else args.repeats)):
         runner.restore()
@@ -256,8 +257,11 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
         # asked of the library, not guessed from the command line: the engine can decline the tail block
         # (HP_TAIL_MAX_BLOCKS, split steps, a library that predates the call)
         launches = (c1[0] - c0[0]) if c0 is not None else 0
-        tail_carried = tail_carried and launches > 0 and c1[1] - c0[1] == launches and args.steps % launches == 0
-        per_launch.add(args.steps // launches if launches > 0 and args.steps % launches == 0 else 0)
+        tail_carried = tail_carried and launches > 0 and c1[1] - c0[1] == launches
+        # launches < steps: iteration PAIRS ran (godunov_march2; a batch that starts on the odd iteration of a pair runs one
+        # single iteration first and may end with one) -- the dominant kernel then covers two iterations per launch
+        per_launch.add(2 if 0 < launches < args.steps else 1)
+        pair_counts = (args.steps - launches, 2 * launches - args.steps) if 0 < launches < args.steps else (0, launches)
         k_ms, k_n = runner.domain.kernel_timing_read()
         runs.append((el, k_ms, k_n))
     overhead_ms = runner.domain.kernel_timing_overhead()
@@ -279,10 +283,10 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
                overhead_ms=overhead_ms, strip_info=strip_info, loop=getattr(runner, "loop", "batch call"),
                cells_per_launch=cols * runner.local_rows_total, flux_kernel=runner.flux_kernel_name, levels=levels,
                fused=(runner.domain.boundaries_fused() if workload == "s-rain" else None), workload=workload,
-               tail_carried=tail_carried, iterations_per_launch=(per_launch.pop() if len(per_launch) == 1 else 0),
+               tail_carried=tail_carried, iterations_per_launch=(max(per_launch) if per_launch else 1), pair_counts=pair_counts,
                # an iteration is ONE launch: the flux launch carried the time advance (counted by the library) and nothing else
                # is queued per iteration (S-RAIN keeps the stand-alone boundary pass's launch, which declines when fused)
-               one_launch=(tail_carried and len(per_launch) == 1 and workload != "s-rain"))
+               one_launch=(tail_carried and workload != "s-rain"))
     if world > 1 and not last:
         runner.close(destroy_group=False)
     else:
@@ -298,7 +302,7 @@ def roofline_of(args, leg):
     ipl = max(1, leg.get("iterations_per_launch") or 1)       # 2: a launch covers a PAIR of iterations (hp_kernels.hpp: godunov_march2)
     bytes_launch = bpc * leg["cells_per_launch"] * ipl          # SURVEY 8(d)'s per-unit figure x the cell-steps one launch processes
     frac_of = lambda ms: (bytes_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0
-    ms_launch = ms_step * ipl
+    ms_launch = ms_step * ipl       # (pairs: a single iteration at a batch's ends takes longer per step than a pair, so this bounds the pair launch too)
     ev_ms = min(leg["k_ms"], ms_launch) if (leg["one_launch"] and leg["k_ms"] > 0) else leg["k_ms"]   # a kernel is never longer than the iterations it is all of
     launch_ms = ms_launch if leg["one_launch"] else ev_ms
     r = {"bound": "hbm", "achieved": frac_of(launch_ms) * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -307,7 +311,7 @@ def roofline_of(args, leg):
                          "duration is at most the step's" if ipl == 1 else
                          f"ms_per_step x {ipl}: one launch covers {ipl} iterations and carries their time advances, so the kernel's duration "
                          f"is at most {ipl} steps'") if leg["one_launch"] else "HIP-event samples of the flux kernel"),
-         "iterations_per_launch": ipl,
+         "iterations_per_launch": ipl, "timed_region_launches": {"pairs": leg.get("pair_counts", (0, 0))[0], "single_iterations": leg.get("pair_counts", (0, 0))[1]},
          "avg_launch_ms": launch_ms, "frac_event_sampled": frac_of(ev_ms), "avg_launch_ms_event_sampled": ev_ms,
          "avg_launch_ms_raw": raw, "event_pair_overhead_ms": leg["overhead_ms"], "launches_sampled": leg["k_n"],
          "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": leg["cells_per_launch"],

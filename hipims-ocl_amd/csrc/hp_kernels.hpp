@@ -1511,11 +1511,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(muscl_waves
 			// here: that row's five dry tests need rows y..y+2, all in registers); a still row never does -- if the
 			// next row turns out not to be inert, it re-derives that face from its own cell state, which the still
 			// row's `same` test has shown to be the still row's state too (same values in, same bits out).
-			const bool wet_q0 = (rc.c.z - rc.zb) > vs && rc.c.qx == T(0) && rc.c.qy == T(0);
+			// (the votes are taken only where they can matter: live rows pay for `dry5` alone)
 			const bool inertD = wave_all(dry5);
-			const bool inertS = same_c && quiet_n && quiet_s && wave_all(wet_q0);
-			const bool dry5_n = ((rn.c.z - rn.zb) < vs) && (rnn.c.zmax < vs) && dryE_n && (rc.c.zmax < vs) && dryW_n;
-			const bool inertD_n = wave_all(dry5_n);
+			bool inertS = false, inertD_n = false;
+			if (same_c && quiet_n && quiet_s) {
+				const bool wet_q0 = (rc.c.z - rc.zb) > vs && rc.c.qx == T(0) && rc.c.qy == T(0);
+				inertS = wave_all(wet_q0);
+			}
+			if (inertD) {
+				const bool dry5_n = ((rn.c.z - rn.zb) < vs) && (rnn.c.zmax < vs) && dryE_n && (rc.c.zmax < vs) && dryW_n;
+				inertD_n = wave_all(dry5_n);
+			}
 
 			const bool inert = inertS || inertD;
 

@@ -761,12 +761,18 @@ __device__ __forceinline__ Faces<T> muscl_predict_impl(const Raw<T>& c, const Ra
 	// Cheapest sufficient test for a quiet row (see below): a cell whose four neighbours carry exactly its own level, bed
 	// and discharges has all differences zero, hence all limited slopes zero -- sixteen compares instead of the eight
 	// limiter evaluations that would discover the same thing.
-	const bool same = n.z == c.z && n.zb == c.zb && n.qx == c.qx && n.qy == c.qy &&
-	                  e.z == c.z && e.zb == c.zb && e.qx == c.qx && e.qy == c.qy &&
-	                  s.z == c.z && s.zb == c.zb && s.qx == c.qx && s.qy == c.qy &&
-	                  w.z == c.z && w.zb == c.zb && w.qx == c.qx && w.qy == c.qy;
-	quiet_row = wave_all(first || same);
-	same_row = wave_all(same);                  // every lane's neighbourhood is one state (used by the kernel's inert-row test)
+	// (round 5: on live water ONE lane whose northern neighbour stands at another level settles both votes -- the other fifteen
+	// compares are only made where no such lane exists)
+	bool same = false;
+	quiet_row = same_row = false;
+	if (!wave_any(!first && n.z != c.z)) {
+		same = n.z == c.z && n.zb == c.zb && n.qx == c.qx && n.qy == c.qy &&
+		       e.z == c.z && e.zb == c.zb && e.qx == c.qx && e.qy == c.qy &&
+		       s.z == c.z && s.zb == c.zb && s.qx == c.qx && s.qy == c.qy &&
+		       w.z == c.z && w.zb == c.zb && w.qx == c.qx && w.qy == c.qy;
+		quiet_row = wave_all(first || same);
+		same_row = wave_all(same);              // every lane's neighbourhood is one state (used by the kernel's inert-row test)
+	}
 	if (quiet_row) return f;
 
 	Face4<T> sx, sy;                                                                    // :343-346

@@ -343,6 +343,10 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples);   
 /* The cost of an empty event pair that the last hp_kernel_timing() measured and hp_kernel_timing_read() takes off every
  * sample (raw average = avg_ms + this): reported so that lines with and without the correction can be compared. */
 int hp_kernel_timing_overhead(hp_domain_t* d, double* overhead_ms);
+/* (Round 5: where it is the same computation -- Godunov scheme, FAST arithmetic, single domain, no boundary conditions, quirk Q1 on,
+ * a grid of at least two rounds of blocks -- hp_step_batch runs PAIRS of iterations as one launch each (hp_kernels.hpp:
+ * godunov_march2; bit-identical to the single iterations, half the HBM traffic).  HP_TWO_STEP=0 / 1 in the environment forces it
+ * off / on.  Everything observable through this interface is the same either way; hp_launch_counts shows which ran.) */
 /* How many whole-domain flux launches the domain has queued since it was created, and how many of them carried their own tail
  * block (reduction + time advance inside the flux launch: an iteration is then ONE launch; otherwise the flux launch is followed
  * by an advance launch).  bench.py states its roofline basis from the difference of two readings around the timed region. */
