@@ -203,8 +203,11 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
         # HIPIMS_MI_BACKEND=gloo: rehearsal of this branch with several processes on one GPU (host-staged exchange)
         backend = os.environ.get("HIPIMS_MI_BACKEND", "nccl")
         device = local_rank if backend == "nccl" else local_rank % max(1, hp.device_count())
+        # --exchange-period 2: two reaches of ghost rows, one exchange per two iterations -- and, for Godunov FAST strips big enough,
+        # iteration PAIRS as one launch (hp_engine.hip: run_pair; the weak-scaling shape gains 20 % on one GPU).  Opt-in: the
+        # default keeps the transport every multi-rank test and probe of five rounds has run on
         runner = StripRunner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
-                             device=device, rank=rank, world=world, backend=backend)
+                             device=device, rank=rank, world=world, backend=backend, exchange_period=args.exchange_period)
     if workload == "s-rain":
         st, bed, man, rain = syn.s_rain_rows(cols, rows, runner.local_lo, runner.local_hi, dx=dx, dtype=real)
         runner.upload(st, bed, man)
@@ -363,6 +366,8 @@ def main():
     ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
                     help="N > 1: both (default) = `value` from the strong leg (the metric's 4096^2 grid cut into N strips) and the "
                          "object `weak` from the configs' ladder (16.8 Mcell per GPU); weak / strong = that leg only")
+    ap.add_argument("--exchange-period", type=int, choices=[1, 2], default=1,
+                    help="N > 1: iterations per ghost-row exchange (2: two reaches of ghost rows; lets big Godunov strips run iteration pairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-manning-leg", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")

@@ -129,6 +129,7 @@ struct hp_domain {
 	// what the ranks told each other at the start of the batch (hp_strip_step_batch): which of them price a new maximum on
 	// the iterations that the ping-pong phase alone would not make them price
 	bool             strip_any_bdy = false, strip_any_full = false;
+	bool             strip_pairs = false;             // the batch's handshake: every rank can run iteration pairs (godunov_march2 over two-reach ghost rows)
 	// halo overlap (strip decomposition): the row segments next to the ghost rows run on their own stream so the
 	// neighbours' halo transfer can start while the interior segments are still being computed
 	bool             halo_overlap = false;
@@ -803,38 +804,55 @@ static int two_step_mode()
 }
 // (the part of the test that does not change from one iteration to the next: this domain's batches are made of pairs wherever two
 // iterations are to be had)
-static bool pairs_possible(const hp_domain* d)
+static bool pairs_possible_common(const hp_domain* d)
 {
 	const int mode = two_step_mode();
 	if (mode == 0 || (mode < 0 && !d->march2_pays)) return false;
 	static const bool tail_enabled = !(std::getenv("HP_LAUNCH_TAIL") && std::atoi(std::getenv("HP_LAUNCH_TAIL")) == 0);
 	return d->desc.scheme == HP_SCHEME_GODUNOV && d->desc.kernel != HP_KERNEL_BASIC && d->desc.math_mode == HP_MATH_FAST &&
-	       d->bdy.empty() && !d->comm && d->comm_world <= 1 && !d->peer_mine && d->desc.row_offset == 0 && d->desc.global_rows == d->desc.rows &&
-	       (!d->desc.dynamic_dt || (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0) &&
+	       d->bdy.empty() && (!d->desc.dynamic_dt || (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0) &&
 	       tail_enabled && d->tail_words != nullptr && d->desc.rows >= 5 && d->desc.cols >= 5;
+}
+static bool pairs_possible(const hp_domain* d)          // a single domain
+{
+	return pairs_possible_common(d) && !d->comm && d->comm_world <= 1 && !d->peer_mine && d->desc.row_offset == 0 &&
+	       d->desc.global_rows == d->desc.rows;
 }
 static bool pair_eligible(const hp_domain* d)
 {
 	return pairs_possible(d) && d->use_alt == 0 && (!d->desc.dynamic_dt || (!d->need_full_reduce && !d->edge_dirty));
 }
-template <typename T> int run_pair_t(hp_domain* d)
+// A ROW STRIP runs pairs where it stores two reaches of ghost rows (one exchange per two iterations anyway) and the strips write
+// their rows into each other themselves (transport level 2: the pair's tail block holds the one mailbox round, which is the
+// hand-over).  What THIS rank can do goes into the batch's handshake (strip_handshake); the ranks pair up only if all of them can.
+static bool strip_pairs_possible_here(const hp_domain* d)
+{
+	return pairs_possible_common(d) && d->comm && d->comm_world > 1 && d->peer_direct && d->ghost_rows == 2 && !d->rings_differ;
+}
+template <typename T> int run_pair_t(hp_domain* d, const bool strip)
 {
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
 	unsigned blocks;
 	long lo, hi;
-	launch_rows(d, 1, lo, hi);
+	if (strip) {                                                          // the strip's OWNED rows: the pair consumes both reaches of ghost rows
+		const bool south = d->desc.row_offset > 0, north = d->desc.row_offset + d->desc.rows < d->desc.global_rows;
+		lo = south ? d->ghost_rows : 1;
+		hi = d->desc.rows - (north ? d->ghost_rows : 1);
+	} else launch_rows(d, 1, lo, hi);
 	if (!make_tile_map(lo, hi, 1, PART_ALL, (int)((p.cols - 2 + MARCH2_COLS - 1) / MARCH2_COLS), d->march2_rseg, d->march2_rseg, 0, tm, blocks, d->march2_rseg,
 	                   0, d->own_lo, d->own_hi, 8))
 		return HP_ERR_STATE;
 	if (blocks > tail_limit()) return HP_ERR_STATE;                      // (the caller falls back to single iterations)
-	d->tail_want = true; d->tail_allowed = true; d->push_now = false;
-	d->tail_fresh = d->desc.dynamic_dt ? 1 : 0;
+	d->tail_want = true; d->tail_allowed = true; d->push_now = strip;    // (strip: the final rows of the edge ranges leave with the launch)
+	// single domain: the second iteration prices the primary buffer (1); a strip: ... and every rank reduces, through the mailboxes,
+	// whose round is also the hand-over of the rows (7; fixed timestep: the round alone, 4) -- step_begin_impl's `fresh`
+	d->tail_fresh = strip ? (d->desc.dynamic_dt ? 7 : 4) : (d->desc.dynamic_dt ? 1 : 0);
 	d->tail_done = false;
 	LaunchTail<T> tail;
 	const int kind = make_tail<T>(d, blocks, PART_ALL, d->stream, tail_limit(), tail);
-	d->tail_want = false;
-	if (kind != 1) return HP_ERR_STATE;
+	d->tail_want = false; d->push_now = false;
+	if (kind != (strip ? 2 : 1)) return HP_ERR_STATE;
 	tail.pair = 1;
 	const void* src = d->state[0];
 	void* dst = d->state[1];
@@ -842,11 +860,12 @@ template <typename T> int run_pair_t(hp_domain* d)
 	const bool sample = d->timing_stride > 0 && d->timing_used < d->timing_events.size() &&
 	                    (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
 	if (sample) HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].first, d->stream));
-#define HP_LAUNCH_K1B(CFL_)                                                                                                               \
-	hipLaunchKernelGGL((godunov_march2<CFL_, 1, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const Scalars<T>*)d->scalars,             \
+#define HP_LAUNCH_K1B(CFL_, TAIL_)                                                                                                        \
+	hipLaunchKernelGGL((godunov_march2<CFL_, TAIL_, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const Scalars<T>*)d->scalars,         \
 	                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning, (T*)d->cfl_slot,                    \
 	                   (const T*)d->cfl_slot + SLOT_EDGE, tm, tail)
-	if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1); else HP_LAUNCH_K1B(0);
+	if (strip) { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, 2); else HP_LAUNCH_K1B(0, 2); }
+	else       { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, 1); else HP_LAUNCH_K1B(0, 1); }
 #undef HP_LAUNCH_K1B
 	HIP_TRY(hipGetLastError());
 	if (sample) { HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].second, d->stream)); d->timing_used++; }
@@ -856,6 +875,11 @@ template <typename T> int run_pair_t(hp_domain* d)
 		hipLaunchKernelGGL((swap_edge_ring<T>), dim3(32), dim3(256), 0, d->stream, (State4<T>*)d->state[0], (State4<T>*)d->state[1],
 		                   (long)d->desc.cols, (long)d->desc.rows);
 	std::swap(d->state[0], d->state[1]);
+	if (strip) {                                                          // every rank swaps: a neighbour's buffer b is the one it calls b now
+		std::swap(d->peer_state[0][0], d->peer_state[0][1]);
+		std::swap(d->peer_state[1][0], d->peer_state[1][1]);
+		d->ghost_valid = d->ghost_rows;                                   // the exchange happened inside the launch
+	}
 	d->other_stale = true;
 	d->tail_done = false; d->fork_is_advance = false;
 	d->adv_fresh = d->desc.dynamic_dt ? 1 : 0;
@@ -864,7 +888,7 @@ template <typename T> int run_pair_t(hp_domain* d)
 	d->pairs += 1;
 	return HP_OK;
 }
-static int run_pair(hp_domain* d) { return d->desc.precision == 8 ? run_pair_t<double>(d) : run_pair_t<float>(d); }
+static int run_pair(hp_domain* d, const bool strip = false) { return d->desc.precision == 8 ? run_pair_t<double>(d, strip) : run_pair_t<float>(d, strip); }
 // Before a single-iteration kernel builds on the non-current buffer again (it leaves all-dry cells of its destination untouched,
 // quirk Q3): that buffer holds a state two iterations old after pairs -- bring it up to date with one device copy.
 static int repair_other_buffer(hp_domain* d)
@@ -1994,11 +2018,14 @@ int strip_handshake(hp_domain* d)
 {
 	d->strip_any_bdy = !d->bdy.empty() && d->desc.scheme != HP_SCHEME_MUSCL_HANCOCK;
 	d->strip_any_full = d->need_full_reduce;
+	d->strip_pairs = false;
 	if (d->comm_world <= 1) return HP_OK;
 	// (element 0 also carries the mailboxes' sticky error word of THIS rank as a value above 1: the all-reduce then tells every
 	// rank that the exchange broke somewhere, and all of them fail together instead of one leaving the others in a collective)
 	const bool broken = peer_error_check(d) != HP_OK;
-	const double mine[8] = {broken ? 3.0 : (d->strip_any_bdy ? 1.0 : 0.0), d->strip_any_full ? 1.0 : 0.0, (double)d->use_alt, -(double)d->use_alt,
+	// (element 0: 3 = this rank's exchange is broken, 1 = it has boundary conditions, 0.5 = it has none but cannot run iteration
+	// pairs, 0 = it can: the maximum over the ranks says what ALL of them may do)
+	const double mine[8] = {broken ? 3.0 : (d->strip_any_bdy ? 1.0 : (strip_pairs_possible_here(d) ? 0.0 : 0.5)), d->strip_any_full ? 1.0 : 0.0, (double)d->use_alt, -(double)d->use_alt,
 	                        (double)d->ghost_valid, -(double)d->ghost_valid, (double)d->ghost_rows, -(double)d->ghost_rows};
 	double all[8];
 	char* slot = (char*)d->cfl_slot + (size_t)SLOT_HANDSHAKE * d->esize;
@@ -2020,8 +2047,9 @@ int strip_handshake(hp_domain* d)
 		                               : std::string("the exchange between the strips broke on another rank (a strip was not heard from in time)"));
 	if (all[2] != -all[3]) return fail(HP_ERR_STATE, "the strips disagree on the ping-pong phase (different iteration counts?)");
 	if (all[4] != -all[5] || all[6] != -all[7]) return fail(HP_ERR_STATE, "the strips disagree on their ghost rows");
-	d->strip_any_bdy = all[0] > 0.0;
+	d->strip_any_bdy = all[0] >= 1.0;
 	d->strip_any_full = all[1] > 0.0;
+	d->strip_pairs = all[0] == 0.0;
 	return HP_OK;
 }
 
@@ -2378,7 +2406,18 @@ int hp_strip_step_batch(hp_domain_t* d, uint32_t n_iterations)
 	const long g = strip_ghosts(d);
 	if ((rc = strip_handshake(d)) != HP_OK) return rc;
 	d->fork_is_advance = fork_ready && d->comm_world <= 1;            // (the handshake queued work behind the last advance_time)
+	// (a maximum that some rank has yet to price anew -- an upload since the last batch -- keeps the ranks on single iterations
+	// until the first iteration that prices on every rank has run: a decision every rank takes from the same, handshaken facts)
+	bool full_pending = d->strip_any_full;
 	for (uint32_t i = 0; i < n_iterations; ++i) {
+		if (i + 2 <= n_iterations && d->strip_pairs && !full_pending && d->use_alt == 0 && d->ghost_valid == d->ghost_rows) {
+			rc = run_pair(d, true);
+			if (rc != HP_OK) return rc == HP_ERR_STATE ? fail(HP_ERR_STATE, "a strip could not launch an iteration pair the ranks had agreed on") : rc;
+			++i;
+			d->fork_is_advance = false;
+			continue;
+		}
+		if (d->use_alt == 1) full_pending = false;    // this iteration writes the primary buffer: every rank prices it
 		d->fuse_next = i + 1 < n_iterations;          // as hp_step_batch: the rows sent to the neighbours carry the rain too
 		if (d->ghost_valid < g) return fail(HP_ERR_STATE, "ghost rows exhausted");
 		// an iteration consumes g layers of ghost rows; when fewer than g are left afterwards, the new state's rows are

@@ -1145,6 +1145,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	const unsigned voff_state = lane_col * (unsigned)sizeof(State4<T>), voff_scalar = lane_col * (unsigned)sizeof(T);
 	const unsigned row_state = (unsigned)p.cols * (unsigned)sizeof(State4<T>), row_scalar = (unsigned)p.cols * (unsigned)sizeof(T);
 	const long last_row = p.rows - 1;
+	// (TAIL == 2, a row strip) the final rows of the edge ranges are stored into the strip neighbours' ghost rows as well, written
+	// through -- as in K1; a pair hands over two reaches of rows at once
+	const __amdgpu_buffer_rsrc_t srd_peer0 = make_srd((TAIL == 2 && tail.peer_rows[0] ? tail.peer_rows[0] : dst) + cell0, cells_left * sizeof(State4<T>));
+	const __amdgpu_buffer_rsrc_t srd_peer1 = make_srd((TAIL == 2 && tail.peer_rows[1] ? tail.peer_rows[1] : dst) + cell0, cells_left * sizeof(State4<T>));
+	auto store_peer = [&](const State4<T>& v, const long y, const bool write_lane) {
+		const bool e0 = (int)y >= tail.edge_rows[0] && (int)y < tail.edge_rows[1];   // wave-uniform
+		const bool e1 = (int)y >= tail.edge_rows[2] && (int)y < tail.edge_rows[3];
+		buf_store_state<HP_AUX_THROUGH>(v, e1 ? srd_peer1 : srd_peer0, (write_lane && (e0 || e1)) ? voff_state : HP_OOB, (unsigned)(y - row_base) * row_state);
+	};
 	auto load_row = [&](long y, const bool live = true) {                          // (rows beyond the grid: the nearest one -- only ring rows ask)
 		y = y < 0 ? 0 : (y > last_row ? last_row : y);
 		RowRegs<T> r;
@@ -1246,6 +1255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		}
 		if (update) {
 			buf_store_state(out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - row_base) * row_state);
+			if (TAIL == 2) store_peer(out, y, write);
 			if (CFL_MODE == 1 && write && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 				const T s = cfl_speed<false>(out.z, out.zmax, out.qx, out.qy, uc.zb, p.qs);
 				if (s > vmax) vmax = s;
@@ -1280,6 +1290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 				const size_t id = (size_t)y * p.cols + xc;
 				const State4<T> c = src[id];
 				dst[id] = c;
+				if (TAIL == 2) store_peer(c, y, true);                          // (the neighbour's copy of the cell gets the same store)
 				if (CFL_MODE == 1 && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 					const T s = cfl_speed<false>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
 					if (s > vmax) vmax = s;

@@ -89,6 +89,7 @@ lib = hp.load_library()
 hp._check(lib, lib.hp_comm_load(os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so").encode()), "hp_comm_load")
 uid = hp.comm_unique_id()
 got, scal, errors = [None] * world, [None] * world, []
+launches = [None] * world
 start = threading.Barrier(world)
 tickets, peers_active = [None] * world, [None] * world
 
@@ -126,6 +127,7 @@ def rank_main(r):
         dom.sync()
         got[r] = dom.download()[own_lo - lo:own_hi - lo]
         scal[r] = dom.read_scalars()
+        launches[r] = dom.launch_counts()[0]
         dom.strip_comm_destroy()
         dom.close()
     except Exception as e:                                # noqa: BLE001
@@ -152,6 +154,7 @@ if not same:
     print("differing cells:", len(bad), "rows", sorted(set(bad[:, 0].tolist()))[:20], "cols", sorted(set(bad[:, 1].tolist()))[:12],
           "strip edges", [pp[:2] for pp in parts], flush=True)
 times = {(s["time"], s["timestep"]) for s in scal}
+print("flux launches per rank", launches, "iterations", steps + sum(wander), flush=True)
 print("ranks", world, "scheme", scheme, precision, "overlap", overlap, "rain", rain_on, "period", period, "cell boundary on rank", cell_rank, "variant", variant or "-", "peer-written maximum", peers_active, "bit-identical", same, "times", times,
       "single", (want_sc["time"], want_sc["timestep"]), flush=True)
 os._exit(0 if same and times == {(want_sc["time"], want_sc["timestep"])} else 1)

@@ -441,3 +441,27 @@ def test_cxx_strip_loop_with_ranks_that_are_processes(world, scheme, precision, 
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
     stamp = "time %.17g dt %.17g" % (want_sc["time"], want_sc["timestep"])
     assert all(stamp in o for o in outs), (stamp, outs)
+
+
+@pytest.mark.parametrize("world,precision,variant,batches", [(2, "f64", "", "1,2,87"), (3, "f64", "", "40,7,64"), (4, "f32", "", "5,2,90"),
+                                                              (3, "f64", "fixed", "1,2,60"), (8, "f64", "", "16,33,40")])
+def test_strips_run_iteration_pairs(world, precision, variant, batches):
+    """Round 5: row strips with two reaches of ghost rows and the strips' own transport run PAIRS of Godunov iterations as one
+    launch (godunov_march2 with the edge rows stored into the neighbours and ONE mailbox round per pair; HP_TWO_STEP=1 forces it
+    on these small grids).  The single domain beside them runs pairs too; the gathered strips must equal it bit for bit, time and
+    timestep included, over batches that start on either iteration of a pair -- and the strips must really have paired up."""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(__file__), "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", lib,
+                               os.path.join(os.path.dirname(lib), "fake_rccl.cpp")])
+    args = [str(world), str(hp.SCHEME_GODUNOV), precision, "0", "0", "2", "-2", "2"] + ([variant] if variant else [])
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "strip_threads_worker.py")] + args,
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, HP_TWO_STEP="1", STRIP_WORKER_BATCHES=batches))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "bit-identical True" in res.stdout
+    line = [l for l in res.stdout.splitlines() if l.startswith("flux launches per rank")][0]
+    counts = eval(line.split("flux launches per rank ")[1].split(" iterations")[0])
+    iterations = int(line.split("iterations ")[1])
+    assert all(c < 0.7 * iterations for c in counts), line                    # pairs, not single iterations
