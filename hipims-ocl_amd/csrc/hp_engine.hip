@@ -167,6 +167,8 @@ struct hp_domain {
 	bool             other_stale = false;             // pairs (godunov_march2) ran since the non-current state buffer last held a state the single-iteration kernels can build on
 	int              march2_rseg = 24;                // tile height of the two-iterations kernel
 	bool             march2_pays = false;             // the grid is big enough for it (hp_domain_create)
+	int              march2_nbands = 8;               // its row bands (one-round grids: searched)
+	bool             print_tiling = false;
 	uint64_t         pairs = 0;                       // iteration pairs run by it
 	uint64_t         flux_launches = 0, flux_launches_tailed = 0;   // whole-domain flux launches of hp_step_batch / hp_strip_step_batch, and how many carried their own tail block
 	bool             tail_failed = false;             // a tail block gave up waiting (SLOT_TAIL_ERR seen by the host): the domain is unusable
@@ -841,7 +843,7 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip)
 		hi = d->desc.rows - (north ? d->ghost_rows : 1);
 	} else launch_rows(d, 1, lo, hi);
 	if (!make_tile_map(lo, hi, 1, PART_ALL, (int)((p.cols - 2 + MARCH2_COLS - 1) / MARCH2_COLS), d->march2_rseg, d->march2_rseg, 0, tm, blocks, d->march2_rseg,
-	                   0, d->own_lo, d->own_hi, 8))
+	                   0, d->own_lo, d->own_hi, d->march2_nbands))
 		return HP_ERR_STATE;
 	if (blocks > tail_limit()) return HP_ERR_STATE;                      // (the caller falls back to single iterations)
 	d->tail_want = true; d->tail_allowed = true; d->push_now = strip;    // (strip: the final rows of the edge ranges leave with the launch)
@@ -1238,6 +1240,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	if (std::getenv("HP_PRINT_TILING"))
 		std::fprintf(stderr, "[hipims_mi] tiling %ld x %ld: K1/K6 %d rows x %d bands, K2 %d rows x %d bands\n", (long)desc->cols, (long)desc->rows,
 		             d->march_rseg, d->march_nbands, d->muscl_rseg, d->muscl_nbands);
+	d->print_tiling = std::getenv("HP_PRINT_TILING") != nullptr;
 	if (const char* e = std::getenv("HP_MARCH_RSEG")) {                   // tuning knob: rows per wavefront tile
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= 64) { d->march_rseg = d->march_rseg_parts = v; d->tall_rseg = 16; }   // a forced 16 stays 16
@@ -1253,8 +1256,46 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 		d->march2_rseg = 12;
 		for (int r : {32, 24, 18}) if (blocks_at(r) >= 4 * slots) { d->march2_rseg = r; break; }
 		d->march2_pays = blocks_at(12) >= 2 * slots;
+		// One round of blocks (the 4096 x 514 strip of a strong-scaling run): as for K1 (pick: one_round_search), what such a launch
+		// lasts is what its most loaded CU walks -- (bands, rows) by simulating the dealing, a tile costing its rows plus the two
+		// extra first-step rows and the pipeline fill.  profiles/r05u_strip_pair_sweep.txt: 14 bands x 15 rows 31.6 us per iteration
+		// against 33.7 in single iterations and 36.0 with 8 bands x 12 rows; taken from 1.5 M cells on (below: untested).
+		static const bool search = !(std::getenv("HP_TILING_SEARCH") && std::atoi(std::getenv("HP_TILING_SEARCH")) == 0);
+		const long updated_rows = (long)desc->rows - 2;
+		if (!d->march2_pays && search && d->cells >= 1500000 && blocks_at(12) >= slots / 2) {
+			const double fill = std::getenv("HP_MARCH2_FILL") ? std::atof(std::getenv("HP_MARCH2_FILL")) : 4.0;
+			double best_cost = 1e30;
+			int best_nb = 0, best_r = 0;
+			std::vector<double> load((size_t)cus);
+			std::vector<int> count((size_t)cus);
+			for (int nb = 8; nb <= 32; ++nb) {                              // (at least a band per XCD: 4 bands x 14 rows lost 2 % at 1448^2)
+				const long brows = (updated_rows + nb - 1) / nb;
+				for (int r = 8; r <= 32 && r <= brows; ++r) {
+					const long nseg = (brows + r - 1) / r, blocks = (long)nb * groups * nseg;
+					if (blocks > slots) continue;
+					std::fill(load.begin(), load.end(), 0.0);
+					std::fill(count.begin(), count.end(), 0);
+					for (long b = 0; b < blocks; ++b) {                      // tile_rows() of hp_kernels.hpp
+						const long band = b % nb, i = b / nb, seg = i / groups;
+						const long y0 = band * brows + seg * r;
+						const long h = std::min(y0 + r, std::min(updated_rows, (band + 1) * brows)) - y0;
+						if (h <= 0) continue;
+						load[(size_t)(b % cus)] += (double)h + fill;
+						count[(size_t)(b % cus)] += 1;
+					}
+					double worst = 0.0;
+					for (int c = 0; c < cus; ++c)
+						worst = std::max(worst, load[(size_t)c] * (count[(size_t)c] >= 3 ? 1.0 : count[(size_t)c] == 2 ? 1.2 : 1.6));
+					if (worst < best_cost - 1e-9 || (worst < best_cost + 1e-9 && r > best_r)) { best_cost = worst; best_nb = nb; best_r = r; }
+				}
+			}
+			if (best_nb > 0) { d->march2_rseg = best_r; d->march2_nbands = best_nb; d->march2_pays = true; }
+		}
 	}
 	if (const char* e = std::getenv("HP_MARCH2_RSEG")) { const int v = std::atoi(e); if (v >= 2 && v <= 32) d->march2_rseg = v; }
+	if (d->print_tiling)
+		std::fprintf(stderr, "[hipims_mi] tiling %ld x %ld: pair kernel %d rows x %d bands, %s\n", (long)desc->cols, (long)desc->rows, d->march2_rseg,
+		             d->march2_nbands, d->march2_pays ? "taken by default" : "not taken by default");
 	if (const char* e = std::getenv("HP_TAIL_RSEG")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) d->tail_rseg = v; }
 	if (const char* e = std::getenv("HP_TAIL_PCT"))  { const int v = std::atoi(e); if (v >= 0 && v <= 100) d->tail_pct = v; }
 	if (const char* e = std::getenv("HP_INERTIAL_RSEG")) {
