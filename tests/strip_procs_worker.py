@@ -63,6 +63,7 @@ for n in (1, 2, steps - 3):
 dom.sync()
 sc = dom.read_scalars()
 np.save(os.path.join(where, f"owned.{rank}.npy"), dom.download()[own_lo - lo:own_hi - lo])
-print("rank", rank, "of", world, "level", level, "time %.17g dt %.17g" % (sc["time"], sc["timestep"]), flush=True)
+print("rank", rank, "of", world, "level", level, "time %.17g dt %.17g" % (sc["time"], sc["timestep"]), "flux launches", dom.launch_counts()[0],
+      "iterations", sc["iterations"], flush=True)
 dom.strip_comm_destroy()
 dom.close()

@@ -390,7 +390,10 @@ def test_peer_mailboxes_report_a_missing_rank_instead_of_hanging():
 
 @pytest.mark.parametrize("world,scheme,precision,rain,period", [
     (2, hp.SCHEME_GODUNOV, "f64", 0, 1), (3, hp.SCHEME_GODUNOV, "f32", 1, 1), (3, hp.SCHEME_MUSCL_HANCOCK, "f64", 0, 1), (2, hp.SCHEME_GODUNOV, "f64", 1, 2),
-    (8, hp.SCHEME_GODUNOV, "f64", 1, 1)])
+    (8, hp.SCHEME_GODUNOV, "f64", 1, 1),
+    # round 5: iteration PAIRS on the ranks (two reaches of ghost rows, no rain; period -2 = period 2 with HP_TWO_STEP=1 in the ranks'
+    # environment): the pair launch stores its edge rows into the other PROCESSES' buffers, every rank swaps its IPC-mapped views
+    (3, hp.SCHEME_GODUNOV, "f64", 0, -2), (4, hp.SCHEME_GODUNOV, "f32", 0, -2)])
 def test_cxx_strip_loop_with_ranks_that_are_processes(world, scheme, precision, rain, period, tmp_path):
     """The strip loop as it runs in production -- one PROCESS per rank -- on the one GPU of the box: every rank maps its
     neighbours' state buffers and all ranks' mailboxes through IPC handles, the advance kernels write ghost rows and maxima
@@ -408,6 +411,9 @@ def test_cxx_strip_loop_with_ranks_that_are_processes(world, scheme, precision, 
     shm = tmp_path / "allreduce.shm"
     shm.write_bytes(bytes(4096))
     env = dict(os.environ, FAKE_RCCL_SHM=str(shm), HP_PEER_TEST_MS="20000")
+    pairs = period < 0
+    if pairs:
+        period, env = 2, dict(env, HP_TWO_STEP="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "strip_procs_worker.py"), str(r), str(world), str(tmp_path),
                                str(scheme), precision, str(rain), str(period)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
              for r in range(world)]
@@ -441,6 +447,10 @@ def test_cxx_strip_loop_with_ranks_that_are_processes(world, scheme, precision, 
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
     stamp = "time %.17g dt %.17g" % (want_sc["time"], want_sc["timestep"])
     assert all(stamp in o for o in outs), (stamp, outs)
+    if pairs:                                                  # ... and the ranks really paired up
+        for o in outs:
+            line = [l for l in o.splitlines() if "flux launches" in l][0]
+            assert int(line.split("flux launches ")[1].split()[0]) < 0.7 * int(line.split("iterations ")[1]), line
 
 
 @pytest.mark.parametrize("world,precision,variant,batches", [(2, "f64", "", "1,2,87"), (3, "f64", "", "40,7,64"), (4, "f32", "", "5,2,90"),
