@@ -60,10 +60,10 @@ __global__ __launch_bounds__(256) void godunov_basic(const Params<T> p, const Sc
 // K4  advance_time : tst_Advance_Normal (CLDynamicTimestep.clc:27-146), one lane.
 //     `slot` holds the (all-reduced) maximum wave speed; it is cleared for the next accumulation.
 //     UPDATE_ONLY = tst_UpdateTimestep (:255-317).
-// -------------------------------------------------------------------------------------------------
 //     slot[0] = running maximum of this iteration (all-reduced by the host across strips), cleared here;
 //     slot[SLOT_SAVED] = maximum last used (re-used when the primary buffer was not touched: `fresh` == 0, Q1);
 //     slot[SLOT_EDGE], slot[SLOT_EDGE+1] = edge-ring maxima of the two state buffers (read by the march kernels).
+// -------------------------------------------------------------------------------------------------
 // tst_Advance_Normal's arithmetic (CLDynamicTimestep.clc:42-145) on a register copy of the time-control block: `vmax` is the
 // maximum wave speed the reduction delivered.  Used by advance_body (the block in memory) and by the two-iterations kernel, whose
 // every wavefront needs the SECOND iteration's timestep before the first has been launched (quirk Q1 makes it computable).
@@ -1075,7 +1075,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 }
 
 // -------------------------------------------------------------------------------------------------
-// K1b godunov_march2 : TWO Godunov iterations in one pass (round 5; FAST flavour, single domain, no boundary conditions).
+// K1b godunov_march2 : TWO Godunov iterations in one pass (round 5; FAST flavour, no boundary conditions; single domains with
+//     TAIL 1, row strips that store two reaches of ghost rows with TAIL 2).
 //
 //  Why it is possible.  Quirk Q1: the reference's reduction always prices the PRIMARY state buffer.  An iteration that reads the
 //  primary buffer (every other one) therefore re-prices the state it started from: the timestep of the iteration after it follows
