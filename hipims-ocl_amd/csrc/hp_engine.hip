@@ -853,7 +853,7 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip)
 	d->tail_done = false;
 	LaunchTail<T> tail;
 	const int kind = make_tail<T>(d, blocks, PART_ALL, d->stream, tail_limit(), tail);
-	d->tail_want = false; d->push_now = false;
+	d->tail_want = false; d->tail_allowed = false; d->push_now = false;
 	if (kind != (strip ? 2 : 1)) return HP_ERR_STATE;
 	tail.pair = 1;
 	const void* src = d->state[0];
@@ -876,6 +876,7 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip)
 	if (d->rings_differ)                                                  // (rare: only after partial uploads -- see swap_edge_ring)
 		hipLaunchKernelGGL((swap_edge_ring<T>), dim3(32), dim3(256), 0, d->stream, (State4<T>*)d->state[0], (State4<T>*)d->state[1],
 		                   (long)d->desc.cols, (long)d->desc.rows);
+	HIP_TRY(hipGetLastError());
 	std::swap(d->state[0], d->state[1]);
 	if (strip) {                                                          // every rank swaps: a neighbour's buffer b is the one it calls b now
 		std::swap(d->peer_state[0][0], d->peer_state[0][1]);
