@@ -164,6 +164,7 @@ struct hp_domain {
 	unsigned long long* tail_words = nullptr;         // one word per flux block (EMPTY between launches)
 	bool             rings_differ = false;            // a partial state upload went into ONE buffer: the edge rings of the two may differ (swap_edge_ring)
 	bool             saved_rings_differ = false;
+	bool             fill_now = false;                // this iteration's K1 launch stores the cells the reference leaves untouched as well (dispatch_begin)
 	bool             other_stale = false;             // pairs (godunov_march2) ran since the non-current state buffer last held a state the single-iteration kernels can build on
 	int              march2_rseg = 24;                // tile height of the two-iterations kernel
 	bool             march2_pays = false;             // the grid is big enough for it (hp_domain_create)
@@ -522,7 +523,7 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	                   d->ghost_rows, d->own_lo, d->own_hi, d->march_nbands))
 		return HP_OK;
 	sweep_direction(d, part, tm);
-	const int truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0;
+	const int truncated = ((d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0 ? 1 : 0) | (d->fill_now ? 2 : 0);   // the kernel's `flags`
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit(), tail);
 #define HP_LAUNCH_K1S(FUSED_, TAIL_, LIST_, NEXT_, SPEC_)                                                                                   \
@@ -913,10 +914,18 @@ static int repair_other_buffer(hp_domain* d)
 
 int dispatch_begin(hp_domain* d)
 {
-	{ const int rc0 = repair_other_buffer(d); if (rc0 != HP_OK) return rc0; }
+	// after iteration pairs the non-current buffer is out of date; K1 brings it up to date by itself (its FILL flag: every cell of the
+	// launch's rows is stored), any other kernel gets the device copy first
+	static const bool fill_enabled = !(std::getenv("HP_FILL_AFTER_PAIRS") && std::atoi(std::getenv("HP_FILL_AFTER_PAIRS")) == 0);
+	const bool fill = fill_enabled && d->other_stale && d->desc.scheme == HP_SCHEME_GODUNOV && d->desc.kernel != HP_KERNEL_BASIC;
+	if (!fill) { const int rc0 = repair_other_buffer(d); if (rc0 != HP_OK) return rc0; }
+	d->fill_now = fill;
 	const bool strict = d->desc.math_mode == HP_MATH_STRICT;
-	if (d->desc.precision == 8) return strict ? step_begin_impl<double, true>(d) : step_begin_impl<double, false>(d);
-	return strict ? step_begin_impl<float, true>(d) : step_begin_impl<float, false>(d);
+	const int rc = d->desc.precision == 8 ? (strict ? step_begin_impl<double, true>(d) : step_begin_impl<double, false>(d))
+	                                      : (strict ? step_begin_impl<float, true>(d) : step_begin_impl<float, false>(d));
+	d->fill_now = false;
+	if (fill && rc == HP_OK) d->other_stale = false;
+	return rc;
 }
 
 int dispatch_end(hp_domain* d)

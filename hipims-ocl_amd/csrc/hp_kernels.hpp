@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
                                                      const TileMap tm, const AreaBdyList<T>* __restrict__ fused_list,
-                                                     const int fuse_next, const int truncated, const LaunchTail<T> tail)
+                                                     const int fuse_next, const int flags, const LaunchTail<T> tail)
 {
 	if (TAIL != 0 && blockIdx.x >= tail.flux_blocks) {                             // the launch's own tail (LaunchTail above)
 		launch_tail(p, tail);
@@ -721,6 +721,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 	const bool with_friction = p.friction != 0;
 	T vmax = T(0);
 	unsigned long long stale_rows = 0;   // bit i: row y0+i of this lane was left untouched (all-dry, Q3); rseg <= 64
+	const bool truncated = (flags & 1) != 0;                                       // HP_QUIRK_BDY_TRUNCATED
+	// FILL: the destination buffer holds nothing to build on (iteration pairs have run since it was last written: hp_engine.hip,
+	// run_pair) -- the cells the reference leaves untouched (Q3) are stored too, with the value the host's repair copy would have put
+	// there, the source's
+	const bool fill = (flags & 2) != 0;
 
 	// ---- fused area boundaries of the NEXT iteration (see above) ----
 	FusedBdy<T> fb[FUSED_BDY_MAX];
@@ -956,8 +961,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 			                                                            with_friction, spec_bad);
 			if (!disabled) {
 				if (dry5) {                                                               // dst untouched (Q3)
-					write = false;
-					if (out_x) stale_rows |= 1ull << (unsigned)(y - y0);
+					if (!fill) {                                                          // (FILL: stored, priced and rained on right here, as `out` = the source's value)
+						write = false;
+						if (out_x) stale_rows |= 1ull << (unsigned)(y - y0);
+					}
 				} else {
 					out = upd;
 				}
@@ -1008,7 +1015,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 			if (!wave_all(dryC && dryN && dryS)) break;
 			rQ = load_row((y + 2 <= y1) ? (y + 2) : y1, y + 2 <= y1);
 			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
-			const bool write = out_x && disabled;                                      // nulls are carried, dry cells untouched (Q3)
+			const bool write = out_x && (disabled || fill);                            // nulls are carried, dry cells untouched (Q3; FILL: carried too)
 			if (out_x && !disabled) stale_rows |= 1ull << (unsigned)(y - y0);
 			const Side<T> sN = make_side_impl<STRICT, PL>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs, spec_bad);
 			fS = face_dry_for_right<AXIS_Y, STRICT>(sC, sN, vs);
@@ -1045,7 +1052,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 		for (long y = y0; y < y1; ++y) {
 			if ((stale_rows >> (unsigned)(y - y0)) & 1ull) {
 				const size_t id = (size_t)y * p.cols + xc;
-				const State4<T> c = dst[id];
+				const State4<T> c = fill ? src[id] : dst[id];
 				const T zb = bed[id];
 				if (CFL_MODE == 1 && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 					const T s = cfl_speed_impl<STRICT, PL>(c.z, c.zmax, c.qx, c.qy, zb, p.qs, false, spec_bad);

@@ -270,6 +270,11 @@ def test_bench_line_names_the_collective_library_on_the_cxx_loop():
     """One real RCCL rank through bench.py's N > 1 code path is not reachable (N = 1 takes the batch call), so the
     reporting hook is checked where it lives: the C++ strip loop with a 1-rank communicator says which library it
     loaded and how many ranks THAT LIBRARY counts."""
+    import socket
+    with socket.socket() as s:                      # (its own rendezvous: the test does not lean on an earlier one's environment)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = strips.StripRunner(64, 64, rank=0, world=1, loop="cxx")
     try:
         info = r.domain.strip_info()
