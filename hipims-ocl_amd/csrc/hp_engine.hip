@@ -533,14 +533,9 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 	                   truncated, tail)
 #define HP_LAUNCH_K1(FUSED_, TAIL_, LIST_, NEXT_) HP_LAUNCH_K1S(FUSED_, TAIL_, LIST_, NEXT_, false)
 	constexpr bool CAN_SPEC = STRICT && sizeof(T) == 8;       // a speculative STRICT fp64 batch: see launch_muscl
-	if (CAN_SPEC && d->spec_now && tail_kind != 2 && part == PART_ALL) {
-		if (d->fusable) {
-			if (tail_kind == 1) HP_LAUNCH_K1S(true, 1, (const AreaBdyList<T>*)d->fused_list, d->fuse_next, CAN_SPEC);
-			else                HP_LAUNCH_K1S(true, 0, (const AreaBdyList<T>*)d->fused_list, d->fuse_next, CAN_SPEC);
-		} else {
-			if (tail_kind == 1) HP_LAUNCH_K1S(false, 1, (const AreaBdyList<T>*)nullptr, 0, CAN_SPEC);
-			else                HP_LAUNCH_K1S(false, 0, (const AreaBdyList<T>*)nullptr, 0, CAN_SPEC);
-		}
+	if (CAN_SPEC && d->spec_now && !d->fusable && tail_kind != 2 && part == PART_ALL) {        // (never with fused boundaries: spec_wanted)
+		if (tail_kind == 1) HP_LAUNCH_K1S(false, 1, (const AreaBdyList<T>*)nullptr, 0, CAN_SPEC);
+		else                HP_LAUNCH_K1S(false, 0, (const AreaBdyList<T>*)nullptr, 0, CAN_SPEC);
 	} else
 	if (d->fusable) {
 		if (tail_kind == 2)      HP_LAUNCH_K1(true, 2, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
@@ -1743,7 +1738,13 @@ bool spec_wanted(const hp_domain* d, uint32_t n)
 	// the denominator-side v_div_scale + compare that make the detection exact cost most of what the shared reciprocal saves
 	// (without any detection the same kernels run at 0.426 / 0.657 / 0.518 / 0.926 ms).  Not worth a snapshot per batch by default.
 	static const bool enabled = std::getenv("HP_STRICT_SPECULATE") && std::atoi(std::getenv("HP_STRICT_SPECULATE")) != 0;
-	return enabled && n >= SPEC_MIN && d->desc.math_mode == HP_MATH_STRICT && d->desc.precision == 8 && !d->comm &&
+	// Not with FUSED area boundaries (round 5).  The speculative flavour of the fused kernel with its own tail block is the engine's
+	// largest instantiation -- 168 VGPRs with 58-66 of them spilled and 103-114 spilled SGPRs -- and what the compiler made of it
+	// stopped being the plain kernel's arithmetic when an unrelated flag was added to the kernel (deterministic, relative 1e-7 ...
+	// 1e-4, no word raised; the same source built for two waves per SIMD, without the vector spills, is exact again:
+	// profiles/r05fg_spec_fused_tail_miscompare.txt).  A 2-3 % experiment is not worth an instantiation that only holds while the
+	// register allocator is lucky: such domains run the plain STRICT kernels.
+	return enabled && n >= SPEC_MIN && d->desc.math_mode == HP_MATH_STRICT && d->desc.precision == 8 && !d->comm && !d->fusable &&
 	       d->desc.kernel != HP_KERNEL_BASIC && (d->desc.scheme == HP_SCHEME_GODUNOV || d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK);
 }
 int spec_begin(hp_domain* d)

@@ -84,15 +84,15 @@ __device__ __forceinline__ float fmax0_raw(const float a) { float r; asm("v_max_
 __device__ __forceinline__ float fmin0_raw(const float a) { float r; asm("v_min_f32 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }
 
 // ---- FAST-flavour primitives: hardware seed + Newton steps instead of the IEEE expansions ----
-// 1/x to about 1 ulp: v_rcp_f64 seed, two Newton-Raphson steps (the IEEE division adds scaling + fix-up).
-// Measured on gfx950 (tools/seedcheck): seed 4.6e-8 relative (2^-24.4), one step 2.1e-15, two steps 1.1e-16;
+// 1/x to about 1 ulp: v_rcp_f64 seed r, residual e = 1 - x r, ONE third-order step r (1 + e + e^2) -- what is left is e^3 (1e-22)
+// and the last fma's rounding (the IEEE division adds scaling + fix-up; two Newton-Raphson steps, rounds 2-4, are one fma more).
+// Measured on gfx950 (tools/seedcheck): seed 4.6e-8 relative (2^-24.4), one Newton step 2.1e-15, two steps 1.1e-16;
 // v_rsq_f64 seed 5.2e-8.
 __device__ __forceinline__ double rcp_fast(double x)
 {
-	double r = __builtin_amdgcn_rcp(x);
+	const double r = __builtin_amdgcn_rcp(x);
 	double e = __builtin_fma(-x, r, 1.0);
-	r = __builtin_fma(r, e, r);
-	e = __builtin_fma(-x, r, 1.0);
+	e = __builtin_fma(e, e, e);
 	return __builtin_fma(r, e, r);
 }
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32 is 1 ulp already
@@ -102,10 +102,10 @@ __device__ __forceinline__ double sqrt_fast(double x)
 {
 	x = __builtin_fmax(x, 1e-300);
 	const double y = __builtin_amdgcn_rsq(x);
-	double g = x * y, h = 0.5 * y;
+	double g = x * y;
+	const double h = 0.5 * y;                         // (left at the seed's 5e-8: it only scales the last correction, itself 4e-15 of g)
 	const double r = __builtin_fma(-h, g, 0.5);
 	g = __builtin_fma(g, r, g);
-	h = __builtin_fma(h, r, h);
 	const double d = __builtin_fma(-g, g, x);
 	return __builtin_fma(d, h, g);
 }
@@ -376,9 +376,11 @@ __device__ __forceinline__ FacePair<T> face_solve_fast(const Side<T>& L, const S
 	const T qnL = hL * unL, qnR = hR * unR;                                               // :99-102
 	const T ghL = g * hL, ghR = g * hR;
 	const T aL = celerity_fast(ghL), aR = celerity_fast(ghR);                             // :103-106
-	const T tmp = fma_(T(0.25), unL - unR, T(0.5) * (aL + aR));                           // :123-126
-	const T u_star = fma_(T(0.5), unL + unR, aL - aR);
-	const T a_star = fabs_(tmp);
+	// :123-126 through the two Riemann invariants (halved): u* = (unL + unR)/2 + aL - aR = pL + mR, a* = |(unL - unR)/4 + (aL + aR)/2|
+	// = |pL - mR| / 2 -- five operations for the reference's seven
+	const T pL = fma_(T(0.5), unL, aL), mR = fma_(T(0.5), unR, -aR);
+	const T u_star = pL + mR;
+	const T a_star = fabs_(T(0.5) * (pL - mR));
 	T sL = fmin_(unL - aL, u_star - a_star), sR = fmax_(unR + aR, u_star + a_star);       // :129-140
 	if (!all_wet) {
 		sL = dryL ? fma_(T(-2), aR, unR) : sL;
@@ -644,17 +646,19 @@ __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb
 		d3 = div_shared<PLAIN>(fE.fy - fW.fy, rdx, bad) + div_shared<PLAIN>(fN.fy - fS.fy, rdx, bad) - sy;
 		}
 	} else {
-		// dx == dy: one multiplication by 1/dx per component instead of eight divisions
+		// dx == dy: the sums stay multiplied by dx -- the flush below compares them with VERY_SMALL dx, the update multiplies by
+		// dt / dx (both wave-uniform and formed once per launch) -- instead of eight divisions
 		const T hg = T(0.5) * g;
 		const T sxd = hg * (fE.eta_nb + fW.eta_nb) * (fE.zb_nb - fW.zb_nb);      // = -sx * dx
 		const T syd = hg * (fN.eta_nb + fS.eta_nb) * (fN.zb_nb - fS.zb_nb);
-		d0 = ((fE.f0 - fW.f0) + (fN.f0 - fS.f0)) * inv_dx;
-		d2 = ((fE.fx - fW.fx) + (fN.fx - fS.fx) + sxd) * inv_dx;
-		d3 = ((fE.fy - fW.fy) + (fN.fy - fS.fy) + syd) * inv_dx;
+		d0 = (fE.f0 - fW.f0) + (fN.f0 - fS.f0);
+		d2 = (fE.fx - fW.fx) + (fN.fx - fS.fx) + sxd;
+		d3 = (fE.fy - fW.fy) + (fN.fy - fS.fy) + syd;
 	}
-	d0 = small_to_zero<STRICT>(d0, vs);
-	d2 = small_to_zero<STRICT>(d2, vs);
-	d3 = small_to_zero<STRICT>(d3, vs);
+	const T flush = STRICT ? vs : vs * dx;
+	d0 = small_to_zero<STRICT>(d0, flush);
+	d2 = small_to_zero<STRICT>(d2, flush);
+	d3 = small_to_zero<STRICT>(d3, flush);
 
 	const bool stop = fN.stop || fE.stop || fS.stop || fW.stop;
 	if (STRICT) {
@@ -669,9 +673,10 @@ __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb
 			asm volatile("");                                    // (a real branch: if-converted, its eight selects ran on every row)
 			c.qx = stop ? T(0) : c.qx; c.qy = stop ? T(0) : c.qy;
 		}
-		c.z  = fma_(-dt, d0, c.z);
-		c.qx = fma_(-dt, d2, c.qx);
-		c.qy = fma_(-dt, d3, c.qy);
+		const T lam = -(dt * inv_dx);
+		c.z  = fma_(lam, d0, c.z);
+		c.qx = fma_(lam, d2, c.qx);
+		c.qy = fma_(lam, d3, c.qy);
 		if (with_friction) friction_fast(c.qx, c.qy, c.z, zb, n, dt, vs);
 	}
 
