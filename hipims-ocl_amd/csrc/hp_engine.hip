@@ -1170,6 +1170,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 						const double fill = std::getenv("HP_TILING_FILL") ? std::atof(std::getenv("HP_TILING_FILL")) : 3.5;
 						double best_cost = 1e30;
 						int best_nb = 8, best_r = rseg;
+						long best_pref = -2;
 						std::vector<double> load((size_t)cus);
 						std::vector<int> count((size_t)cus);
 						for (int nb = 1; nb <= 32; ++nb) {
@@ -1193,10 +1194,14 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 									const double f = count[(size_t)c] >= 3 ? 1.0 : count[(size_t)c] == 2 ? 1.2 : 1.6;
 									worst = std::max(worst, load[(size_t)c] * f);
 								}
-								// (ties: the taller first tiles -- 15 + 15 + 5 measured ahead of 12 + 12 + 11 --, then the tiling nearest to
-								// the 8-band one, whose bands keep to their XCD's L2)
-								if (worst < best_cost - 1e-9 || (worst < best_cost + 1e-9 && (r > best_r || (r == best_r && std::abs(nb - 8) < std::abs(best_nb - 8))))) {
-									best_cost = worst; best_nb = nb; best_r = r;
+								// (ties: round 5 -- the last tile of a band as tall as it can be up to half a full tile (the pair kernel's rule below;
+								// K1 on the 4096 x 514 strip: 14 + 14 + 7 33.3 us, 13 + 13 + 9 33.1, round 4's 15 + 15 + 5 34.3, profiles/r05fq_*) --,
+								// then the taller first tiles, then the tiling nearest to the 8-band one, whose bands keep to their XCD's L2)
+								const long last = brows - (nseg - 1) * r;
+								const long pref = (nseg >= 2 && nseg <= 3 && 2 * last <= r) ? last : -1;
+								if (worst < best_cost - 1e-9 || (worst < best_cost + 1e-9 && (pref > best_pref || (pref == best_pref &&
+								    (r > best_r || (r == best_r && std::abs(nb - 8) < std::abs(best_nb - 8))))))) {
+									best_cost = worst; best_nb = nb; best_r = r; best_pref = pref;
 								}
 							}
 						}
@@ -1271,6 +1276,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 			const double fill = std::getenv("HP_MARCH2_FILL") ? std::atof(std::getenv("HP_MARCH2_FILL")) : 4.0;
 			double best_cost = 1e30;
 			int best_nb = 0, best_r = 0;
+			long best_pref = -2;
 			std::vector<double> load((size_t)cus);
 			std::vector<int> count((size_t)cus);
 			for (int nb = 8; nb <= 32; ++nb) {                              // (at least a band per XCD: 4 bands x 14 rows lost 2 % at 1448^2)
@@ -1291,7 +1297,17 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 					double worst = 0.0;
 					for (int c = 0; c < cus; ++c)
 						worst = std::max(worst, load[(size_t)c] * (count[(size_t)c] >= 3 ? 1.0 : count[(size_t)c] == 2 ? 1.2 : 1.6));
-					if (worst < best_cost - 1e-9 || (worst < best_cost + 1e-9 && r > best_r)) { best_cost = worst; best_nb = nb; best_r = r; }
+					// Ties -- the same rows and the same number of tiles on every CU, cut differently (37 rows as 16 + 16 + 5, 15 + 15 + 7,
+					// 14 + 14 + 9 ...): measured over eight one-round shapes (profiles/r05fp_tie_sweep.txt), the pair kernel wants the LAST
+					// tile of a band as tall as it can be without exceeding half a full tile -- 15 + 15 + 7 is 4 % ahead of 16 + 16 + 5 and
+					// 6 % ahead of 13 + 13 + 11 on the 4096 x 514 strip (30.0 against 31.4 / 32.0 us), 11 + 11 + 5 6 % ahead of 12 + 12 + 3
+					// on 3072 x 514 -- and otherwise the taller tiles.
+					// (bands of two or three tiles: with more the rule made 1448^2 slower)
+					const long last = brows - (nseg - 1) * r;
+					const long pref = (nseg >= 2 && nseg <= 3 && 2 * last <= r) ? last : -1;
+					if (worst < best_cost - 1e-9 || (worst < best_cost + 1e-9 && (pref > best_pref || (pref == best_pref && r > best_r)))) {
+						best_cost = worst; best_nb = nb; best_r = r; best_pref = pref;
+					}
 				}
 			}
 			if (best_nb > 0) { d->march2_rseg = best_r; d->march2_nbands = best_nb; d->march2_pays = true; }

@@ -944,16 +944,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 			fW.f0 = from_west(forW.f0); fW.fx = from_west(forW.fx);
 			fW.fy = from_west(forW.fy); fW.eta_nb = from_west(forW.eta_nb);
 			fW.zb_nb = from_west(forW.zb_nb);
-			const bool dryC = (rc.c.z - rc.zb) < vs;
+			// the five dry tests of :248-255.  (FAST) a face whose lanes ALL have water on both sides (FacePair::wet) lies between two wet
+			// cells in every lane -- a cell's depth is at least its depth above the face's common bed --, so such a wavefront skips the tests
+			// (fp64 only: in fp32 the two branches cost what the six instructions save -- profiles/r05fm_three_builds_ab.txt)
+			constexpr bool LAZY_DRY = !STRICT && sizeof(T) == 8;
+			bool dryC = false, dryE = false, dryN = false;
+			if (!LAZY_DRY || !fx.wet) {
+				asm volatile("");                                                     // (a real branch: speculated, its six instructions ran on every row)
+				dryC = (rc.c.z - rc.zb) < vs;
+				dryE = (sE.eta - sE.zb) < vs;
+			}
 			const int flags = from_west((int)forW.stop | ((int)dryC << 1));
 			fW.stop = (flags & 1) != 0;
 			const bool dryW = (flags & 2) != 0;
-			const bool dryE = (sE.eta - sE.zb) < vs;
-			const bool dryN = (rn.c.z - rn.zb) < vs;
 
 			sN = make_side_impl<STRICT, PL>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs, spec_bad);
 			const FacePair<T> fy = face_solve_impl<AXIS_Y, STRICT, true, true, PL>(sC, sN, vs, spec_bad);
 			const FaceFlux<T> fN = fy.forL;
+			if (!LAZY_DRY || !fy.wet) {
+				asm volatile("");
+				dryN = (rn.c.z - rn.zb) < vs;
+			}
 
 			const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0);     // :214-218
 			const bool dry5 = dryC && dryN && dryE && dryS && dryW;                   // :248-255
@@ -1173,6 +1184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		r.n = p.manning_uniform ? p.manning_value : buf_load_scalar(srd_man, vc_, k * row_scalar, T());
 		return r;
 	};
+	constexpr bool LAZY_DRY = sizeof(T) == 8;                                      // (K1's row step: the dry tests only where a face is not wet throughout)
 	// west flux of a cell = what the lane to its west found for its east face (as in K1)
 	auto flux_from_west = [&](const FaceFlux<T>& forW, const bool dryC, bool& dryW) {
 		FaceFlux<T> fW;
@@ -1205,13 +1217,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 			const bool ring_row = r <= 0 || r >= last_row;                         // wave-uniform: passes through, but its north face is needed
 			sN = make_side<false>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
 			const FacePair<T> fy = face_solve_fast<AXIS_Y>(sCa, sN, vs);
-			const bool dryC = (rc.c.z - rc.zb) < vs;
+			// (a face whose lanes all have water on both sides lies between wet cells: K1's row step)
+			bool dryC = false, dryN = false;
+			if (!LAZY_DRY || !fy.wet) {
+				asm volatile("");
+				dryC = (rc.c.z - rc.zb) < vs;
+				dryN = (rn.c.z - rn.zb) < vs;
+			}
 			if (!ring_row) {
 				const Side<T> sE = side_from_east(sCa);
 				const FacePair<T> fx = face_solve_fast<AXIS_X>(sCa, sE, vs);
 				bool dryW;
 				const FaceFlux<T> fW = flux_from_west(fx.forR, dryC, dryW);
-				const bool dryE = (sE.eta - sE.zb) < vs, dryN = (rn.c.z - rn.zb) < vs;
+				bool dryE = false;
+				if (!LAZY_DRY || !fx.wet) {
+					asm volatile("");
+					dryE = (sE.eta - sE.zb) < vs;
+				}
 				const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0); // :214-218
 				const bool dry5 = dryC && dryN && dryE && drySa && dryW;               // :248-255 (untouched: see the header)
 				const State4<T> upd = godunov_update<false>(rc.c, rc.zb, rc.n, dt_a, fy.forL, fx.forL, fSa, fW, p.dx, p.inv_dx, vs, with_friction);
@@ -1239,13 +1261,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		bool write = out_x;
 		if (!skip_b) {
 			const FacePair<T> fy = face_solve_fast<AXIS_Y>(sCb, sN, vs);
-			const bool dryC = (uc.c.z - uc.zb) < vs;
+			bool dryC = false, dryN = false;
+			if (!LAZY_DRY || !fy.wet) {
+				asm volatile("");
+				dryC = (uc.c.z - uc.zb) < vs;
+				dryN = (un.c.z - un.zb) < vs;
+			}
 			if (update) {
 				const Side<T> sE = side_from_east(sCb);
 				const FacePair<T> fx = face_solve_fast<AXIS_X>(sCb, sE, vs);
 				bool dryW;
 				const FaceFlux<T> fW = flux_from_west(fx.forR, dryC, dryW);
-				const bool dryE = (sE.eta - sE.zb) < vs, dryN = (un.c.z - un.zb) < vs;
+				bool dryE = false;
+				if (!LAZY_DRY || !fx.wet) {
+					asm volatile("");
+					dryE = (sE.eta - sE.zb) < vs;
+				}
 				const bool disabled = uc.c.zmax <= T(-9999.0) || uc.c.z == T(-9999.0);
 				const bool dry5 = dryC && dryN && dryE && drySb && dryW;
 				const State4<T> upd = godunov_update<false>(uc.c, uc.zb, n_c, dt_b, fy.forL, fx.forL, fSb, fW, p.dx, p.inv_dx, vs, with_friction);

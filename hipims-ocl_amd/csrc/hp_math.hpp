@@ -110,6 +110,17 @@ __device__ __forceinline__ double sqrt_fast(double x)
 	return __builtin_fma(d, h, g);
 }
 __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32: 1 ulp, no denormal rescaling
+// the same for an argument the caller keeps away from zero (x >= 1e-300)
+__device__ __forceinline__ double sqrt_fast_pos(double x)
+{
+	const double y = __builtin_amdgcn_rsq(x);
+	double g = x * y;
+	const double h = 0.5 * y;
+	const double r = __builtin_fma(-h, g, 0.5);
+	g = __builtin_fma(g, r, g);
+	const double d = __builtin_fma(-g, g, x);
+	return __builtin_fma(d, h, g);
+}
 // x^(-1/3), x > 0: fp32 exp2/log2 seed (relative error ~1e-6), two Newton steps y <- y + y(1 - x y^3)/3.
 __device__ __forceinline__ double rcbrt_fast(double x)
 {
@@ -310,7 +321,7 @@ __device__ __forceinline__ FaceFlux<T> finish_wet(const FaceCore<T> k, const Rec
 	return o;
 }
 
-template <typename T> struct FacePair { FaceFlux<T> forL, forR; };
+template <typename T> struct FacePair { FaceFlux<T> forL, forR; bool wet; };   // wet (FAST, wave-uniform): every lane has water on both sides of its face
 
 // ---- FAST flavour of a face solve: DEPTH FORM (round 5) ----------------------------------------------------------------------
 // The reference evaluates the pressure-like part of the normal-momentum flux in free-surface form on SHIFTED levels
@@ -342,15 +353,22 @@ template <typename T> struct FacePair { FaceFlux<T> forL, forR; };
 // A wavefront whose lanes all have water on both sides skips what only a dry side can need: zeroed velocities (:87-92), dry-side
 // wave speeds (:129-140), the shift and the stopping conditions (:101-133); a wet-wet lane gets the same bits either way.
 template <typename T> __device__ __forceinline__ T celerity_fast(const T gh);
-template <> __device__ __forceinline__ double celerity_fast(const double gh) { return sqrt_fast(gh); }        // clamps at 1e-150
-template <> __device__ __forceinline__ float  celerity_fast(const float gh)  { return __builtin_amdgcn_sqrtf(__builtin_fmaxf(gh, 1e-30f)); }
+template <> __device__ __forceinline__ double celerity_fast(const double gh) { return sqrt_fast_pos(gh); }    // (gh >= 1e-300: face_solve_fast keeps the depths above 1.02e-301)
+template <> __device__ __forceinline__ float  celerity_fast(const float gh)  { return __builtin_amdgcn_sqrtf(__builtin_fmaxf(gh, 1e-30f)); }   // (fp32 keeps its own clamp: below)
 
 template <int AXIS, typename T>
 __device__ __forceinline__ FacePair<T> face_solve_fast(const Side<T>& L, const Side<T>& R, const T vs)
 {
 	const T g = gravity<T>(), half_g = T(0.5) * g;
 	const T zbm = fmax_raw(L.zb, R.zb);
-	const T hL = fmax_(L.eta - zbm, T(0)), hR = fmax_(R.eta - zbm, T(0));                 // :84-97
+	// :84-97.  fp64: the two clamps -- the depths at zero, the celerities away from zero -- are one, and only a wavefront with a dry
+	// side somewhere pays for it: a dry side's depth is held at 1.02e-301 instead of 0, so that g h >= 1e-300 under the root;
+	// everything such a depth multiplies underflows to the zero it stood for.  (fp32 keeps the two clamps on every face: the merged
+	// form measured 1-3 % SLOWER there, profiles/r05fm_three_builds_ab.txt -- its instructions are single-issue either way and the
+	// longer dry-side block costs more than four of them save.)
+	constexpr bool MERGED = sizeof(T) == 8;
+	T hL = L.eta - zbm, hR = R.eta - zbm;
+	if (!MERGED) { hL = fmax_(hL, T(0)); hR = fmax_(hR, T(0)); }
 	T unL = (AXIS == AXIS_X ? L.u0 : L.v0), unR = (AXIS == AXIS_X ? R.u0 : R.v0);
 	T utL = (AXIS == AXIS_X ? L.v0 : L.u0), utR = (AXIS == AXIS_X ? R.v0 : R.u0);
 	const bool all_wet = wave_all(hL > vs && hR > vs);
@@ -358,6 +376,7 @@ __device__ __forceinline__ FacePair<T> face_solve_fast(const Side<T>& L, const S
 	T ZL = zbm, ZR = zbm;
 	bool stopL = false, stopR = false;
 	if (!all_wet) {
+		if (MERGED) { hL = fmax_(hL, T(1.02e-301)); hR = fmax_(hR, T(1.02e-301)); }
 		// stopping conditions (:101-133) on the cell-centre velocities and raw discharges
 		const T qrawL = (AXIS == AXIS_X ? L.qx : L.qy), qrawR = (AXIS == AXIS_X ? R.qx : R.qy);
 		const bool shared = (hR <= vs && unL < T(0)) || (hL <= vs && unR > T(0));
@@ -399,6 +418,7 @@ __device__ __forceinline__ FacePair<T> face_solve_fast(const Side<T>& L, const S
 	o.forL.eta_nb = hR; o.forL.zb_nb = ZL; o.forL.stop = stopL;
 	o.forR.f0 = f0; o.forR.fx = o.forL.fx; o.forR.fy = o.forL.fy;
 	o.forR.eta_nb = hL; o.forR.zb_nb = ZR; o.forR.stop = stopR;
+	o.wet = all_wet;
 	return o;
 }
 
@@ -501,6 +521,7 @@ __device__ __forceinline__ FacePair<T> face_solve_impl(const Side<T>& L, const S
 	FacePair<T> out;
 	out.forL = oL;
 	out.forR = oR;
+	out.wet = false;
 	return out;
 }
 template <int AXIS, bool STRICT, bool WANT_L, bool WANT_R, typename T>
