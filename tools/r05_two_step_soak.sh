@@ -9,5 +9,6 @@ sed 's/  # .*//' /tmp/soak_pairs_raw.txt > /tmp/soak_pairs.txt
 {
 echo "two-step soak: seeds $FIRST .. $((FIRST + N - 1)): $(wc -l < /tmp/soak_single.txt) single lines, $(wc -l < /tmp/soak_pairs.txt) pair lines"
 if diff -q /tmp/soak_single.txt /tmp/soak_pairs.txt > /dev/null; then echo "ALL $(wc -l < /tmp/soak_pairs.txt) configurations bit-identical (pairs forced on vs off)"; else echo "MISMATCHES:"; diff /tmp/soak_single.txt /tmp/soak_pairs.txt | head -20; fi
+echo "configurations that ended in non-finite states (a fixed timestep beyond the CFL limit; not compared): $(grep -c non-finite /tmp/soak_pairs.txt)"
 awk '{n+=$NF; it+=$8} END {print "iterations", it, "flux launches with pairs", n}' /tmp/soak_pairs_raw.txt
 } | tee gpurun_out/${TAG}.txt
