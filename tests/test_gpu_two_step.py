@@ -36,6 +36,23 @@ def test_pairs_are_the_same_computation_as_single_iterations(scenario, precision
     assert np.array_equal(pairs["state"], single["state"])
 
 
+def test_the_single_iteration_after_pairs_fills_or_copies_to_the_same_bits(tmp_path):
+    """After pairs the non-current buffer is two states old.  The first single iteration behind them either stores the cells the
+    reference leaves untouched itself (K1's FILL flag, the default) or is preceded by a device copy of the current state
+    (HP_FILL_AFTER_PAIRS=0, the round-5 A/B switch): the same bits, on wet/dry terrain where untouched cells exist, over batches of
+    odd length (every one ends in such a single iteration) -- and both equal the run without pairs."""
+    outs = {}
+    for name, env in (("fill", {"HP_TWO_STEP": "1"}), ("copy", {"HP_TWO_STEP": "1", "HP_FILL_AFTER_PAIRS": "0"}), ("single", {"HP_TWO_STEP": "0"})):
+        out = os.path.join(str(tmp_path), f"{name}.npz")
+        r = subprocess.run([sys.executable, WORKER, "rough", "f64", out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = np.load(out)
+    assert int(outs["fill"]["launches"]) == int(outs["copy"]["launches"]) < int(outs["single"]["launches"])
+    for other in ("copy", "single"):
+        assert np.array_equal(outs["fill"]["state"], outs[other]["state"]), other
+        assert outs["fill"]["t"] == outs[other]["t"] and outs["fill"]["dt"] == outs[other]["dt"], other
+
+
 def test_default_takes_pairs_on_big_grids_only(tmp_path):
     out = os.path.join(str(tmp_path), "default.npz")
     env = {k: v for k, v in os.environ.items() if k != "HP_TWO_STEP"}
