@@ -121,15 +121,16 @@ __device__ __forceinline__ double sqrt_fast_pos(double x)
 	const double d = __builtin_fma(-g, g, x);
 	return __builtin_fma(d, h, g);
 }
-// x^(-1/3), x > 0: fp32 exp2/log2 seed (relative error ~1e-6), two Newton steps y <- y + y(1 - x y^3)/3.
+// x^(-1/3), x > 0: fp32 exp2/log2 seed y (relative error e ~ 1e-6), residual e = 1 - x y^3, ONE third-order step
+// y (1 + e/3 + 2 e^2/9) -- the series of (1 - e)^(-1/3); what is left is 14/81 e^3 (1e-19).  (Rounds 2-4: two Newton steps, four
+// instructions more.)
 __device__ __forceinline__ double rcbrt_fast(double x)
 {
 	const float xf = (float)x;
-	double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (-1.0f / 3.0f));
-	double e = __builtin_fma(-x * y, y * y, 1.0);
-	y = __builtin_fma(y * (1.0 / 3.0), e, y);
-	e = __builtin_fma(-x * y, y * y, 1.0);
-	return __builtin_fma(y * (1.0 / 3.0), e, y);
+	const double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (-1.0f / 3.0f));
+	const double e = __builtin_fma(-x * y, y * y, 1.0);
+	const double p = __builtin_fma(e, 2.0 / 9.0, 1.0 / 3.0);
+	return __builtin_fma(y, p * e, y);
 }
 __device__ __forceinline__ float rcbrt_fast(float x)
 {
