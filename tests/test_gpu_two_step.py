@@ -53,6 +53,23 @@ def test_the_single_iteration_after_pairs_fills_or_copies_to_the_same_bits(tmp_p
         assert outs["fill"]["t"] == outs[other]["t"] and outs["fill"]["dt"] == outs[other]["dt"], other
 
 
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_a_boundary_added_behind_pairs(precision, tmp_path):
+    """Pairs need a domain without boundary conditions; one may be added later.  The first single iteration behind the pairs then is
+    K1 with the rain FUSED in and the FILL flag set (its destination is two states old): the run must equal the one without pairs bit
+    for bit -- and the one that copies instead of filling."""
+    outs = {}
+    for name, env in (("fill", {"HP_TWO_STEP": "1"}), ("copy", {"HP_TWO_STEP": "1", "HP_FILL_AFTER_PAIRS": "0"}), ("single", {"HP_TWO_STEP": "0"})):
+        out = os.path.join(str(tmp_path), f"{name}.npz")
+        r = subprocess.run([sys.executable, WORKER, "rainlater", precision, out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = np.load(out)
+    assert int(outs["fill"]["launches"]) == int(outs["copy"]["launches"]) <= int(outs["single"]["launches"]) - 10      # the first 24 iterations: pairs
+    for other in ("copy", "single"):
+        assert np.array_equal(outs["fill"]["state"], outs[other]["state"]), other
+        assert outs["fill"]["t"] == outs[other]["t"] and outs["fill"]["dt"] == outs[other]["dt"], other
+
+
 def test_default_takes_pairs_on_big_grids_only(tmp_path):
     out = os.path.join(str(tmp_path), "default.npz")
     env = {k: v for k, v in os.environ.items() if k != "HP_TWO_STEP"}

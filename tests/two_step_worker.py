@@ -31,6 +31,10 @@ elif scenario == "fixed":                   # fixed timestep (no reduction at al
     st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
     kw = dict(dynamic_dt=False, dt_fixed=0.01)
     plan = [("run", 41), ("run", 40)]
+elif scenario == "rainlater":               # pairs first, then a rain boundary arrives: the first single iteration behind the pairs is K1 with FUSED
+    cols, rows = 500, 333                   # boundaries AND the FILL flag (the buffer it writes is two states old); dry land keeps untouched cells
+    st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
+    plan = [("run", 24), ("rain",), ("run", 9), ("run", 30), ("download",), ("run", 5)]
 else:
     raise SystemExit(scenario)
 dom = hp.Domain(cols, rows, precision=precision, math_mode=hp.MATH_FAST, **kw)
@@ -49,6 +53,8 @@ for step in plan:
         dom.state_save()
     elif step[0] == "restore":
         dom.state_restore()
+    elif step[0] == "rain":
+        dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, np.array([[0.0, 90.0], [5.0, 30.0], [10.0, 0.0]]), 5.0, 10.0)
 final = dom.download()
 sc = dom.read_scalars()
 counts = dom.launch_counts()
