@@ -43,24 +43,45 @@ BYTES_PER_CELL_STEP = {"f64": 80.0, "f32": 40.0}      # read sta
 LADDER = {1: (4096, 4096), 2: (8192, 4096), 4: (8192, 8192), 8: (16384, 8192)}
 
 
-def pmc_traffic(kernel_substr, scheme):
-    """HBM bytes per launch of the flux kernel from the newest committed PMC summary of THIS workload (profiles/
-    rNN*_<scheme>4096_pmc.json, produced by tools/profile_bench.sh + tools/summarize_profile.py from the default bench
-    command: FETCH_SIZE x2 + WRITE_SIZE, separate passes)."""
+def pmc_counters(kernel_substr, stem):
+    """Per-launch PMC figures of the flux kernel from the newest committed summary of THIS workload (profiles/
+    rNN*_<stem>_pmc.json, produced by tools/profile_bench.sh + tools/summarize_profile.py from the same bench command: FETCH_SIZE x2 +
+    WRITE_SIZE in separate passes = HBM bytes; SQ_INSTS_VALU = vector instructions issued, per wavefront)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{scheme}4096_*pmc.json"))):
-        if "developed" in os.path.basename(f):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{stem}_*pmc.json")) + glob.glob(os.path.join(ROOT, "profiles", f"*_{stem}_pmc.json"))):
+        if "developed" in os.path.basename(f) and "developed" not in stem:
             continue
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        vals = [k["hbm_bytes_per_launch"] for name, k in d.get("kernels", {}).items()
-                if kernel_substr in name and "hbm_bytes_per_launch" in k]
-        if vals:
-            best = (sum(vals) / len(vals), os.path.basename(f))
+        ks = [k for name, k in d.get("kernels", {}).items() if kernel_substr in name and "hbm_bytes_per_launch" in k]
+        if ks:
+            k = max(ks, key=lambda e: e.get("hbm_bytes_per_launch", 0))          # (several instantiations: the one that moves the grid)
+            best = {"hbm_bytes": k["hbm_bytes_per_launch"], "valu": k.get("SQ_INSTS_VALU"), "file": os.path.basename(f)}
     return best
+
+
+SIMDS, CLOCK_HZ, CYCLES_PER_WAVE_INSTRUCTION = 1024, 2.4e9, 4      # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles
+
+
+def attach_pmc(roof, kernel_substr, stem):
+    """`traffic` (measured HBM GB/s) and the two fractions that say what bounds the kernel, from the committed PMC summary of the same
+    command: hbm_frac_measured = traffic / peak (what the HBM interface really sees; `frac` is ALGORITHMIC bytes per second, SURVEY
+    8(d)'s 80 B per cell-step, and exceeds it where a launch covers two iterations), valu_issue_frac = the share of the launch the
+    vector ALUs need for issue alone (VERDICT r05, next #2)."""
+    c = pmc_counters(kernel_substr, stem)
+    k_ms = roof["avg_launch_ms"]
+    if not c or not k_ms or k_ms <= 0:
+        return
+    roof["traffic"] = c["hbm_bytes"] / 1e9 / (k_ms * 1e-3)                           # GB/s, same unit as achieved
+    roof["traffic_bytes_per_launch"] = c["hbm_bytes"]
+    roof["traffic_source"] = "profiles/" + c["file"]
+    roof["hbm_frac_measured"] = roof["traffic"] / HBM_PEAK_GBS
+    if c.get("valu"):
+        roof["valu_instructions_per_launch"] = c["valu"]
+        roof["valu_issue_frac"] = c["valu"] * CYCLES_PER_WAVE_INSTRUCTION / (SIMDS * CLOCK_HZ) / (k_ms * 1e-3)
 
 
 def usable_cores():
@@ -182,6 +203,11 @@ WORKLOAD_NAMES = {"s-rain": "S-RAIN gridded-rainfall on dry terrain", "s-rough":
                   "s-dam": "S-DAM flat-DEM dam-break"}
 
 
+def variant(args, **kw):
+    """A copy of the command line with some fields replaced: the extra legs of the default line (other scheme, precision, window)."""
+    return argparse.Namespace(**{**vars(args), **kw})
+
+
 def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=False, repeats=None, last=True, workload=None):
     """One timed leg: build this rank's runner for a `cols x rows` grid cut into `world` strips, load the workload, pre-warm,
     then `repeats` x (restore, W warm-up steps, EXACTLY K timed steps between barrier + device sync); median repeat.
@@ -209,7 +235,15 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
         runner = StripRunner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
                              device=device, rank=rank, world=world, backend=backend, exchange_period=args.exchange_period)
     if workload == "s-rain":
-        st, bed, man, rain = syn.s_rain_rows(cols, rows, runner.local_lo, runner.local_hi, dx=dx, dtype=real)
+        # built in row blocks (the float64 intermediates of 8192^2 at once are 6 GB and most of the leg's wall time)
+        n_local = runner.local_hi - runner.local_lo
+        st, bed, man = np.empty((n_local, cols, 4), real), np.empty((n_local, cols), real), np.empty((n_local, cols), real)
+        for r0 in range(runner.local_lo, runner.local_hi, 1024):
+            r1 = min(r0 + 1024, runner.local_hi)
+            a, b, c, rain = syn.s_rain_rows(cols, rows, r0, r1, dx=dx, dtype=real)
+            st[r0 - runner.local_lo:r1 - runner.local_lo], bed[r0 - runner.local_lo:r1 - runner.local_lo] = a, b
+            man[r0 - runner.local_lo:r1 - runner.local_lo] = c
+        del a, b, c
         runner.upload(st, bed, man)
         runner.domain.add_gridded(hp.GRIDDED_RAIN_INTENSITY, rain["grids"], rain["resolution"], rain["off_x"],
                                   rain["off_y"], rain["interval"])
@@ -320,6 +354,13 @@ def roofline_of(args, leg):
          "algorithmic_bytes_per_cell_step": bpc, "cells_per_launch": leg["cells_per_launch"],
          "cell_steps_per_launch": leg["cells_per_launch"] * ipl}
     r["flux_launches_carried_their_tail"] = bool(leg.get("tail_carried"))
+    # What `frac` is NOT: an HBM utilisation.  It prices SURVEY 8(d)'s 80 (40) B per cell-step, the
+    # contract's figure; a launch that covers TWO iterations keeps the intermediate state in registers and HAS to move only half of
+    # that per cell-step, so `frac` can pass 1.0 there.  The bytes such a launch must move, priced the same way:
+    r["bytes_launch_must_move"] = bpc * leg["cells_per_launch"]          # state in + bed + Manning + state out, once per launch
+    r["frac_of_bytes_launch_must_move"] = r["frac"] / ipl
+    r["frac_is"] = ("algorithmic bytes (SURVEY 8d: %g B per cell-step x cell-steps per launch) / launch time / 8 TB/s -- not HBM "
+                    "utilisation: see hbm_frac_measured (PMC traffic / peak) and valu_issue_frac beside it" % bpc)
     if leg["workload"] in ("s-dam", "s-rain", "s-rough") and leg.get("manning_uniform", True):
         # the synthetic workloads have ONE Manning value, which the engine passes as a scalar: the bytes such a launch
         # really has to move are 72 (fp64) / 36 (fp32) per cell; SURVEY 8(d)'s contract figure stays above
@@ -372,6 +413,7 @@ def main():
     ap.add_argument("--no-manning-leg", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")
     ap.add_argument("--no-moving-leg", action="store_true", help="skip the moving-water leg (S-ROUGH) of the default line")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the c3_muscl / c5_fp32_rain legs of the default line (BASELINE configs[2], [4])")
     ap.add_argument("--no-single-leg", action="store_true", help="N > 1: skip rank 0's single-domain leg (speedup_vs_1gpu_same_run)")
     ap.add_argument("--repeats", type=int, default=3, help="timed repeats of --steps steps; the median is reported")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed time-based pre-warm (the state is restored afterwards)")
@@ -408,6 +450,17 @@ def main():
             manning_leg["manning_uniform"] = False
         if args.math == "fast" and not args.no_strict_leg:
             strict_leg = run_leg(args, hp, cols, rows, 1, 0, local_rank, "strict", repeats=1)
+        c3_legs, c5_leg = {}, None
+        if default_cfg and not args.no_config_legs:
+            # BASELINE.json configs[2] and configs[4] on the driver's own line (missing #2): the MUSCL-Hancock kernel on
+            # the same grid -- the bench window and a developed flood -- and C5's shape, 8192^2 fp32 with gridded rain fused into the
+            # flux kernel (at least 50 warm-up steps: the hydrological gate, one second of model time, opens inside the window)
+            a3 = variant(args, scheme="muscl")
+            c3_legs["window"] = (a3, run_leg(a3, hp, cols, rows, 1, 0, local_rank, "fast", repeats=1))
+            a3d = variant(args, scheme="muscl", evolve_steps=1500)
+            c3_legs["developed"] = (a3d, run_leg(a3d, hp, cols, rows, 1, 0, local_rank, "fast", repeats=1))
+            a5 = variant(args, precision="f32", workload="s-rain", warmup=max(args.warmup, 50))
+            c5_leg = (a5, run_leg(a5, hp, 8192, 8192, 1, 0, local_rank, "fast", repeats=1, workload="s-rain"))
         moving_leg = None
         if args.workload == "s-dam" and not args.no_moving_leg:
             # the headline window of S-DAM is ~98 % still water; this leg is the same grid, scheme and mode on water that moves
@@ -434,7 +487,8 @@ def main():
                 single_leg = run_leg(args, hp, strong_grid[0], strong_grid[1], 1, 0, local_rank, args.math, repeats=max(1, args.repeats - 1))
             dist.barrier()
             dist.destroy_process_group()
-        manning_leg = strict_leg = moving_leg = None
+        manning_leg = strict_leg = moving_leg = c5_leg = None
+        c3_legs = {}
         default_cfg = False
 
     if rank == 0:
@@ -489,14 +543,33 @@ def main():
                                    "ms_per_step": moving_leg["elapsed"] / args.steps * 1e3, "frac": rw["frac"],
                                    "frac_basis": rw["frac_basis"], "frac_event_sampled": rw["frac_event_sampled"],
                                    "kernel": rw["kernel"], "sim_time_s": moving_leg["sc"]["time"]}
+        def extra_leg(what, a, leg, stem, kernel_substr):
+            r = roofline_of(a, leg)
+            attach_pmc(r, kernel_substr, stem)
+            n = leg["cols"] * leg["rows"]
+            e = {"what": what + ": " + workload_of(a, leg), "value": n * a.steps / leg["elapsed"] / 1e6, "unit": "Mcell-steps/s",
+                 "dtype": a.precision, "ms_per_step": leg["elapsed"] / a.steps * 1e3,
+                 "timed_steps": [a.warmup + a.evolve_steps, a.warmup + a.evolve_steps + a.steps], "sim_time_s": leg["sc"]["time"]}
+            for key in ("frac", "achieved", "kernel", "frac_basis", "avg_launch_ms", "frac_event_sampled", "launches_sampled", "iterations_per_launch",
+                        "algorithmic_bytes_per_cell_step", "frac_of_bytes_launch_must_move", "traffic", "traffic_source", "hbm_frac_measured", "valu_issue_frac"):
+                if key in r:
+                    e[key] = r[key]
+            if leg.get("fused") is not None:
+                e["area_boundaries"] = "fused into the flux kernel's store epilogue" if leg["fused"] else "separate pass"
+            return e
+        if c3_legs:
+            a, leg = c3_legs["window"]
+            out["c3_muscl"] = extra_leg("BASELINE configs[2]: MUSCL-Hancock + MINMOD, bench window", a, leg, "muscl4096", "muscl_march<false")
+            a, leg = c3_legs["developed"]
+            out["c3_muscl"]["developed_flood"] = extra_leg("the same after 1500 untimed steps", a, leg, "muscl4096_developed", "muscl_march<false")
+        if c5_leg:
+            a, leg = c5_leg
+            out["c5_fp32_rain"] = extra_leg("BASELINE configs[4]'s shape on one GPU: fp32, spatially varying rainfall", a, leg,
+                                            "godunov_srain_f32_8192", "godunov_march")
         if default_cfg:
             # (the pair kernel's name when launches covered two iterations: hp::godunov_march2<...>)
-            tr = pmc_traffic("godunov_march2<" if out["roofline"]["iterations_per_launch"] == 2 else args.scheme + "_march<false", args.scheme)
-            k_ms = out["roofline"]["avg_launch_ms"]
-            if tr:
-                out["roofline"]["traffic"] = tr[0] / 1e9 / (k_ms * 1e-3) if k_ms > 0 else None   # GB/s, same unit as achieved
-                out["roofline"]["traffic_bytes_per_launch"] = tr[0]
-                out["roofline"]["traffic_source"] = "profiles/" + tr[1]
+            attach_pmc(out["roofline"], "godunov_march2<" if out["roofline"]["iterations_per_launch"] == 2 else args.scheme + "_march<false",
+                       args.scheme + "4096")
         if not args.no_cpu_baseline and world == 1:
             scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
             out["cpu_baseline"] = cpu_baseline(main_leg["cols"], args.precision, scheme, main_leg["levels"])

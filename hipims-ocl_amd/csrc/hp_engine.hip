@@ -162,8 +162,9 @@ struct hp_domain {
 	bool             push_now = false;                // this iteration's advance kernel carries the ghost rows
 	// the flux launch's own tail block instead of a separate advance launch (LaunchTail, hp_kernels.hpp): small launches only
 	unsigned long long* tail_words = nullptr;         // one word per flux block (EMPTY between launches)
-	bool             rings_differ = false;            // a partial state upload went into ONE buffer: the edge rings of the two may differ (swap_edge_ring)
+	bool             rings_differ = false;            // a partial state upload went into ONE buffer: the edge rings of the two may differ -- no iteration pairs until the next full upload (pair_eligible)
 	bool             saved_rings_differ = false;
+	bool             rings_checked = false;           // ... and have been compared since (rings_really_differ): the flag is a fact, not a maybe
 	bool             fill_now = false;                // this iteration's K1 launch stores the cells the reference leaves untouched as well (dispatch_begin)
 	bool             other_stale = false;             // pairs (godunov_march2) ran since the non-current state buffer last held a state the single-iteration kernels can build on
 	int              march2_rseg = 24;                // tile height of the two-iterations kernel
@@ -171,6 +172,7 @@ struct hp_domain {
 	int              march2_nbands = 8;               // its row bands (one-round grids: searched)
 	bool             print_tiling = false;
 	uint64_t         pairs = 0;                       // iteration pairs run by it
+	unsigned         single_streak = 0;               // single iterations since the last pair (step_begin_impl: which launches hp_kernel_timing samples)
 	uint64_t         flux_launches = 0, flux_launches_tailed = 0;   // whole-domain flux launches of hp_step_batch / hp_strip_step_batch, and how many carried their own tail block
 	bool             tail_failed = false;             // a tail block gave up waiting (SLOT_TAIL_ERR seen by the host): the domain is unusable
 	bool             strip_first = false;             // hp_strip_step_batch: the batch's first iteration
@@ -647,7 +649,10 @@ template <typename T, bool STRICT> int step_begin_impl(hp_domain* d)
 	// hp_kernel_timing (nothing is created inside a timed region; once the pool is used up sampling stops)
 	// (a domain whose batches are made of iteration pairs samples THOSE launches -- run_pair -- not the odd single iteration at a
 	// batch's ends: hp_kernel_timing reports one kernel's average, the dominant one's)
-	const bool sample = d->timing_stride > 0 && d->timing_used < d->timing_events.size() && !pairs_possible(d) &&
+	// (... while pairs really run: a domain that COULD pair but does not -- batches of one iteration, a launch too big for the tail
+	// block, a maximum that stays stale -- is seen by its run of single iterations and samples them)
+	d->single_streak++;
+	const bool sample = d->timing_stride > 0 && d->timing_used < d->timing_events.size() && (!pairs_possible(d) || d->single_streak > 3) &&
 	                    (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (sample) {
@@ -816,9 +821,36 @@ static bool pairs_possible(const hp_domain* d)          // a single domain
 	return pairs_possible_common(d) && !d->comm && d->comm_world <= 1 && !d->peer_mine && d->desc.row_offset == 0 &&
 	       d->desc.global_rows == d->desc.rows;
 }
+// After partial uploads (rings_differ: the two buffers' edge rings MAY differ) the rings are compared once, the first time pairs are
+// wanted: block-wise loads of a whole grid (hp_domain_upload_rows over all rows: how grids too big for one host array arrive) leave
+// them equal to the zero-filled other buffer's wherever the ring is the usual closed wall (state 0), and such domains pair.  Blocks.
+constexpr size_t HOST_RINGS = 496;          // byte offset in the pinned block
+static int rings_really_differ(hp_domain* d)
+{
+	if (!d->rings_differ || d->rings_checked) return HP_OK;
+	unsigned long long* word = (unsigned long long*)((char*)d->scalars + 192);     // (device scratch behind the Scalars block)
+	HIP_TRY(hipMemsetAsync(word, 0, 8, d->stream));
+	if (d->desc.precision == 8)
+		hipLaunchKernelGGL((rings_compare<double>), dim3(32), dim3(256), 0, d->stream, (const State4<double>*)d->state[0],
+		                   (const State4<double>*)d->state[1], (long)d->desc.cols, (long)d->desc.rows, word);
+	else
+		hipLaunchKernelGGL((rings_compare<float>), dim3(32), dim3(256), 0, d->stream, (const State4<float>*)d->state[0],
+		                   (const State4<float>*)d->state[1], (long)d->desc.cols, (long)d->desc.rows, word);
+	HIP_TRY(hipGetLastError());
+	volatile unsigned long long* host = (volatile unsigned long long*)((char*)d->host_scalars + HOST_RINGS);
+	*host = 1;
+	HIP_TRY(hipMemcpyAsync((void*)host, word, 8, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	d->rings_checked = true;
+	if (*host == 0) d->rings_differ = false;
+	return HP_OK;
+}
+// (not after a PARTIAL upload -- rings_differ, until the next full one: queueWritePartial goes to the current buffer only, so the two
+// buffers' edge rings may differ, and single iterations read the OTHER buffer's ring on every second iteration while a pair carries the
+// primary buffer's through both steps: next to ring cells that matter hydraulically -- an edge without walls -- the two part.  ADVICE r05)
 static bool pair_eligible(const hp_domain* d)
 {
-	return pairs_possible(d) && d->use_alt == 0 && (!d->desc.dynamic_dt || (!d->need_full_reduce && !d->edge_dirty));
+	return pairs_possible(d) && d->use_alt == 0 && !d->rings_differ && (!d->desc.dynamic_dt || (!d->need_full_reduce && !d->edge_dirty));
 }
 // A ROW STRIP runs pairs where it stores two reaches of ghost rows (one exchange per two iterations anyway) and the strips write
 // their rows into each other themselves (transport level 2: the pair's tail block holds the one mailbox round, which is the
@@ -868,11 +900,7 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip)
 	HIP_TRY(hipGetLastError());
 	if (sample) { HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].second, d->stream)); d->timing_used++; }
 	// the pass wrote state k + 2 into the other buffer: that buffer IS the primary one from here on (two single iterations would
-	// have left the newest state in the primary buffer; the ring maxima are the same for both buffers while no ring cell changes)
-	if (d->rings_differ)                                                  // (rare: only after partial uploads -- see swap_edge_ring)
-		hipLaunchKernelGGL((swap_edge_ring<T>), dim3(32), dim3(256), 0, d->stream, (State4<T>*)d->state[0], (State4<T>*)d->state[1],
-		                   (long)d->desc.cols, (long)d->desc.rows);
-	HIP_TRY(hipGetLastError());
+	// have left the newest state in the primary buffer; the two buffers' edge rings are equal -- pair_eligible -- and so are their maxima)
 	std::swap(d->state[0], d->state[1]);
 	if (strip) {                                                          // every rank swaps: a neighbour's buffer b is the one it calls b now
 		std::swap(d->peer_state[0][0], d->peer_state[0][1]);
@@ -880,6 +908,7 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip)
 		d->ghost_valid = d->ghost_rows;                                   // the exchange happened inside the launch
 	}
 	d->other_stale = true;
+	d->single_streak = 0;
 	d->tail_done = false; d->fork_is_advance = false;
 	d->adv_fresh = d->desc.dynamic_dt ? 1 : 0;
 	d->cells_calculated += 2 * (uint64_t)d->desc.cols * (uint64_t)d->desc.rows;
@@ -893,16 +922,8 @@ static int run_pair(hp_domain* d, const bool strip = false) { return d->desc.pre
 static int repair_other_buffer(hp_domain* d)
 {
 	if (!d->other_stale) return HP_OK;
-	if (!d->rings_differ) {
-		HIP_TRY(hipMemcpyAsync(d->state[d->use_alt ^ 1], d->state[d->use_alt], d->cells * 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
-	} else if (d->desc.precision == 8) {                                  // (each buffer keeps its own edge ring)
-		hipLaunchKernelGGL((copy_interior<double>), dim3(2048), dim3(256), 0, d->stream, (const State4<double>*)d->state[d->use_alt],
-		                   (State4<double>*)d->state[d->use_alt ^ 1], (long)d->desc.cols, (long)d->desc.rows);
-	} else {
-		hipLaunchKernelGGL((copy_interior<float>), dim3(2048), dim3(256), 0, d->stream, (const State4<float>*)d->state[d->use_alt],
-		                   (State4<float>*)d->state[d->use_alt ^ 1], (long)d->desc.cols, (long)d->desc.rows);
-	}
-	HIP_TRY(hipGetLastError());
+	// (the edge rings of the two buffers are equal whenever pairs have run: pair_eligible, hp_domain_upload_rows)
+	HIP_TRY(hipMemcpyAsync(d->state[d->use_alt ^ 1], d->state[d->use_alt], d->cells * 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
 	d->other_stale = false;
 	return HP_OK;
 }
@@ -1498,10 +1519,18 @@ int hp_state_restore(hp_domain_t* d)
 	HIP_TRY(hipMemcpyAsync(d->state[d->saved_use_alt], d->saved_state, bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->state[d->saved_use_alt ^ 1], (char*)d->saved_state + bytes, bytes, hipMemcpyDeviceToDevice, d->stream));
 	HIP_TRY(hipMemcpyAsync(d->scalars, d->saved_scalars, sc_bytes, hipMemcpyDeviceToDevice, d->stream));
-	HIP_TRY(hipMemcpyAsync(d->cfl_slot, (char*)d->saved_scalars + sc_bytes, CFL_SLOT_BYTES, hipMemcpyDeviceToDevice, d->stream));
+	// (the slot block AROUND the sticky "a tail block gave up" word: a word raised since the checkpoint, and not yet seen by the host
+	// through hp_sync / hp_read_scalars, must survive the roll-back -- ADVICE r05)
+	{
+		const size_t lo = (size_t)SLOT_TAIL_ERR * d->esize, hi = lo + d->esize;
+		const char* from = (const char*)d->saved_scalars + sc_bytes;
+		HIP_TRY(hipMemcpyAsync(d->cfl_slot, from, lo, hipMemcpyDeviceToDevice, d->stream));
+		HIP_TRY(hipMemcpyAsync((char*)d->cfl_slot + hi, from + hi, CFL_SLOT_BYTES - hi, hipMemcpyDeviceToDevice, d->stream));
+	}
 	d->use_alt = d->saved_use_alt;
 	d->other_stale = false;                                               // (a checkpoint is taken with both buffers brought up to date)
 	d->rings_differ = d->saved_rings_differ;
+	d->rings_checked = false;
 	d->ghost_valid = d->saved_ghost_valid;
 	// a bed or state upload between save and restore has left its own marks: they stay
 	d->need_full_reduce = d->need_full_reduce || d->saved_full_reduce;
@@ -1536,11 +1565,15 @@ int hp_domain_upload_rows(hp_domain_t* d, const void* host, int64_t row0, int64_
 	if (!host) return fail(HP_ERR_INVALID, "host == NULL");
 	if (row0 < 0 || nrows < 0 || row0 + nrows > d->desc.rows) return fail(HP_ERR_INVALID, "row range out of bounds");
 	const size_t per_row = (size_t)d->desc.cols * d->esize * 4;
+	// queueWritePartial goes to the CURRENT buffer only: the other one keeps what it held -- after iteration pairs it has to be
+	// brought up to date first, or the rows written now would reach it with the next single iteration's FILL
+	if ((rc = repair_other_buffer(d)) != HP_OK) return rc;
 	HIP_TRY(hipMemcpyAsync((char*)d->state[d->use_alt] + (size_t)row0 * per_row, host, (size_t)nrows * per_row,
 	                       hipMemcpyHostToDevice, d->stream));
 	d->need_full_reduce = true;
 	d->edge_dirty = true;
 	d->rings_differ = true;
+	d->rings_checked = false;
 	return HP_OK;
 }
 
@@ -1785,6 +1818,7 @@ int run_iterations(hp_domain* d, uint32_t n_iterations)
 	int rc;
 	for (uint32_t i = 0; i < n_iterations; ++i) {
 		// two iterations in one pass where that is the same computation (run_pair)
+		if (i + 2 <= n_iterations && d->rings_differ && !d->rings_checked && pairs_possible(d) && (rc = rings_really_differ(d)) != HP_OK) return rc;
 		if (i + 2 <= n_iterations && pair_eligible(d)) {
 			rc = run_pair(d);
 			if (rc == HP_OK) { ++i; continue; }

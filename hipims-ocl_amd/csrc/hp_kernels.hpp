@@ -350,10 +350,10 @@ template <typename T>
 __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail<T>& tail)
 {
 	__shared__ T part[4];
-	__shared__ int late_any;
-	if (threadIdx.x == 0) late_any = atomic_peek(tail.slot + SLOT_TAIL_ERR) != T(0);   // an earlier launch of this domain gave up
+	__shared__ int failed_before, late_any;     // two words: a wave that times out early must not look like "an earlier launch failed" to a slower wave's first read
+	if (threadIdx.x == 0) { failed_before = atomic_peek(tail.slot + SLOT_TAIL_ERR) != T(0); late_any = 0; }   // an earlier launch of this domain gave up
 	__syncthreads();
-	if (late_any) return;
+	if (failed_before) return;
 	T m = T(0);
 	bool late = false;
 	for (unsigned i = threadIdx.x; i < tail.poll_blocks; i += blockDim.x) {
@@ -487,6 +487,17 @@ __device__ __forceinline__ float buf_load_scalar(__amdgpu_buffer_rsrc_t r, const
 // ours is.  All operands of the store are therefore kept alive through the wait states behind it: nothing may overwrite
 // them before this fence, whatever else gets scheduled in between (four wait states: round 2's two were found by trial, and
 // the cost is two cycles per row).
+// The fence binds VALUES, not registers (round 6, tools/isa_store_hazard.py): where the stored values also live in other registers -- the
+// state that is stored is priced, carried to the next row, stored a second time into a strip neighbour -- the compiler satisfied the
+// fence's inputs from THOSE copies and recycled the store's own data registers one slot behind it (found in the shipped code of round 5:
+// godunov_march2<0, 2, float>, inertial_march<true, 0, 2, double>, both behind a peer store).  store_operands_own makes the four data
+// words values of their own first: defined by an (empty) asm, they have no other copy the fence could be fed from, so keeping them
+// alive to the fence means keeping the store's registers.  The build's assembly is scanned for the pattern on every build
+// (tests/test_resource_usage.py): a store whose data or offset register is written inside the window fails the CPU suite.
+__device__ __forceinline__ void store_operands_own(hp_u32x4& a)
+{
+	asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+}
 __device__ __forceinline__ void store_fence(const hp_u32x4& a, const unsigned voff, const unsigned soff)
 {
 	asm volatile("s_nop 3" : : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(voff), "s"(soff) : "memory");
@@ -508,6 +519,7 @@ __device__ __forceinline__ void buf_store_state(const State4<double>& s, __amdgp
 	a.z = (unsigned)__double2loint(s.zmax); a.w = (unsigned)__double2hiint(s.zmax);
 	b.x = (unsigned)__double2loint(s.qx); b.y = (unsigned)__double2hiint(s.qx);
 	b.z = (unsigned)__double2loint(s.qy); b.w = (unsigned)__double2hiint(s.qy);
+	store_operands_own(a); store_operands_own(b);
 	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, AUX);
 	__builtin_amdgcn_raw_buffer_store_b128(b, r, (int)voff + 16, (int)soff, AUX);
 	store_fence(a, voff, soff);
@@ -519,6 +531,7 @@ __device__ __forceinline__ void buf_store_state(const State4<float>& s, __amdgpu
 	asm volatile("" : "+v"(voff));
 	hp_u32x4 a;
 	a.x = __float_as_uint(s.z); a.y = __float_as_uint(s.zmax); a.z = __float_as_uint(s.qx); a.w = __float_as_uint(s.qy);
+	store_operands_own(a);
 	__builtin_amdgcn_raw_buffer_store_b128(a, r, (int)voff, (int)soff, AUX);
 	store_fence(a, voff, soff);
 }
@@ -1347,36 +1360,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	if (TAIL != 0) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
 }
 
-// The edge ring of the two state buffers, exchanged (godunov_march2's companion; launched only while the rings differ).  No flux
-// kernel writes ring cells, so each buffer keeps the ring it was given -- the same in both after a full upload, different after
-// a PARTIAL one (queueWritePartial goes to the current buffer only).  Two single iterations leave the newest state in the buffer
-// it started from; a pair leaves it in the other one, and the host swaps the pointers: the rings swap with them here, so that
-// every later download shows what the single iterations would have shown.
+// Do the edge rings of the two state buffers hold the same bits?  (hp_engine.hip: rings_really_differ.  No flux kernel writes ring cells,
+// so each buffer keeps the ring it was given -- the same in both after a full upload, possibly different after a PARTIAL one, which goes
+// to the current buffer only, CSchemeGodunov.cpp:1064-1065 vs queueWritePartial.  A pair carries the primary buffer's ring through both
+// of its steps, single iterations read the other buffer's on every second one: pairs need equal rings.)  Raises *differ.
 template <typename T>
-__global__ __launch_bounds__(256) void swap_edge_ring(State4<T>* __restrict__ a, State4<T>* __restrict__ b, const long cols, const long rows)
+__global__ __launch_bounds__(256) void rings_compare(const State4<T>* __restrict__ a, const State4<T>* __restrict__ b, const long cols, const long rows,
+                                                     unsigned long long* differ)
 {
 	const long n = 2 * cols + 2 * (rows - 2);
+	bool bad = false;
 	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
 		long x, y;
 		if (i < cols) { x = i; y = 0; }
 		else if (i < 2 * cols) { x = i - cols; y = rows - 1; }
 		else { const long j = i - 2 * cols; x = (j & 1) ? cols - 1 : 0; y = 1 + (j >> 1); }
 		const size_t id = (size_t)y * cols + x;
-		const State4<T> va = a[id], vb = b[id];
-		a[id] = vb; b[id] = va;
+		// bit patterns, not values: -0.0 / +0.0 and NaNs would otherwise pass or fail for the wrong reason
+		const unsigned* wa = reinterpret_cast<const unsigned*>(a + id);
+		const unsigned* wb = reinterpret_cast<const unsigned*>(b + id);
+		#pragma unroll
+		for (unsigned w = 0; w < sizeof(State4<T>) / 4; ++w) bad = bad || wa[w] != wb[w];
 	}
-}
-
-// ... and the interior of one buffer copied onto the other's (the rings stay as they are): what hipMemcpy does for run_pair's
-// repair of the non-current buffer while the rings are equal, for the rare domain whose rings differ
-template <typename T>
-__global__ __launch_bounds__(256) void copy_interior(const State4<T>* __restrict__ from, State4<T>* __restrict__ to, const long cols, const long rows)
-{
-	const size_t cells = (size_t)cols * rows;
-	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x) {
-		const long y = (long)(id / cols), x = (long)(id - (size_t)y * cols);
-		if (x >= 1 && x <= cols - 2 && y >= 1 && y <= rows - 2) to[id] = from[id];
-	}
+	if (bad) *differ = 1ull;
 }
 
 // -------------------------------------------------------------------------------------------------

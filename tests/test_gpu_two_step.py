@@ -3,8 +3,9 @@ computation as the two single-iteration launches -- same per-cell operations in 
 instead of memory -- so the FAST engine with pairs (HP_TWO_STEP=1) is held to the FAST engine without (HP_TWO_STEP=0) BIT FOR BIT:
 state, time, timestep, counters; over batches of odd and even length, downloads in between, a sync point with clipped and
 suspended iterations, tst_UpdateTimestep, a device checkpoint, wet/dry terrain with untouched cells (quirk Q3), fp64 and fp32,
-dynamic and fixed timestep.  (Against the oracle the FAST mode keeps its usual tolerance: tests/test_gpu_parity.py run with the
-default, under which grids of a million cells and more take the pair kernel.)"""
+dynamic and fixed timestep.  (This is a self-comparison.  The pair kernel against the ORACLE and the reference-kernel fixtures:
+tests/test_gpu_pairs_oracle.py -- the oracle comparisons of tests/test_gpu_parity.py stay below the default's threshold, 1.5 M cells
+or two rounds of blocks at 12-row tiles, and run godunov_march.)"""
 import os
 import subprocess
 import sys

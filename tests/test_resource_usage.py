@@ -1,0 +1,66 @@
+"""What the compiler made of the kernels, held against a committed table (CPU only -- hipcc cross-compiles).
+
+Round 5 ended with an instantiation whose results depended on what the register allocator had spilled (LAB_NOTES R5.13), and nothing
+in the build or the tests bounded spills or checked the one hand-made hazard fence of the engine.  Two checks on the BUILT library:
+
+* every kernel's scratch bytes and spilled vector registers stay within hipims-ocl_amd/csrc/resource_budget.json (the build writes
+  the compiler's kernel-resource-usage remarks to lib/resource_usage.txt -- the reference logs the same figures for every kernel it
+  creates, src/OpenCL/Executors/COCLKernel.cpp:284-328); a STRICT instantiation -- the mode that promises the reference's bits -- may
+  spill vector registers only if the table names it (each named one is under an `array_equal` test against the oracle on the GPU);
+* no 16-byte buffer store has one of its operand registers written inside the hazard window behind it (tools/isa_store_hazard.py
+  on the library's own code object: the fence of hp_kernels.hpp binds values, the scan looks at registers)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+CSRC = os.path.join(ROOT, "hipims-ocl_amd", "csrc")
+LIB = os.path.join(ROOT, "hipims-ocl_amd", "lib", "libhipims_mi.so")
+USAGE = os.path.join(ROOT, "hipims-ocl_amd", "lib", "resource_usage.txt")
+BUDGET = os.path.join(CSRC, "resource_budget.json")
+
+
+@pytest.fixture(scope="module")
+def built():
+    """The library and its usage file, newer than every source (a stale binary would be checked against the wrong table)."""
+    sources = [os.path.join(CSRC, f) for f in ("hp_engine.hip", "hp_kernels.hpp", "hp_math.hpp", "hp_crmath.h", "Makefile")]
+    newest = max(os.path.getmtime(f) for f in sources)
+    if not (os.path.exists(LIB) and os.path.exists(USAGE) and min(os.path.getmtime(LIB), os.path.getmtime(USAGE)) >= newest):
+        subprocess.check_call(["make", "-C", CSRC, "all"])                      # (two minutes)
+    return LIB
+
+
+def test_spills_and_scratch_stay_within_the_committed_table(built):
+    import resource_usage as ru
+    recs = ru.parse(USAGE)
+    budget = json.load(open(BUDGET))
+    table, strict_allowed = budget["kernels"], set(budget["strict_kernels_allowed_to_spill_vector_registers"])
+    assert len(recs) > 150                                                       # every instantiation reported
+    over, strict_spills = [], []
+    for name, r in recs.items():
+        if r["scratch"] is None or r["vgpr_spill"] is None:
+            over.append((name, "no figures (indirect call / dynamic stack?)"))
+            continue
+        b = table.get(name, {"scratch": 0, "vgpr_spill": 0})
+        if r["scratch"] > b["scratch"] or r["vgpr_spill"] > b["vgpr_spill"]:
+            over.append((name, f"scratch {r['scratch']} B (budget {b['scratch']}), spilled VGPRs {r['vgpr_spill']} (budget {b['vgpr_spill']})"))
+        if ru.is_strict(name) and r["vgpr_spill"] > 0 and name not in strict_allowed:
+            strict_spills.append((name, r["vgpr_spill"]))
+    assert not over, "kernels over their budget (raise csrc/resource_budget.json only with the bit-exact GPU suite green):\n" + \
+        "\n".join(f"  {n}: {w}" for n, w in over)
+    assert not strict_spills, f"STRICT instantiations with vector spills that the table does not name: {strict_spills}"
+    # the headline kernels' shape is part of the design: three waves per SIMD for the fp64 marches
+    for name in ("hp::godunov_march2<1, 1, double>", "hp::godunov_march<false, 1, false, 1, double, false>"):
+        assert recs[name]["waves"] == 3, (name, recs[name]["waves"])
+
+
+def test_no_register_of_a_16_byte_store_is_written_inside_the_hazard_window(built, tmp_path):
+    import isa_store_hazard as ish
+    report, bad = ish.scan(ish.disassemble(built, str(tmp_path)), 4)
+    assert len(report) > 150
+    offenders = {k: v for k, v in report.items() if v[1] is not None and v[1][0] < 4}
+    assert bad == 0 and not offenders, offenders

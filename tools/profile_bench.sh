@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/$1; shift
 rm -rf "$OUT"; mkdir -p "$OUT"
-ARGS="$* --no-cpu-baseline --no-manning-leg --no-moving-leg --no-strict-leg"
+ARGS="$* --no-cpu-baseline --no-manning-leg --no-moving-leg --no-strict-leg --no-config-legs"
 QUICK="--prewarm-s 0.1 --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 200 --warmup 20 $ARGS > $OUT/bench_kt.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 20 --warmup 5 $QUICK $ARGS > $OUT/bench_pmc_sq.log 2>&1

@@ -1,28 +1,60 @@
 #!/usr/bin/env python3
-"""Compact per-kernel resource table (VGPRs, SGPRs, scratch, LDS, occupancy) from hipcc's
--Rpass-analysis=kernel-resource-usage; runs here (cross-compile, no GPU).  usage: tools/resource_usage.py [filter]"""
-import os, re, subprocess, sys
+"""Parse the compiler's kernel-resource-usage remarks (hipims-ocl_amd/lib/resource_usage.txt, written by the library's build) into
+one record per kernel: demangled name, VGPRs, SGPRs, spilled VGPRs / SGPRs, scratch bytes per lane, waves per SIMD, LDS bytes.
+
+    python tools/resource_usage.py [resource_usage.txt]            # the table
+    python tools/resource_usage.py [resource_usage.txt] --budget   # JSON in the shape of csrc/resource_budget.json
+
+tests/test_resource_usage.py imports parse().  (The reference logs the same figures for every kernel it creates:
+src/OpenCL/Executors/COCLKernel.cpp:284-328.)"""
+import json
+import os
+import re
+import subprocess
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "hipims-ocl_amd", "csrc", "hp_engine.hip")
-flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math".split()
-out = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
-                     capture_output=True, text=True).stderr
-rows, cur = [], None
-for line in out.splitlines():
-    m = re.search(r"remark:\s+(.*?)\s+\[-Rpass", line)
-    if not m:
-        continue
-    t = m.group(1)
-    if t.startswith("Function Name:"):
-        cur = {"name": t.split(":", 1)[1].strip()}
-        rows.append(cur)
-    elif cur is not None and ":" in t:
-        k, v = t.split(":", 1)
-        cur[k.strip()] = v.strip()
-names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
-flt = sys.argv[1] if len(sys.argv) > 1 else ""
-print(f"{'kernel':70s} VGPR AGPR SGPR scratch   LDS occ  sgpr-spill vgpr-spill")
-for r, n in zip(rows, names):
-    n = re.sub(r"\(.*", "", n).replace("void hp::", "")
-    if flt in n:
-        print(f"{n:70s} {r.get('VGPRs','?'):>4} {r.get('AGPRs','?'):>4} {r.get('TotalSGPRs','?'):>4} {r.get('ScratchSize [bytes/lane]','?'):>7} {r.get('LDS Size [bytes/block]','?'):>5} {r.get('Occupancy [waves/SIMD]','?'):>3} {r.get('SGPRs Spill','?'):>10} {r.get('VGPRs Spill','?'):>10}")
+DEFAULT = os.path.join(ROOT, "hipims-ocl_amd", "lib", "resource_usage.txt")
+FIELDS = {"VGPRs": "vgprs", "TotalSGPRs": "sgprs", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill",
+          "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "waves", "LDS Size [bytes/block]": "lds"}
+
+
+def parse(path=DEFAULT):
+    recs, cur = [], None
+    for line in open(path):
+        body = line.strip()
+        if body.startswith("Function Name:"):
+            cur = {"mangled": body.split(": ", 1)[1]}
+            recs.append(cur)
+        elif cur is not None and ":" in body:
+            k, v = body.split(":", 1)
+            if k.strip() in FIELDS:
+                v = v.strip()
+                cur[FIELDS[k.strip()]] = int(v) if re.fullmatch(r"-?\d+", v) else None      # (symbolic: a kernel that calls through a pointer)
+    names = subprocess.run(["c++filt"] + [r["mangled"] for r in recs], capture_output=True, text=True, check=True).stdout.splitlines()
+    out = {}
+    for r, n in zip(recs, names):
+        n = re.sub(r"^void ", "", re.sub(r"\(.*", "", n))
+        if not n.startswith("hp::"):
+            continue                                                       # (the two store_scalar / copy_scalar helpers of the host file)
+        r["name"] = n
+        out[n] = r
+    return out
+
+
+def is_strict(name):
+    """STRICT instantiations: the first template argument of the flux kernels / the reductions."""
+    m = re.match(r"hp::(godunov_march|muscl_march|inertial_march|godunov_basic|cfl_reduce|cfl_edge_ring)<(true|false)", name)
+    return bool(m and m.group(2) == "true")
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    recs = parse(args[0] if args else DEFAULT)
+    if "--budget" in sys.argv:
+        print(json.dumps({n: {"scratch": r["scratch"], "vgpr_spill": r["vgpr_spill"]} for n, r in sorted(recs.items())
+                          if (r["scratch"] or 0) > 0 or (r["vgpr_spill"] or 0) > 0}, indent=1))
+    else:
+        for n, r in recs.items():
+            print(f"{n:72s} VGPR {r['vgprs']!s:>4} SGPR {r['sgprs']!s:>4} scratch {r['scratch']!s:>4} B  spilled V {r['vgpr_spill']!s:>3} S {r['sgpr_spill']!s:>3}"
+                  f"  waves {r['waves']}  LDS {r['lds']}")
