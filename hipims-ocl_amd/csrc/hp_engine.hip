@@ -171,6 +171,15 @@ struct hp_domain {
 	bool             march2_pays = false;             // the grid is big enough for it (hp_domain_create)
 	int              march2_nbands = 8;               // its row bands (one-round grids: searched)
 	bool             print_tiling = false;
+	// quirk Q3 across pair launches, exactly (hp_kernels.hpp: PairAux): stamps of the cells whose first-step stale value the next launch needs
+	void*            z_state = nullptr;               // State4<T> per cell (allocated with the first pair)
+	unsigned*        z_gen = nullptr;                 // per cell: number of the pair launch that stamped it
+	unsigned long long* haz_words = nullptr;          // two words: [g & 1] == g <=> pair launch g stamped something
+	unsigned         pair_gen = 0;                    // number of the last pair launch -- the one that wrote the current state while other_stale holds
+	bool             saved_m1_valid = false;
+	bool             pair_fused_next = false;         // the last pair stored its state with the next iteration's boundaries applied (SLOT_BDY = 1)
+	bool             m1_valid = false;                // area boundaries: cfl_slot[SLOT_M1] prices the primary buffer with the next iteration's boundaries (left by the last pair)
+	uint64_t         pair_cold_starts = 0;
 	uint64_t         pairs = 0;                       // iteration pairs run by it
 	unsigned         single_streak = 0;               // single iterations since the last pair (step_begin_impl: which launches hp_kernel_timing samples)
 	uint64_t         flux_launches = 0, flux_launches_tailed = 0;   // whole-domain flux launches of hp_step_batch / hp_strip_step_batch, and how many carried their own tail block
@@ -420,6 +429,8 @@ template <typename T> int make_tail(hp_domain* d, unsigned& blocks, int part, hi
 	if (part == PART_ALL) d->flux_launches++;
 	if (!(d->tail_want && part == PART_ALL && stream == d->stream && blocks <= limit)) return 0;
 	tail.done = d->tail_words;
+	tail.done1 = d->tail_words + TAIL_MAX_BLOCKS + 8;
+	tail.bdy_flag = 0;
 	tail.flux_blocks = blocks;
 	tail.poll_blocks = blocks + tail_debug_extra_word();
 	tail.timeout = (unsigned long long)tail_timeout_ms() * 100000ull;       // wall_clock64: 100 MHz
@@ -526,13 +537,18 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 		return HP_OK;
 	sweep_direction(d, part, tm);
 	const int truncated = ((d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0 ? 1 : 0) | (d->fill_now ? 2 : 0);   // the kernel's `flags`
+	// (FILL: the source was written by pair launch pair_gen, whose stamps say where the destination must NOT get the source's value)
+	PairAux<T> aux{};
+	if (d->fill_now && d->z_state) {
+		aux.stamps = (const StampBufs<T>*)((const char*)d->haz_words + 16); aux.prev_gen = d->pair_gen;
+	}
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit(), tail);
 #define HP_LAUNCH_K1S(FUSED_, TAIL_, LIST_, NEXT_, SPEC_)                                                                                   \
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, FUSED_, TAIL_, T, SPEC_>), dim3(blocks), dim3(256), 0, stream, p,                   \
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, LIST_, NEXT_,   \
-	                   truncated, tail)
+	                   truncated, tail, aux)
 #define HP_LAUNCH_K1(FUSED_, TAIL_, LIST_, NEXT_) HP_LAUNCH_K1S(FUSED_, TAIL_, LIST_, NEXT_, false)
 	constexpr bool CAN_SPEC = STRICT && sizeof(T) == 8;       // a speculative STRICT fp64 batch: see launch_muscl
 	if (CAN_SPEC && d->spec_now && !d->fusable && tail_kind != 2 && part == PART_ALL) {        // (never with fused boundaries: spec_wanted)
@@ -812,8 +828,13 @@ static bool pairs_possible_common(const hp_domain* d)
 	const int mode = two_step_mode();
 	if (mode == 0 || (mode < 0 && !d->march2_pays)) return false;
 	static const bool tail_enabled = !(std::getenv("HP_LAUNCH_TAIL") && std::atoi(std::getenv("HP_LAUNCH_TAIL")) == 0);
+	// boundary conditions: none, or area boundaries the flux kernel can carry itself (`fusable`: uniform / coarse gridded ones; round 6) --
+	// the pair kernel applies them between its two steps and prices the state it stores with and without the next iteration's
+	// (godunov_march2, BDY); single domains only.  HP_PAIR_BDY=0 keeps such domains on single iterations (A/B runs).
+	static const bool bdy_enabled = !(std::getenv("HP_PAIR_BDY") && std::atoi(std::getenv("HP_PAIR_BDY")) == 0);
+	const bool bdy_ok = d->bdy.empty() || (bdy_enabled && d->fusable && !d->comm && d->comm_world <= 1 && d->desc.dynamic_dt);
 	return d->desc.scheme == HP_SCHEME_GODUNOV && d->desc.kernel != HP_KERNEL_BASIC && d->desc.math_mode == HP_MATH_FAST &&
-	       d->bdy.empty() && (!d->desc.dynamic_dt || (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0) &&
+	       bdy_ok && (!d->desc.dynamic_dt || (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0) &&
 	       tail_enabled && d->tail_words != nullptr && d->desc.rows >= 5 && d->desc.cols >= 5;
 }
 static bool pairs_possible(const hp_domain* d)          // a single domain
@@ -859,7 +880,39 @@ static bool strip_pairs_possible_here(const hp_domain* d)
 {
 	return pairs_possible_common(d) && d->comm && d->comm_world > 1 && d->peer_direct && d->ghost_rows == 2 && !d->rings_differ;
 }
-template <typename T> int run_pair_t(hp_domain* d, const bool strip)
+// The stamps' buffers (PairAux), allocated with a domain's first pair.  HP_PAIR_STAMPS=0: none -- round 5's behaviour, the cell's
+// current value stands in for the stale one everywhere (A/B runs, and the test that shows what the stamps are for).
+static int pair_stamps_alloc(hp_domain* d)
+{
+	static const bool enabled = !(std::getenv("HP_PAIR_STAMPS") && std::atoi(std::getenv("HP_PAIR_STAMPS")) == 0);
+	if (!enabled || d->z_state) return HP_OK;
+	HIP_TRY(hipMalloc(&d->z_state, d->cells * 4 * d->esize));
+	HIP_TRY(hipMalloc((void**)&d->z_gen, d->cells * sizeof(unsigned)));
+	HIP_TRY(hipMalloc((void**)&d->haz_words, 64));
+	HIP_TRY(hipMemsetAsync(d->z_gen, 0, d->cells * sizeof(unsigned), d->stream));
+	HIP_TRY(hipMemsetAsync(d->haz_words, 0, 64, d->stream));
+	// the kernels reach the three buffers through ONE pointer (StampBufs, hp_kernels.hpp): the table sits behind the two words
+	const StampBufs<double> table{(State4<double>*)d->z_state, d->z_gen, d->haz_words};       // (three addresses: the same layout for both precisions)
+	HIP_TRY(hipMemcpyAsync((char*)d->haz_words + 16, &table, sizeof table, hipMemcpyHostToDevice, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));                           // (`table` is a local)
+	return HP_OK;
+}
+// Area boundaries: the pair kernel needs the primary buffer priced WITH the first iteration's boundaries (slot[SLOT_M1]).  Every BDY
+// pair leaves that figure for its successor; where there is no such predecessor -- the first pair after single iterations, an upload,
+// a new target time -- the first half of iteration k is done the reference's own way: the stand-alone boundary pass on the primary
+// buffer (it declines by itself if a fused store has applied them), the stand-alone reduction, and the result moved to SLOT_M1.
+template <typename T> int pair_cold_start(hp_domain* d)
+{
+	int rc;
+	if ((rc = apply_boundaries<T>(d, d->state[0])) != HP_OK) return rc;
+	if ((rc = launch_reduce<T>(d, d->state[0], d->own_lo, d->own_hi)) != HP_OK) return rc;
+	hipLaunchKernelGGL((pair_cold_start_words<T>), dim3(1), dim3(1), 0, d->stream, (T*)d->cfl_slot);
+	HIP_TRY(hipGetLastError());
+	d->m1_valid = true;
+	d->pair_cold_starts++;
+	return HP_OK;
+}
+template <typename T> int run_pair_t(hp_domain* d, const bool strip, const bool followed)
 {
 	const Params<T> p = make_params<T>(d);
 	TileMap tm;
@@ -883,20 +936,39 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip)
 	const int kind = make_tail<T>(d, blocks, PART_ALL, d->stream, tail_limit(), tail);
 	d->tail_want = false; d->tail_allowed = false; d->push_now = false;
 	if (kind != (strip ? 2 : 1)) return HP_ERR_STATE;
-	tail.pair = 1;
+	const bool bdy = !d->bdy.empty();
+	int rc;
+	if ((rc = pair_stamps_alloc(d)) != HP_OK) return rc;
+	bool in_place = false;
+	if (bdy && !d->m1_valid) {                                            // (queued in front of the pair launch: same stream)
+		if ((rc = pair_cold_start<T>(d)) != HP_OK) return rc;
+		in_place = true;
+	} else if (bdy) in_place = d->pair_fused_next;                        // the pair before stored this iteration's boundaries with its state
+	tail.pair = bdy ? 2 : 1;
+	tail.bdy_flag = bdy && followed ? 1 : 0;
+	PairAux<T> aux{};
+	aux.stamps = d->z_state ? (const StampBufs<T>*)((const char*)d->haz_words + 16) : nullptr;
+	aux.prev_gen = d->other_stale ? d->pair_gen : 0u;                     // `src` was written by a pair launch: its stamps apply
+	aux.gen = ++d->pair_gen;
+	if (aux.gen == 0) aux.gen = ++d->pair_gen;                            // (0 means "no launch")
+	aux.list = (const AreaBdyList<T>*)d->fused_list; aux.fuse_next = bdy && followed ? 1 : 0; aux.in_place = in_place ? 1 : 0;
+	aux.truncated = (d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0 ? 1 : 0;
 	const void* src = d->state[0];
 	void* dst = d->state[1];
 	// flux-kernel timing (hp_kernel_timing): as in step_begin_impl -- a sampled launch here covers two iterations
 	const bool sample = d->timing_stride > 0 && d->timing_used < d->timing_events.size() &&
 	                    (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
 	if (sample) HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].first, d->stream));
-#define HP_LAUNCH_K1B(CFL_, TAIL_)                                                                                                        \
-	hipLaunchKernelGGL((godunov_march2<CFL_, TAIL_, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const Scalars<T>*)d->scalars,         \
+#define HP_LAUNCH_K1B(CFL_, BDY_, TAIL_)                                                                                                  \
+	hipLaunchKernelGGL((godunov_march2<false, CFL_, BDY_, TAIL_, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const Scalars<T>*)d->scalars, \
 	                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning, (T*)d->cfl_slot,                    \
-	                   (const T*)d->cfl_slot + SLOT_EDGE, tm, tail)
-	if (strip) { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, 2); else HP_LAUNCH_K1B(0, 2); }
-	else       { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, 1); else HP_LAUNCH_K1B(0, 1); }
+	                   (const T*)d->cfl_slot + SLOT_EDGE, tm, tail, aux)
+	if (strip)    { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, false, 2); else HP_LAUNCH_K1B(0, false, 2); }
+	else if (bdy) HP_LAUNCH_K1B(1, true, 1);                              // (area boundaries pair with a dynamic timestep only: pairs_possible_common)
+	else          { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, false, 1); else HP_LAUNCH_K1B(0, false, 1); }
 #undef HP_LAUNCH_K1B
+	d->pair_fused_next = bdy && followed;
+	d->m1_valid = bdy;
 	HIP_TRY(hipGetLastError());
 	if (sample) { HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].second, d->stream)); d->timing_used++; }
 	// the pass wrote state k + 2 into the other buffer: that buffer IS the primary one from here on (two single iterations would
@@ -916,7 +988,12 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip)
 	d->pairs += 1;
 	return HP_OK;
 }
-static int run_pair(hp_domain* d, const bool strip = false) { return d->desc.precision == 8 ? run_pair_t<double>(d, strip) : run_pair_t<float>(d, strip); }
+// `followed`: another iteration of the same batch comes after the pair (area boundaries: the pair stores its state with that iteration's
+// boundaries applied, as K1's fused epilogue does; a batch's last launch never does -- what a download sees is the reference's buffer)
+static int run_pair(hp_domain* d, const bool strip = false, const bool followed = false)
+{
+	return d->desc.precision == 8 ? run_pair_t<double>(d, strip, followed) : run_pair_t<float>(d, strip, followed);
+}
 // Before a single-iteration kernel builds on the non-current buffer again (it leaves all-dry cells of its destination untouched,
 // quirk Q3): that buffer holds a state two iterations old after pairs -- bring it up to date with one device copy.
 static int repair_other_buffer(hp_domain* d)
@@ -924,6 +1001,15 @@ static int repair_other_buffer(hp_domain* d)
 	if (!d->other_stale) return HP_OK;
 	// (the edge rings of the two buffers are equal whenever pairs have run: pair_eligible, hp_domain_upload_rows)
 	HIP_TRY(hipMemcpyAsync(d->state[d->use_alt ^ 1], d->state[d->use_alt], d->cells * 4 * d->esize, hipMemcpyDeviceToDevice, d->stream));
+	if (d->z_state) {                                                     // ... except where the last pair launch stamped a different value (PairAux)
+		if (d->desc.precision == 8)
+			hipLaunchKernelGGL((stamps_to_buffer<double>), dim3(1024), dim3(256), 0, d->stream, (State4<double>*)d->state[d->use_alt ^ 1],
+			                   (const State4<double>*)d->z_state, d->z_gen, d->haz_words, d->pair_gen, d->cells);
+		else
+			hipLaunchKernelGGL((stamps_to_buffer<float>), dim3(1024), dim3(256), 0, d->stream, (State4<float>*)d->state[d->use_alt ^ 1],
+			                   (const State4<float>*)d->z_state, d->z_gen, d->haz_words, d->pair_gen, d->cells);
+		HIP_TRY(hipGetLastError());
+	}
 	d->other_stale = false;
 	return HP_OK;
 }
@@ -1376,8 +1462,8 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 	if (std::getenv("HP_PRINT_BUFFERS"))
 		std::fprintf(stderr, "[hipims_mi] buffers: state[0] %p state[1] %p bed %p manning %p\n", d->state[0], d->state[1], d->bed, d->manning);
 
-	HIP_TRY_C(hipMalloc((void**)&d->tail_words, (TAIL_MAX_BLOCKS + 8) * sizeof(unsigned long long)));
-	HIP_TRY_C(hipMemset(d->tail_words, 0xff, (TAIL_MAX_BLOCKS + 8) * sizeof(unsigned long long)));      // every word EMPTY
+	HIP_TRY_C(hipMalloc((void**)&d->tail_words, 2 * (TAIL_MAX_BLOCKS + 8) * sizeof(unsigned long long)));
+	HIP_TRY_C(hipMemset(d->tail_words, 0xff, 2 * (TAIL_MAX_BLOCKS + 8) * sizeof(unsigned long long)));      // every word EMPTY (two arrays: LaunchTail::done, done1)
 	HIP_TRY_C(hipHostMalloc(&d->host_scalars, 512, hipHostMallocDefault));
 	HIP_TRY_C(hipMemset(d->state[0], 0, d->cells * 4 * d->esize));
 	HIP_TRY_C(hipMemset(d->state[1], 0, d->cells * 4 * d->esize));
@@ -1413,6 +1499,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
 	hipFree(d->scalars); hipFree(d->cfl_slot);
 	hipFree(d->saved_state); hipFree(d->saved_scalars); hipFree(d->fused_list); hipFree(d->tail_words);
+	hipFree(d->z_state); hipFree(d->z_gen); hipFree(d->haz_words);
 	hipFree(d->spec_state); hipFree(d->spec_scalars);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
@@ -1431,6 +1518,7 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	if (!host) return fail(HP_ERR_INVALID, "host == NULL");
 	if (d->in_step) return fail(HP_ERR_STATE, "upload between hp_step_begin and hp_step_end");
 	switch (which) {
@@ -1500,6 +1588,7 @@ int hp_state_save(hp_domain_t* d)
 	d->saved_edge_dirty = d->edge_dirty;
 	d->saved_use_alt = d->use_alt;
 	d->saved_rings_differ = d->rings_differ;
+	d->saved_m1_valid = d->m1_valid;
 	d->saved_ghost_valid = d->ghost_valid;
 	d->saved_valid = true;
 	return HP_OK;
@@ -1531,6 +1620,8 @@ int hp_state_restore(hp_domain_t* d)
 	d->other_stale = false;                                               // (a checkpoint is taken with both buffers brought up to date)
 	d->rings_differ = d->saved_rings_differ;
 	d->rings_checked = false;
+	d->m1_valid = d->saved_m1_valid;                                      // (slot[SLOT_M1] has come back with the slot block)
+	d->pair_fused_next = false;                                           // (a checkpoint is taken between batches: nothing fused is in the buffer)
 	d->ghost_valid = d->saved_ghost_valid;
 	// a bed or state upload between save and restore has left its own marks: they stay
 	d->need_full_reduce = d->need_full_reduce || d->saved_full_reduce;
@@ -1562,6 +1653,7 @@ int hp_domain_upload_rows(hp_domain_t* d, const void* host, int64_t row0, int64_
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	if (!host) return fail(HP_ERR_INVALID, "host == NULL");
 	if (row0 < 0 || nrows < 0 || row0 + nrows > d->desc.rows) return fail(HP_ERR_INVALID, "row range out of bounds");
 	const size_t per_row = (size_t)d->desc.cols * d->esize * 4;
@@ -1582,6 +1674,7 @@ int hp_boundary_add_uniform(hp_domain_t* d, int definition, const void* series, 
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	if (!series || entries == 0 || !(interval > 0)) return fail(HP_ERR_INVALID, "bad uniform boundary");
 	if (definition != HP_UNIFORM_RAIN_INTENSITY && definition != HP_UNIFORM_LOSS_RATE)
 		return fail(HP_ERR_INVALID, "unknown uniform boundary definition");
@@ -1600,6 +1693,7 @@ int hp_boundary_add_gridded(hp_domain_t* d, int definition, const void* grids, u
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	if (!grids || entries == 0 || grid_rows == 0 || grid_cols == 0 || !(resolution > 0) || !(interval > 0))
 		return fail(HP_ERR_INVALID, "bad gridded boundary");
 	{
@@ -1627,6 +1721,7 @@ int hp_boundary_add_cell(hp_domain_t* d, int depth_definition, int discharge_def
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	if (!cells || count == 0 || !series || entries < 2 || !(interval > 0)) return fail(HP_ERR_INVALID, "bad cell boundary");
 	if (depth_definition < 0 || depth_definition > 3 || discharge_definition < 0 || discharge_definition > 3)
 		return fail(HP_ERR_INVALID, "unknown cell boundary definition");
@@ -1660,6 +1755,7 @@ int hp_boundary_clear(hp_domain_t* d)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	HIP_TRY(hipStreamSynchronize(d->stream));
 	for (auto& b : d->bdy) { hipFree(b.data); hipFree(b.cells); }
 	d->bdy.clear();
@@ -1678,6 +1774,7 @@ int hp_set_target_time(hp_domain_t* d, double t)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	return d->desc.precision == 8 ? set_scalar_field<double>(d, offsetof(Scalars<double>, t_sync), t)
 	                              : set_scalar_field<float>(d, offsetof(Scalars<float>, t_sync), t);
 }
@@ -1686,6 +1783,7 @@ int hp_set_time(hp_domain_t* d, double t)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	return d->desc.precision == 8 ? set_scalar_field<double>(d, offsetof(Scalars<double>, t), t)
 	                              : set_scalar_field<float>(d, offsetof(Scalars<float>, t), t);
 }
@@ -1694,6 +1792,7 @@ int hp_force_timestep(hp_domain_t* d, double dt)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	return d->desc.precision == 8 ? set_scalar_field<double>(d, offsetof(Scalars<double>, dt), dt)
 	                              : set_scalar_field<float>(d, offsetof(Scalars<float>, dt), dt);
 }
@@ -1712,6 +1811,7 @@ int hp_update_timestep(hp_domain_t* d)
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
+	d->m1_valid = false;                                                 // (pairs with area boundaries start cold: pair_cold_start)
 	if (d->in_step) return fail(HP_ERR_STATE, "inside a split step");
 	if (d->desc.dynamic_dt && d->desc.global_rows != d->desc.rows)
 		return fail(HP_ERR_UNSUPPORTED, "hp_update_timestep on a row strip: the maximum must be all-reduced across "
@@ -1820,13 +1920,14 @@ int run_iterations(hp_domain* d, uint32_t n_iterations)
 		// two iterations in one pass where that is the same computation (run_pair)
 		if (i + 2 <= n_iterations && d->rings_differ && !d->rings_checked && pairs_possible(d) && (rc = rings_really_differ(d)) != HP_OK) return rc;
 		if (i + 2 <= n_iterations && pair_eligible(d)) {
-			rc = run_pair(d);
+			rc = run_pair(d, false, i + 2 < n_iterations);
 			if (rc == HP_OK) { ++i; continue; }
 			if (rc != HP_ERR_STATE) return rc;                 // (HP_ERR_STATE: not launchable as a pair -- single iterations)
 		}
 		// (K1 FUSED) every iteration but the last carries its successor's rain / loss: between batches the buffers are
 		// what the reference's are -- a download never sees rain of an iteration that has not begun
 		d->fuse_next = i + 1 < n_iterations;
+		d->m1_valid = false;                           // (a single iteration prices one maximum: the next pair starts cold)
 		d->tail_allowed = true;                        // nothing is queued between the flux launch and the advance in this loop
 		rc = dispatch_begin(d);
 		d->tail_allowed = false;

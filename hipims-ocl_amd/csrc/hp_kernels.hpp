@@ -278,7 +278,11 @@ __global__ void advance_time(const Params<T> p, Scalars<T>* sc, T* slot, const i
 template <typename T> struct LaunchTail {
 	unsigned long long* done;      // nullptr: no tail (the classic two launches)
 	unsigned            flux_blocks;
-	int                 pair;          // the launch covered TWO iterations (godunov_march2): the first advance re-uses the remembered maximum (quirk Q1), the second takes this launch's
+	int                 pair;          // the launch covered TWO iterations (godunov_march2): the first advance re-uses the remembered maximum (quirk Q1), the second takes this launch's;
+	                                   // 2: ... on a domain with area boundaries -- the first advance takes slot[SLOT_M1] (the primary buffer priced WITH the first
+	                                   // iteration's rain, by the launch before), and this launch's second word per block (done1) becomes the next slot[SLOT_M1]
+	unsigned long long* done1;         // (pair == 2) per flux block: its maximum with the boundaries of the iteration after the pair applied
+	int                 bdy_flag;      // (pair == 2) what cfl_slot[SLOT_BDY] holds after this launch: 1 = the state it stored carries the next iteration's boundaries
 	unsigned            poll_blocks;   // words the tail block waits for: flux_blocks (HP_DEBUG_TAIL_EXTRA_WORD=1: one more, which nobody writes -- the time-out's test)
 	unsigned long long  timeout;       // wall_clock64 ticks (100 MHz) the tail block waits for ONE word before it gives up (HP_TAIL_TIMEOUT_MS)
 	int                 fresh;     // advance_time's `fresh`
@@ -298,10 +302,11 @@ template <typename T> struct LaunchTail {
 #define HP_TAIL_FORMAL_ORDER 0
 #endif
 // every wavefront of every flux block, at its very end; `m` = the wavefront's maximum (0 when this launch prices nothing)
-template <typename T>
-__device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const T m, const int wave, const int lane, const long y0, const long y1)
+template <bool TWO = false, typename T>
+__device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const T m, const int wave, const int lane, const long y0, const long y1, const T m1 = T(0))
 {
 	__shared__ T part[4];
+	__shared__ T part1[4];
 	// a tile that stored rows into a neighbour reports only once those stores have been acknowledged (its own state's stores
 	// need no such wait: nobody reads them before the next launch); all the other tiles report at once
 	const bool sends = (y0 < tail.edge_rows[1] && y1 > tail.edge_rows[0]) || (y0 < tail.edge_rows[3] && y1 > tail.edge_rows[2]);   // wave-uniform
@@ -317,7 +322,7 @@ __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const
 	// + acknowledged-store form stays the default: it orders exactly the stores that cross to the neighbour and nothing else
 	// (30 000-iteration soaks, the strip fuzz and the process-rank tests all run on it).
 	if (sends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	if (lane == 0) part[wave] = m;
+	if (lane == 0) { part[wave] = m; if (TWO) part1[wave] = m1; }
 	__syncthreads();
 	bool block_sends = false;
 	if (threadIdx.x == 0) {
@@ -325,6 +330,11 @@ __device__ __forceinline__ void tail_block_done(const LaunchTail<T>& tail, const
 		block_sends = sends;
 		T b = part[0];
 		for (int w = 1; w < 4; ++w) if (part[w] > b) b = part[w];
+		if (TWO) {                                               // (a word of its own with its own "arrived": no order between the two stores is needed)
+			T b1 = part1[0];
+			for (int w = 1; w < 4; ++w) if (part1[w] > b1) b1 = part1[w];
+			__hip_atomic_store(tail.done1 + blockIdx.x, peer_bits(b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 #if HP_TAIL_FORMAL_ORDER
 		if (block_sends) __hip_atomic_store(tail.done + blockIdx.x, peer_bits(b), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		else
@@ -354,24 +364,29 @@ __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail
 	if (threadIdx.x == 0) { failed_before = atomic_peek(tail.slot + SLOT_TAIL_ERR) != T(0); late_any = 0; }   // an earlier launch of this domain gave up
 	__syncthreads();
 	if (failed_before) return;
-	T m = T(0);
+	T m = T(0), m1 = T(0);
 	bool late = false;
-	for (unsigned i = threadIdx.x; i < tail.poll_blocks; i += blockDim.x) {
-		unsigned long long w = __hip_atomic_load(tail.done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (w == PEER_EMPTY) {
-			const unsigned long long t0 = wall_clock64();
-			for (;;) {
-				__builtin_amdgcn_s_sleep(HP_TAIL_POLL_SLEEP);
-				w = __hip_atomic_load(tail.done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (w != PEER_EMPTY) break;
-				if (wall_clock64() - t0 > tail.timeout) { late = true; break; }
+	// (pair == 2: every flux block reports TWO maxima, each in a word of its own -- the second array is polled the same way)
+	for (int set = 0; set < (tail.pair == 2 ? 2 : 1) && !late; ++set) {
+		unsigned long long* const words = set ? tail.done1 : tail.done;
+		const unsigned count = set ? tail.flux_blocks : tail.poll_blocks;
+		for (unsigned i = threadIdx.x; i < count; i += blockDim.x) {
+			unsigned long long w = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (w == PEER_EMPTY) {
+				const unsigned long long t0 = wall_clock64();
+				for (;;) {
+					__builtin_amdgcn_s_sleep(HP_TAIL_POLL_SLEEP);
+					w = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (w != PEER_EMPTY) break;
+					if (wall_clock64() - t0 > tail.timeout) { late = true; break; }
+				}
+				if (late) break;
 			}
-			if (late) break;
+			__hip_atomic_store(words + i, PEER_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			T v;
+			peer_value(w, v);
+			if (set) { if (v > m1) m1 = v; } else { if (v > m) m = v; }
 		}
-		__hip_atomic_store(tail.done + i, PEER_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		T v;
-		peer_value(w, v);
-		if (v > m) m = v;
 	}
 	if (late) late_any = 1;                                     // (benign race: every writer writes 1)
 	__syncthreads();
@@ -385,12 +400,15 @@ __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail
 	if (tail.peer_rows[0] || tail.peer_rows[1]) __atomic_thread_fence(__ATOMIC_ACQUIRE);
 #endif
 	m = wave_max(m);
+	__shared__ T part1[4];
+	if (tail.pair == 2) { m1 = wave_max(m1); if ((threadIdx.x & 63) == 0) part1[threadIdx.x >> 6] = m1; }
 	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		for (int w = 1; w < 4; ++w) if (part[w] > m) m = part[w];
 		if (tail.fresh & 1) tail.slot[0] = m;                   // where the atomic maxima of a classic launch would have gathered
 		part[0] = m;
+		if (tail.pair == 2) for (int w = 1; w < 4; ++w) if (part1[w] > m1) m1 = part1[w];
 	}
 	__syncthreads();                                            // (part[0] for wave 0)
 	if (threadIdx.x >= 64) return;
@@ -400,8 +418,18 @@ __device__ __forceinline__ void launch_tail(const Params<T>& p, const LaunchTail
 		if (threadIdx.x == 0 && (tail.fresh & 2)) tail.slot[SLOT_GLOBAL] = all;
 	}
 	if (threadIdx.x != 0) return;
-	if (tail.pair) advance_body<false>(p, tail.sc, tail.slot, 0);      // the pair's first iteration: its reduction re-read the primary buffer (fresh == 0)
+	if (tail.pair == 2) {
+		// area boundaries: the first iteration's reduction priced the primary buffer with ITS rain in it -- the maximum the launch
+		// before left in slot[SLOT_M1] (every wavefront of this launch has taken the second timestep from it: godunov_march2)
+		Scalars<T> s = *tail.sc;
+		advance_scalars(p, s, tail.slot[SLOT_M1]);
+		*tail.sc = s;
+	} else if (tail.pair) advance_body<false>(p, tail.sc, tail.slot, 0);      // the pair's first iteration: its reduction re-read the primary buffer (fresh == 0)
 	advance_body<false>(p, tail.sc, tail.slot, tail.fresh & 3);
+	if (tail.pair == 2) {
+		tail.slot[SLOT_M1] = m1;                                 // what the NEXT pair's first advance will be told
+		tail.slot[SLOT_BDY] = tail.bdy_flag ? T(1) : T(0);       // (for the stand-alone boundary pass of a single iteration that may follow)
+	}
 }
 
 // diagnostic / connection test: one reduction of a caller-given word (hp_strip_peer_round)
@@ -661,11 +689,34 @@ template <typename T> struct AreaBdyList { int count; AreaBdy<T> b[AREA_BDY_MAX]
 // What the fused epilogue of K1 carries per area boundary: the level increment of the tile's lower / upper rain-grid row
 // (a uniform boundary has one value for both), the first row of the upper one, and how it is applied.
 constexpr int FUSED_BDY_MAX = 3;
-constexpr int SLOT_BDY = 96;            // cfl_slot[SLOT_BDY] != 0: the next iteration's area boundaries are already in its source buffer
 template <typename T> struct FusedBdy {
 	T    inc_lo, inc_hi;                // per lane: metres added per application (uniform loss: metres removed)
 	int  y_switch;                      // local row from which inc_hi applies
 	int  mode;                          // -1 inactive, 0 add (uniform rain), 1 loss (floor at the bed), 2 add with the gridded kernel's extra null test
+};
+
+// What an iteration pair needs besides K1's arguments (round 6).
+//  * Quirk Q3, exactly.  A cell the reference leaves untouched at the pair's FIRST step keeps what its destination buffer held: the
+//    state of the iteration before the pair, with that iteration's boundaries -- a value that, when pairs follow each other, never
+//    left the registers of the launch before.  That launch therefore writes it down where it could matter: a cell that may be dry at
+//    the next step (only a dry cell can be left untouched) and whose first-step value differs from what the next launch will read
+//    for it goes into z_state, stamped with the launch's number in z_gen; the launch's word haz[gen & 1] is set to gen.  A launch whose
+//    source was written by pair launch `prev_gen` looks a first-step-untouched cell up (only if haz[prev_gen & 1] == prev_gen, i.e.
+//    hardly ever) and takes the stamped value instead of the cell's current one -- which is what it takes, exactly, for every other
+//    cell.  (Round 5 took the current value everywhere and had 881 181 probe cells to show for it)  The first single
+//    iteration behind pairs (K1's FILL flag) reads the same stamps.
+//  * Area boundaries (BDY).  See the kernel's header.
+// (the three buffers' addresses never change once allocated and are needed on cold paths only: they live in device memory behind ONE
+// pointer, so that the kernels -- whose register budgets have no slack: godunov_march2 runs at 168 VGPRs and 106 SGPRs with spills --
+// keep two scalar registers alive for them instead of six)
+template <typename T> struct StampBufs { State4<T>* z_state; unsigned* z_gen; unsigned long long* haz; };
+template <typename T> struct PairAux {
+	const StampBufs<T>*   stamps;      // nullptr: no stamps (nothing to look up, nothing written down)
+	unsigned              gen, prev_gen;
+	const AreaBdyList<T>* list;        // (BDY) the domain's area boundaries, as K1's fused epilogue gets them
+	int                   fuse_next;   // (BDY) another iteration of the same batch follows the pair: store the state with ITS boundaries applied
+	int                   in_place;    // (BDY) the first iteration's boundaries are in the source buffer already (the launch before stored them / the stand-alone pass ran)
+	int                   truncated;   // HP_QUIRK_BDY_TRUNCATED
 };
 
 // FUSED (round 3): the instantiation a domain with fusable area boundaries runs.  The reference applies rain / loss IN PLACE
@@ -710,7 +761,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
                                                      const TileMap tm, const AreaBdyList<T>* __restrict__ fused_list,
-                                                     const int fuse_next, const int flags, const LaunchTail<T> tail)
+                                                     const int fuse_next, const int flags, const LaunchTail<T> tail, const PairAux<T> aux)
 {
 	if (TAIL != 0 && blockIdx.x >= tail.flux_blocks) {                             // the launch's own tail (LaunchTail above)
 		launch_tail(p, tail);
@@ -739,6 +790,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 	// run_pair) -- the cells the reference leaves untouched (Q3) are stored too, with the value the host's repair copy would have put
 	// there, the source's
 	const bool fill = (flags & 2) != 0;
+	// ... except where the pair launch that wrote `src` stamped the cell (PairAux: the value the reference's buffer would hold there is
+	// not the source's): looked up only if that launch raised its word at all
+	const bool hz_any = fill && aux.stamps != nullptr && aux.prev_gen != 0 && aux.stamps->haz[aux.prev_gen & 1u] == (unsigned long long)aux.prev_gen;
+	auto fill_value = [&](State4<T> v, const long y, const bool want) {
+		if (wave_any(want)) {
+			asm volatile("");
+			if (want) {
+				const size_t id = (size_t)y * p.cols + xc;
+				if (aux.stamps->z_gen[id] == aux.prev_gen) v = aux.stamps->z_state[id];
+			}
+		}
+		return v;
+	};
 
 	// ---- fused area boundaries of the NEXT iteration (see above) ----
 	FusedBdy<T> fb[FUSED_BDY_MAX];
@@ -993,6 +1057,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 					out = upd;
 				}
 			}
+			if (hz_any) out = fill_value(out, y, dry5 && !disabled && out_x);       // (FILL: wave-uniform)
 			fS = fy.forR;
 			dryS = dryC;
 		}
@@ -1043,9 +1108,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 			if (out_x && !disabled) stale_rows |= 1ull << (unsigned)(y - y0);
 			const Side<T> sN = make_side_impl<STRICT, PL>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs, spec_bad);
 			fS = face_dry_for_right<AXIS_Y, STRICT>(sC, sN, vs);
-			// (FUSED: the only cells this loop stores are nulls, which no boundary kernel touches)
-			buf_store_state(rc.c, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
-			if (TAIL == 2) store_peer(rc.c, y, write);
+			// (FUSED: the only cells this loop stores are nulls, which no boundary kernel touches -- and, with FILL, the dry cells, which
+			// the cold pass below stores again with their rain)
+			State4<T> kept = rc.c;
+			if (hz_any) kept = fill_value(kept, y, out_x && !disabled);
+			buf_store_state(kept, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+			if (TAIL == 2) store_peer(kept, y, write);
 			if (!((int)y >= tm.price_lo && (int)y < tm.price_hi)) {
 			} else if (CFL_MODE == 1) {
 				if (write) {
@@ -1076,7 +1144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 		for (long y = y0; y < y1; ++y) {
 			if ((stale_rows >> (unsigned)(y - y0)) & 1ull) {
 				const size_t id = (size_t)y * p.cols + xc;
-				const State4<T> c = fill ? src[id] : dst[id];
+				State4<T> c = fill ? src[id] : dst[id];
+				if (hz_any && aux.stamps->z_gen[id] == aux.prev_gen) c = aux.stamps->z_state[id];
 				const T zb = bed[id];
 				if (CFL_MODE == 1 && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 					const T s = cfl_speed_impl<STRICT, PL>(c.z, c.zmax, c.qx, c.qy, zb, p.qs, false, spec_bad);
@@ -1129,26 +1198,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 //  the buffer that holds the newest state, as after two single iterations.
 // -------------------------------------------------------------------------------------------------
 constexpr int MARCH2_COLS = 60;          // updated columns per wavefront (lanes 2..61)
-template <typename T> struct RowU1 { State4<T> c; T zb; };
+template <typename T> struct RowU1 { State4<T> c; T zb; bool plain; };      // plain: c IS the cell's source value, bit for bit (nothing touched it at the first step)
 
-template <int CFL_MODE, int TAIL, typename T>                      // CFL_MODE 1: price what the pair leaves in the primary buffer; 0: fixed timestep
+template <bool STRICT, int CFL_MODE, bool BDY, int TAIL, typename T>   // CFL_MODE 1: price what the pair leaves in the primary buffer; 0: fixed timestep
 // (three waves per SIMD: 167 VGPRs and four spilled registers measured 0.193 ms per iteration at 4096^2 against 0.215 at two waves
 // and 171 registers without spills -- profiles/r05n_two_step.txt; -DHP_K1B_WAVES_MIN=2 builds the other one)
 #ifndef HP_K1B_WAVES_MIN
 #define HP_K1B_WAVES_MIN 3
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 4 : HP_K1B_WAVES_MIN, sizeof(T) == 4 ? 5 : 3))) void godunov_march2(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 4 : (STRICT ? 2 : HP_K1B_WAVES_MIN), sizeof(T) == 4 ? 5 : (STRICT ? 2 : 3)))) void godunov_march2(
 	const Params<T> p, const Scalars<T>* sc, const T* __restrict__ bed, const State4<T>* __restrict__ src,
 	State4<T>* __restrict__ dst, const T* __restrict__ manning, T* cfl_slot, const T* __restrict__ edge_max,
-	const TileMap tm, const LaunchTail<T> tail)
+	const TileMap tm, const LaunchTail<T> tail, const PairAux<T> aux)
 {
 	if (TAIL != 0 && blockIdx.x >= tail.flux_blocks) {
 		launch_tail(p, tail);
 		return;
 	}
+	// (BDY) increments of the three boundary applications a pair can meet -- [0] the first iteration's, on the source rows as they are
+	// loaded (only when they are not in the buffer yet: the first pair of a batch), [1] the second iteration's, on the intermediate
+	// state in registers, [2] the iteration's after the pair, on the state as it is stored -- per boundary, for the tile's lower / upper
+	// rain-grid row, per lane.  They wait in LDS (one read per row and application) instead of eighteen registers.
+	__shared__ T inc_tab[BDY ? 4 * 3 * FUSED_BDY_MAX * 2 * 64 : 1];
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	long strip, y0, y1;                                                            // rows [y0, y1) receive state k + 2
-	T wave_vmax = T(0);
+	T wave_vmax = T(0), wave_vmax1 = T(0);
 	if (tile_rows(tm, wave, strip, y0, y1)) {
 
 	const long x = strip * MARCH2_COLS - 1 + lane;                                 // lane 2 is the strip's first updated column
@@ -1157,11 +1231,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	const bool ring_x = x <= 0 || x >= p.cols - 1;                                 // an edge-ring column (or a lane beyond the grid): never updated
 	const T vs = p.vs;
 	const bool with_friction = p.friction != 0;
+	const T inv_dx = STRICT ? p.inv_dx_pow2 : p.inv_dx;
 
-	// the two timesteps: this iteration's, and the next one's as tst_Advance_Normal will leave it (see above)
+	// the two timesteps: this iteration's, and the next one's as tst_Advance_Normal will leave it (see above).  With area boundaries
+	// the first iteration's reduction prices the primary buffer with that iteration's rain in it: slot[SLOT_M1], left by the launch before
 	Scalars<T> s1 = *sc;
+	const Scalars<T> s0 = s1;
 	const T dt_a = s1.dt;
-	advance_scalars(p, s1, p.dynamic_dt ? cfl_slot[SLOT_SAVED] : T(0));
+	advance_scalars(p, s1, p.dynamic_dt ? cfl_slot[BDY ? SLOT_M1 : SLOT_SAVED] : T(0));
 	const T dt_b = s1.dt;
 	const bool skip_a = dt_a <= T(0), skip_b = dt_b <= T(0);                       // CLSchemeGodunov.clc:201-206: the state is copied
 
@@ -1197,7 +1274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		r.n = p.manning_uniform ? p.manning_value : buf_load_scalar(srd_man, vc_, k * row_scalar, T());
 		return r;
 	};
-	constexpr bool LAZY_DRY = sizeof(T) == 8;                                      // (K1's row step: the dry tests only where a face is not wet throughout)
+	constexpr bool LAZY_DRY = !STRICT && sizeof(T) == 8;                           // (K1's row step: the dry tests only where a face is not wet throughout)
 	// west flux of a cell = what the lane to its west found for its east face (as in K1)
 	auto flux_from_west = [&](const FaceFlux<T>& forW, const bool dryC, bool& dryW) {
 		FaceFlux<T> fW;
@@ -1209,6 +1286,129 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		return fW;
 	};
 
+	// ---- quirk Q3 at the first step: the stamps of the launch that wrote `src` (PairAux) ----
+#ifndef HP_PAIR_STAMPS_BUILD
+#define HP_PAIR_STAMPS_BUILD 1          // 0: the kernel of round 5 -- no stamps compiled in (A/B builds: what the bookkeeping costs the march)
+#endif
+	const bool hz_on = HP_PAIR_STAMPS_BUILD != 0 && aux.stamps != nullptr;
+	const bool hz_any = hz_on && aux.prev_gen != 0 && aux.stamps->haz[aux.prev_gen & 1u] == (unsigned long long)aux.prev_gen;     // wave-uniform (scalar loads)
+	// (the first-step value of the row stage B works on waits in LDS for the rare lane that has to write it down: held in registers
+	// it would cost the march eight of them from one end of the row step to the other)
+	__shared__ T park_tab[4 * 4 * 64];
+	T* const park = park_tab + wave * (4 * 64) + lane;
+	bool stamped = false;                                                          // this wavefront wrote a stamp (its launch's word is raised at the end)
+
+	// ---- (BDY) which of the three applications are live in THIS launch: scalar arithmetic on the time-control block ----
+	unsigned act = 0;                       // bit j: application j has at least one boundary that acts
+	unsigned modes = 0x3ffffu;              // 2 bits per (j, k): 0 add (uniform rain), 1 loss (floor at the bed), 2 add with the gridded kernel's null test, 3 inactive
+	int ysw[FUSED_BDY_MAX] = {0, 0, 0};     // per boundary: the tile row from which the upper rain-grid row's increment applies
+	bool bdy_x = false;
+	long gy_lim = 0;
+	const bool truncated = BDY && aux.truncated != 0;
+	T* const tab = inc_tab + (BDY ? wave * (3 * FUSED_BDY_MAX * 2 * 64) : 0);
+	if (BDY) {
+		// time, hydrological time and the sign of the timestep as the boundary kernels of iterations k, k + 1, k + 2 see them
+		// (tst_Advance_Normal, CLDynamicTimestep.clc:42-66; the sign of dt(k + 2) is decided by the sync point and the end time
+		// alone, whatever this launch's maximum turns out to be: :112-137 -- K1's fused epilogue rests on the same fact)
+		const T dtn = fmax_(T(0), s1.dt);
+		const T t2 = s1.t + dtn;
+		const T th2 = (s1.t_hydro > T(1.0)) ? dtn : (s1.t_hydro + dtn);
+		const bool pos2 = (s1.t_sync - t2 > p.vs) && (t2 < p.t_end) && (p.dynamic_dt || p.dt_fixed > T(0));
+		const T tj[3] = {s0.t, s1.t, t2}, thj[3] = {s0.t_hydro, s1.t_hydro, th2};
+		const bool posj[3] = {s0.dt > T(0), s1.dt > T(0), pos2};
+		bdy_x = x >= 1 && x <= p.cols - 2 && (!truncated || x < (p.cols / 8) * 8);     // bdy_in_range, column part
+		gy_lim = truncated ? (p.global_rows / 8) * 8 : p.global_rows;
+		const int nb = aux.list->count;
+		const long n_rows = ((y1 + 1 < last_row ? y1 + 1 : last_row) - row_base) + 1;   // rows the wavefront touches (<= 36)
+		#pragma unroll
+		for (int j = 0; j < 3; ++j) {
+			if (j == 0 && aux.in_place) continue;                                     // in the buffer already
+			if (!(thj[j] >= T(1.0))) continue;                                        // the hydrological gate (CLBoundaries.clc:165, :224)
+			#pragma unroll
+			for (int k = 0; k < FUSED_BDY_MAX; ++k) {
+				if (k >= nb) continue;
+				const AreaBdy<T>& b = aux.list->b[k];
+				T inc_lo = T(0), inc_hi = T(0);
+				unsigned mode = 3u;
+				if (b.kind == 0) {
+					if (!posj[j] || tj[j] >= b.u.length) continue;                    // :165-168
+					unsigned long ts = (unsigned long)floor_(tj[j] / b.u.interval);   // :172-173
+					if (ts >= b.u.entries) ts = b.u.entries - 1;
+					inc_lo = inc_hi = b.u.series[2 * ts + 1] / T(3600000.0) * thj[j];
+					mode = b.u.definition == 1 ? 1u : (b.u.definition == 0 ? 0u : 3u);
+				} else {
+					if (b.g.definition != 0 && b.g.definition != 2) continue;         // accumulated depths: nothing is applied (:238-242)
+					unsigned long ts = (unsigned long)floor_(tj[j] / b.g.interval);   // :228
+					if (ts >= b.g.entries) ts = b.g.entries - 1;
+					// this lane's rain-grid column, and the rain-grid row of window row row_base + lane (K1's fused set-up: the host
+					// only fuses grids whose cells are at least 64 model cells wide and high, so a wavefront's rows meet at most two
+					// grid rows and its columns two grid columns)
+					T colf = floor_((((T)xc * p.dx) - b.g.off_x) / b.g.resolution);   // :231
+					if (colf < T(0)) colf = T(0);
+					const long gy_l = row_base + lane + p.row_offset;
+					const T rowf = floor_((((T)gy_l * p.dx) - b.g.off_y) / b.g.resolution);   // :232
+					const unsigned long col = (unsigned long)colf;
+					const unsigned long c0 = (unsigned long)__builtin_amdgcn_readfirstlane((int)col);
+					const unsigned long c1 = (c0 + 1 < b.g.gcols) ? c0 + 1 : c0;
+					const long row_l = (long)rowf;
+					const long r_lo = (long)__builtin_amdgcn_readfirstlane((int)row_l);
+					const unsigned long long in_lo = __ballot(lane < n_rows && row_l == r_lo);
+					const long n_lo = (long)__popcll(in_lo);
+					const long r_hi = (n_lo < n_rows) ? r_lo + 1 : r_lo;
+					const unsigned long base = (b.g.grows * b.g.gcols) * ts;
+					const unsigned long rl = (unsigned long)(r_lo < 0 ? 0 : r_lo), rh = (unsigned long)(r_hi < 0 ? 0 : ((unsigned long)r_hi < b.g.grows ? r_hi : (long)b.g.grows - 1));
+					const T g00 = b.g.grids[base + b.g.gcols * rl + c0], g01 = b.g.grids[base + b.g.gcols * rl + c1];
+					const T g10 = b.g.grids[base + b.g.gcols * rh + c0], g11 = b.g.grids[base + b.g.gcols * rh + c1];
+					const T rate_lo = (col == c0) ? g00 : g01, rate_hi = (col == c0) ? g10 : g11;
+					if (b.g.definition == 0) {                                        // :238-239
+						inc_lo = rate_lo / T(3600000.0) * thj[j];
+						inc_hi = rate_hi / T(3600000.0) * thj[j];
+					} else {                                                          // :241-242
+						inc_lo = rate_lo / (p.dx * p.dx) * thj[j];
+						inc_hi = rate_hi / (p.dx * p.dx) * thj[j];
+					}
+					ysw[k] = (int)(row_base + n_lo);
+					mode = 2u;
+				}
+				if (mode == 3u) continue;
+				tab[((j * FUSED_BDY_MAX + k) * 2 + 0) * 64 + lane] = inc_lo;
+				tab[((j * FUSED_BDY_MAX + k) * 2 + 1) * 64 + lane] = inc_hi;
+				modes = (modes & ~(3u << (2 * (j * FUSED_BDY_MAX + k)))) | (mode << (2 * (j * FUSED_BDY_MAX + k)));
+				act |= 1u << j;
+			}
+		}
+	}
+	const bool fuse = BDY && aux.fuse_next != 0;           // the state is stored with application [2] in it
+
+	T vmax = T(0), vmax1 = T(0);
+	unsigned stale_rows = 0;                                                       // bit i: row y0 + i of this lane keeps state k (quirk Q3 at the second step); tiles are at most 32 rows
+
+	// The march, in two builds of the same statements: LIVE carries the boundary applications (a launch in which the hydrological
+	// gate opens at one of its three moments), !LIVE is the kernel as it is without boundaries -- which is what a BDY launch runs on
+	// all the iterations in between (the gate opens once per second of model time).
+	auto march = [&](auto live_tag) {
+	constexpr bool LIVE = decltype(live_tag)::value;
+	// one cell's share of application J, in the order the boundaries were added: the statements of bdy_area
+	auto apply = [&](auto j_tag, State4<T> c, const T zb, const long y) {
+		constexpr int J = decltype(j_tag)::value;
+		if (!LIVE || !((act >> J) & 1u)) return c;                                 // wave-uniform
+		const long gy = y + p.row_offset;
+		if (!(gy >= 1 && gy <= p.global_rows - 2 && gy < gy_lim)) return c;       // bdy_in_range, row part (wave-uniform)
+		const bool cell_ok = bdy_x && !(c.zmax <= T(-9999.0));                    // :168-169, :220-221 (first half)
+		#pragma unroll
+		for (int k = 0; k < FUSED_BDY_MAX; ++k) {
+			const unsigned m = (modes >> (2 * (J * FUSED_BDY_MAX + k))) & 3u;
+			if (m == 3u) continue;                                                // wave-uniform
+			const T inc = tab[((J * FUSED_BDY_MAX + k) * 2 + ((int)y >= ysw[k] ? 1 : 0)) * 64 + lane];
+			const T z2 = (m == 1u) ? fmax_(zb, c.z - inc) : (c.z + inc);          // :179-180 | :176-177, :238-242
+			const bool ok = cell_ok && !(m == 2u && c.z == T(-9999.0));           // :220-221 (second half; re-tested as the level changes)
+			c.z = ok ? z2 : c.z;
+		}
+		return c;
+	};
+	using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
+	const bool live0 = LIVE && (act & 1u) != 0, live1 = LIVE && (act & 2u) != 0, live2 = LIVE && (act & 4u) != 0;
+
 	// ---- stage A: source row r -> U1(r), K1's row step with the result kept in registers ----
 	RowRegs<T> rc = load_row(y0 - 1);                                              // the first row stage A produces
 	RowRegs<T> rP = load_row(y0), rQ;
@@ -1216,20 +1416,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	FaceFlux<T> fSa = {};
 	bool drySa;
 	{
-		const RowRegs<T> rs = load_row(y0 - 2);
-		const Side<T> sS = make_side<false>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
-		sCa = make_side<false>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
+		RowRegs<T> rs = load_row(y0 - 2);
+		if (live0) { rs.c = apply(J0(), rs.c, rs.zb, y0 - 2 < 0 ? 0 : y0 - 2); rc.c = apply(J0(), rc.c, rc.zb, y0 - 1); }
+		const Side<T> sS = make_side<STRICT>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
+		sCa = make_side<STRICT>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
 		drySa = (rs.c.z - rs.zb) < vs;
-		if (!skip_a) fSa = face_solve_fast<AXIS_Y>(sS, sCa, vs).forR;
+		if (!skip_a) fSa = face_solve<AXIS_Y, STRICT, true, true>(sS, sCa, vs).forR;
 	}
-	auto stage_a = [&](const long r, const RowRegs<T>& rn, RowRegs<T>& pre) {
+	auto stage_a = [&](const long r, const RowRegs<T>& rn_in, RowRegs<T>& pre) {
 		pre = load_row(r + 2, r + 2 <= y1 + 1);                                   // nothing beyond the row north of the tile's halo row
-		RowU1<T> u; u.c = rc.c; u.zb = rc.zb;
+		RowRegs<T> rn = rn_in;
+		if (live0) rn.c = apply(J0(), rn.c, rn.zb, r + 1 > last_row ? last_row : r + 1);   // (the row enters the march here: boundaries first, CSchemeGodunov.cpp:1638)
+		RowU1<T> u; u.c = rc.c; u.zb = rc.zb; u.plain = true;
 		Side<T> sN = sCa;
 		if (!skip_a) {
 			const bool ring_row = r <= 0 || r >= last_row;                         // wave-uniform: passes through, but its north face is needed
-			sN = make_side<false>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
-			const FacePair<T> fy = face_solve_fast<AXIS_Y>(sCa, sN, vs);
+			sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
+			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sCa, sN, vs);
 			// (a face whose lanes all have water on both sides lies between wet cells: K1's row step)
 			bool dryC = false, dryN = false;
 			if (!LAZY_DRY || !fy.wet) {
@@ -1239,7 +1442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 			}
 			if (!ring_row) {
 				const Side<T> sE = side_from_east(sCa);
-				const FacePair<T> fx = face_solve_fast<AXIS_X>(sCa, sE, vs);
+				const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sCa, sE, vs);
 				bool dryW;
 				const FaceFlux<T> fW = flux_from_west(fx.forR, dryC, dryW);
 				bool dryE = false;
@@ -1248,12 +1451,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 					dryE = (sE.eta - sE.zb) < vs;
 				}
 				const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0); // :214-218
-				const bool dry5 = dryC && dryN && dryE && drySa && dryW;               // :248-255 (untouched: see the header)
-				const State4<T> upd = godunov_update<false>(rc.c, rc.zb, rc.n, dt_a, fy.forL, fx.forL, fSa, fW, p.dx, p.inv_dx, vs, with_friction);
-				if (!(ring_x || disabled || dry5)) u.c = upd;
+				const bool dry5 = dryC && dryN && dryE && drySa && dryW;               // :248-255 (untouched: see PairAux)
+				const State4<T> upd = godunov_update<STRICT>(rc.c, rc.zb, rc.n, dt_a, fy.forL, fx.forL, fSa, fW, p.dx, inv_dx, vs, with_friction);
+				const bool touched = !(ring_x || disabled || dry5);
+				if (touched) { u.c = upd; u.plain = false; }
+				// untouched by the reference (Q3): its destination keeps the state of the iteration before the pair.  That is the cell's
+				// current state -- unless the launch before said otherwise
+				if (hz_any && wave_any(dry5 && !ring_x && !disabled)) {
+					if (dry5 && !ring_x && !disabled) {
+						const size_t id = (size_t)r * p.cols + xc;
+						if (aux.stamps->z_gen[id] == aux.prev_gen) { u.c = aux.stamps->z_state[id]; u.plain = false; }
+					}
+				}
 			}
 			fSa = fy.forR;
 			drySa = dryC;
+		}
+		if (live1) {                                                               // the second iteration's boundaries, on its source state
+			const T z_in = u.c.z;
+			u.c = apply(J1(), u.c, u.zb, r);
+			u.plain = u.plain && u.c.z == z_in;
 		}
 		rc = rn;
 		sCa = sN;
@@ -1266,14 +1483,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	Side<T> sCb;
 	FaceFlux<T> fSb = {};
 	bool drySb = false;
-	T vmax = T(0);
-	unsigned stale_rows = 0;                                                       // bit i: row y0 + i of this lane keeps state k (quirk Q3 at the second step); tiles are at most 32 rows
 	auto stage_b = [&](const long y, const RowU1<T>& un, const T n_next, const bool update) {
-		const Side<T> sN = make_side<false>(un.c.z, un.c.qx, un.c.qy, un.zb, vs);
+		const Side<T> sN = make_side<STRICT>(un.c.z, un.c.qx, un.c.qy, un.zb, vs);
 		State4<T> out = uc.c;
 		bool write = out_x;
+		bool untouched = false;                                                    // left alone by the second step (Q3): the primary buffer keeps state k
+		if (hz_on && update) { park[0] = uc.c.z; park[64] = uc.c.zmax; park[128] = uc.c.qx; park[192] = uc.c.qy; }
 		if (!skip_b) {
-			const FacePair<T> fy = face_solve_fast<AXIS_Y>(sCb, sN, vs);
+			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sCb, sN, vs);
 			bool dryC = false, dryN = false;
 			if (!LAZY_DRY || !fy.wet) {
 				asm volatile("");
@@ -1282,7 +1499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 			}
 			if (update) {
 				const Side<T> sE = side_from_east(sCb);
-				const FacePair<T> fx = face_solve_fast<AXIS_X>(sCb, sE, vs);
+				const FacePair<T> fx = face_solve<AXIS_X, STRICT, true, true>(sCb, sE, vs);
 				bool dryW;
 				const FaceFlux<T> fW = flux_from_west(fx.forR, dryC, dryW);
 				bool dryE = false;
@@ -1292,10 +1509,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 				}
 				const bool disabled = uc.c.zmax <= T(-9999.0) || uc.c.z == T(-9999.0);
 				const bool dry5 = dryC && dryN && dryE && drySb && dryW;
-				const State4<T> upd = godunov_update<false>(uc.c, uc.zb, n_c, dt_b, fy.forL, fx.forL, fSb, fW, p.dx, p.inv_dx, vs, with_friction);
+				const State4<T> upd = godunov_update<STRICT>(uc.c, uc.zb, n_c, dt_b, fy.forL, fx.forL, fSb, fW, p.dx, inv_dx, vs, with_friction);
 				if (!disabled) {
 					if (dry5) {                                                        // the primary buffer keeps state k: copied in the cold pass below
 						write = false;
+						untouched = out_x;
 						if (out_x) stale_rows |= 1u << (unsigned)(y - y0);
 					} else {
 						out = upd;
@@ -1306,11 +1524,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 			drySb = dryC;
 		}
 		if (update) {
-			buf_store_state(out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - row_base) * row_state);
-			if (TAIL == 2) store_peer(out, y, write);
+			// what the NEXT launch will read for this cell: the state with the boundaries of the iteration after the pair (stored like
+			// that if another iteration of the batch follows; applied by the next launch as it loads the row otherwise)
+			State4<T> next = out;
+			if (live2) next = apply(J2(), out, uc.zb, y);
+			// Q3 for the launch that follows (PairAux): the first-step value uc.c is written down where that launch could need it and
+			// cannot have it -- a cell that may be dry at its first step and whose value there differs from uc.c.  Cells the second step
+			// left alone hold state k: equal to uc.c if nothing touched them at the first step either (`plain`), unknown here otherwise.
+			if (hz_on) {
+				const bool dry_next = (next.z - uc.zb) < vs || (LIVE && !fuse && (out.z - uc.zb) < vs);
+				bool stamp = write && dry_next;
+				stamp = stamp || (untouched && (!uc.plain || (live2 && next.z != out.z && (next.z - uc.zb) < vs)));
+				if (wave_any(stamp)) {
+					asm volatile("");
+					State4<T> first; first.z = park[0]; first.zmax = park[64]; first.qx = park[128]; first.qy = park[192];      // = uc.c
+					const bool differs = untouched || first.z != next.z || first.qx != next.qx || first.qy != next.qy || first.zmax != next.zmax ||
+					                     (LIVE && !fuse && first.z != out.z);
+					stamp = stamp && differs;
+					if (wave_any(stamp)) {
+						if (stamp) {
+							const size_t id = (size_t)y * p.cols + xc;
+							aux.stamps->z_state[id] = first;
+							aux.stamps->z_gen[id] = aux.gen;
+						}
+						stamped = true;
+					}
+				}
+			}
+			buf_store_state(fuse ? next : out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - row_base) * row_state);
+			if (TAIL == 2) store_peer(fuse ? next : out, y, write);
 			if (CFL_MODE == 1 && write && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
-				const T s = cfl_speed<false>(out.z, out.zmax, out.qx, out.qy, uc.zb, p.qs);
+				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, uc.zb, p.qs);
 				if (s > vmax) vmax = s;
+				if (live2) {                                                           // ... and what the next iteration's reduction will find (slot[SLOT_M1])
+					const T s2 = cfl_speed<STRICT>(next.z, next.zmax, next.qx, next.qy, uc.zb, p.qs);
+					if (s2 > vmax1) vmax1 = s2;
+				}
 			}
 		}
 		uc = un; n_c = n_next;
@@ -1322,7 +1571,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		const T n0 = rc.n;
 		uc = stage_a(y0 - 1, rP, rQ);                                              // (rc = row y0, rP -> rQ holds row y0 + 1)
 		n_c = n0;
-		sCb = make_side<false>(uc.c.z, uc.c.qx, uc.c.qy, uc.zb, vs);
+		sCb = make_side<STRICT>(uc.c.z, uc.c.qx, uc.c.qy, uc.zb, vs);
 		const T n1 = rc.n;
 		const RowU1<T> u0 = stage_a(y0, rQ, rP);
 		stage_b(y0 - 1, u0, n1, false);                                            // stage B without an update: the face below row y0 and its dry flag
@@ -1335,29 +1584,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	}
 	if (r <= y1) { const T nn = rc.n; const RowU1<T> u = stage_a(r, rP, rQ); stage_b(r - 1, u, nn, true); }
 
-	// cells the second step leaves untouched: the primary buffer keeps state k (and the reduction prices it)
+	// cells the second step leaves untouched: the primary buffer keeps state k with the first iteration's boundaries (and the
+	// reduction prices it; the next iteration's boundaries act on it in place)
 	if (wave_any(stale_rows != 0)) {
 		for (long y = y0; y < y1; ++y) {
 			if ((stale_rows >> (unsigned)(y - y0)) & 1u) {
 				const size_t id = (size_t)y * p.cols + xc;
-				const State4<T> c = src[id];
-				dst[id] = c;
-				if (TAIL == 2) store_peer(c, y, true);                          // (the neighbour's copy of the cell gets the same store)
+				const T zb = bed[id];
+				State4<T> c = src[id];
+				if (live0) c = apply(J0(), c, zb, y);
+				State4<T> next = c;
+				if (live2) next = apply(J2(), c, zb, y);
+				dst[id] = fuse ? next : c;
+				if (TAIL == 2) store_peer(fuse ? next : c, y, true);                // (the neighbour's copy of the cell gets the same store)
 				if (CFL_MODE == 1 && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
-					const T s = cfl_speed<false>(c.z, c.zmax, c.qx, c.qy, bed[id], p.qs);
+					const T s = cfl_speed<STRICT>(c.z, c.zmax, c.qx, c.qy, zb, p.qs);
 					if (s > vmax) vmax = s;
+					if (live2) {
+						const T s2 = cfl_speed<STRICT>(next.z, next.zmax, next.qx, next.qy, zb, p.qs);
+						if (s2 > vmax1) vmax1 = s2;
+					}
 				}
 			}
 		}
 	}
+	if (!live2) vmax1 = vmax;                              // nothing acts on the stored state before the next reduction: one maximum
+	};   // march
+
+	if (BDY && act != 0) march(std::true_type()); else march(std::false_type());
+
+	if (stamped && lane == 0) aux.stamps->haz[aux.gen & 1u] = (unsigned long long)aux.gen;
 	if (CFL_MODE != 0) {
-		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; }
+		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; if (e > vmax1) vmax1 = e; }
 		vmax = wave_max(vmax);
-		if (TAIL != 0) wave_vmax = vmax;
+		if (BDY) vmax1 = wave_max(vmax1);
+		if (TAIL != 0) { wave_vmax = vmax; wave_vmax1 = vmax1; }
 		else if (lane == 0 && vmax > T(0)) atomic_max_nonneg(cfl_slot, vmax);
 	}
 	}   // tile / strip guard
-	if (TAIL != 0) tail_block_done(tail, wave_vmax, wave, lane, y0, y1);
+	if (TAIL != 0) tail_block_done<BDY>(tail, wave_vmax, wave, lane, y0, y1, wave_vmax1);
+}
+
+// repair_other_buffer's second half (hp_engine.hip): after the device copy "other := current", the cells the last pair launch stamped get
+// the value the reference's other buffer holds there (PairAux) -- so that whatever builds on that buffer next finds what single iterations
+// would have left in it.
+template <typename T>
+__global__ __launch_bounds__(256) void stamps_to_buffer(State4<T>* __restrict__ other, const State4<T>* __restrict__ z_state, const unsigned* __restrict__ z_gen,
+                                                        const unsigned long long* __restrict__ haz, const unsigned gen, const size_t cells)
+{
+	if (haz[gen & 1u] != (unsigned long long)gen) return;
+	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x)
+		if (z_gen[id] == gen) other[id] = z_state[id];
+}
+
+// Cold start of iteration pairs on a domain with area boundaries (hp_engine.hip: pair_cold_start): the stand-alone boundary pass and the
+// stand-alone reduction have just done the first half of iteration k the reference's way -- boundaries in place, the primary buffer
+// priced -- and this moves the result to where the pair kernel looks for it.
+template <typename T>
+__global__ void pair_cold_start_words(T* slot)
+{
+	slot[SLOT_M1] = atomic_exchange_zero(slot);
+	slot[SLOT_BDY] = T(1);
 }
 
 // Do the edge rings of the two state buffers hold the same bits?  (hp_engine.hip: rings_really_differ.  No flux kernel writes ring cells,

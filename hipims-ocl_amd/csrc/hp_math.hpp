@@ -1074,6 +1074,8 @@ constexpr int SLOT_LOCAL = 33, SLOT_GLOBAL = 34, SLOT_HANDSHAKE = 112;
 constexpr int SLOT_SPEC = 100;
 // raised (non-zero, sticky) by a launch's tail block that gave up waiting for a flux block's word (hp_kernels.hpp: launch_tail)
 constexpr int SLOT_TAIL_ERR = 104;
+constexpr int SLOT_BDY = 96;            // cfl_slot[SLOT_BDY] != 0: the next iteration's area boundaries are already in its source buffer (K1 FUSED, pairs)
+constexpr int SLOT_M1 = 40;             // iteration pairs on domains with area boundaries: the maximum of the primary buffer WITH the next iteration's boundaries applied
 
 __device__ __forceinline__ double atomic_exchange_zero(double* slot)
 {

@@ -38,7 +38,7 @@ def check(d, precision, case, pairs_expected=True):
         assert int(d["launches"]) < 0.62 * int(d["iterations"]), (int(d["launches"]), int(d["iterations"]))   # no silent fall-back to single iterations
     rmse, mx = depth_errors(d["got"], d["want"], d["bed"])
     t_rel = abs(float(d["t"]) - float(d["t_ref"])) / float(d["t_ref"])
-    record("pairs_vs_oracle", case=case, precision=precision, rmse=rmse, max=mx, time_rel=t_rel,
+    record("pairs_vs_oracle", workload=case, precision=precision, rmse=rmse, max=mx, time_rel=t_rel,
            launches=int(d["launches"]), iterations=int(d["iterations"]))
     if precision == "f64":
         assert rmse < 1e-9 and mx < 1e-7, (rmse, mx)
@@ -67,7 +67,7 @@ def test_pair_kernel_against_the_reference_kernel_fixtures(precision, tmp_path):
         d = run(case, precision, tmp_path)
         check(d, precision, case)
         rmse, mx = depth_errors(d["got"], g[key], d["bed"])
-        record("pairs_vs_fixture_f6", case=case, precision=precision, rmse=rmse, max=mx)
+        record("pairs_vs_fixture_f6", workload=case, precision=precision, rmse=rmse, max=mx)
         t_ref = float(g[t_key]) if g[t_key].ndim == 0 else float(g[t_key].astype(np.float64).sum())
         if precision == "f64":
             assert rmse < 1e-9 and mx < 1e-7, (case, rmse, mx)

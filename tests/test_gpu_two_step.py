@@ -71,6 +71,25 @@ def test_a_boundary_added_behind_pairs(precision, tmp_path):
         assert outs["fill"]["t"] == outs[other]["t"] and outs["fill"]["dt"] == outs[other]["dt"], other
 
 
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("scenario", ["rain", "rainloss", "gridrain", "massflux", "bigdt", "drying"])
+def test_pairs_with_area_boundaries_are_the_same_computation(scenario, precision, tmp_path):
+    """Round 6: iteration pairs on domains with rain / loss (godunov_march2 BDY).  The reference applies the boundaries in place before
+    every flux kernel (CSchemeGodunov.cpp:1638; CLBoundaries.clc:130-246): the pair applies the second iteration's in registers
+    between its two steps, stores its state with the next iteration's, and prices that state both ways (the iteration that reads the
+    primary buffer prices it WITH its rain: quirk Q1).  Held to the single-iteration engine (K1 with the fused epilogue, itself held to
+    the oracle by test_gpu_fused_rain.py) bit for bit: uniform rain, rain + loss (drying: quirk Q3's stale values, the stamps), gridded
+    rain, mass flux + rain, timesteps above a second (every gate open), over odd / even batches, downloads, a sync point,
+    tst_UpdateTimestep and a checkpoint."""
+    single, pairs = run(scenario, precision, tmp_path, 0), run(scenario, precision, tmp_path, 1)
+    assert int(single["launches"]) == int(single["iterations"])
+    assert int(pairs["launches"]) < int(pairs["iterations"]) * 0.75             # (every batch of the plan starts cold or ends single)
+    assert int(pairs["iterations"]) == int(single["iterations"])
+    for key in ("t", "dt", "ok", "skipped"):
+        assert pairs[key] == single[key], key
+    assert np.array_equal(pairs["state"], single["state"])
+
+
 def test_default_takes_pairs_on_big_grids_only(tmp_path):
     out = os.path.join(str(tmp_path), "default.npz")
     env = {k: v for k, v in os.environ.items() if k != "HP_TWO_STEP"}

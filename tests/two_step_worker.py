@@ -35,6 +35,24 @@ elif scenario == "rainlater":               # pairs first, then a rain boundary 
     cols, rows = 500, 333                   # boundaries AND the FILL flag (the buffer it writes is two states old); dry land keeps untouched cells
     st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
     plan = [("run", 24), ("rain",), ("run", 9), ("run", 30), ("download",), ("run", 5)]
+elif scenario in ("rain", "rainloss", "gridrain", "bigdt", "drying", "massflux"):
+    # area boundaries under iteration pairs (round 6: godunov_march2 BDY).  Mostly dry rough terrain with pools: rain wets it, the loss
+    # rate dries it again (whole regions at once: the reference then leaves their cells untouched, quirk Q3, with STALE values in the
+    # other buffer -- what the pair kernel's stamps are for); batches of odd and even length, downloads, a sync point, a checkpoint
+    cols, rows = (520, 390) if scenario != "bigdt" else (300, 260)
+    st, bed, man = syn.s_rough(cols, rows, dtype=np.float64, manning=None)
+    st[..., 0] = np.maximum(bed, st[..., 0] - (0.6 if scenario != "drying" else 0.35)); st[..., 1] = st[..., 0]
+    if scenario != "drying":
+        st[..., 2:] = 0
+    else:                                   # thin moving films over the bumps: fronts that dry out within a step or two
+        st[..., 2:] = np.where((st[..., 0] - bed)[..., None] > 1e-3, st[..., 2:] * 0.2, 0.0)
+    st[0] = st[-1] = 0; st[:, 0] = st[:, -1] = 0
+    st, bed, man = st.astype(real), bed.astype(real), man.astype(real)
+    kw = dict(dx=2.0) if scenario != "bigdt" else dict(dx=40.0)       # dx = 40 m: timesteps of a second and more, the hydrological gate opens on EVERY iteration
+    plan = [("bdy",), ("run", 40), ("run", 7), ("download",), ("run", 64), ("run", 1), ("target", None), ("run", 90), ("update",), ("run", 33),
+            ("save",), ("run", 20), ("restore",), ("run", 20), ("download",), ("run", 31)]
+    if scenario == "bigdt":                 # (past the first minute, where tst_Advance_Normal holds the timestep at 0.1 s: CLDynamicTimestep.clc:128-129)
+        plan = [("settime", 70.0)] + plan
 else:
     raise SystemExit(scenario)
 dom = hp.Domain(cols, rows, precision=precision, math_mode=hp.MATH_FAST, **kw)
@@ -46,7 +64,27 @@ for step in plan:
     elif step[0] == "download":
         dom.download()
     elif step[0] == "target":
-        dom.set_target_time(step[1])
+        # (None: a sync point a little ahead of wherever the run is -- clipped and suspended iterations inside the next batch)
+        dom.set_target_time(step[1] if step[1] is not None else dom.read_scalars()["time"] * 1.02 + 0.5)
+    elif step[0] == "settime":
+        dom.set_time(step[1])
+    elif step[0] == "bdy":
+        rng = np.random.default_rng(3)
+        if scenario in ("rain", "rainloss", "bigdt", "drying"):
+            span = 300.0 if scenario == "bigdt" else 30.0
+            dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, np.array([[0.0, 600.0 if scenario != "drying" else 0.0], [span, 200.0], [2 * span, 0.0], [3 * span, 0.0]]), span, 3 * span)
+        if scenario in ("rainloss", "bigdt", "drying"):
+            dom.add_uniform(hp.UNIFORM_LOSS_RATE, np.array([[0.0, 900.0], [1000.0, 900.0]]), 1000.0, 1000.0)
+        if scenario in ("gridrain", "bigdt"):
+            res = 64 * kw["dx"]
+            grids = rng.uniform(0.0, 800.0, (4, rows // 64 + 2, cols // 64 + 2))
+            dom.add_gridded(hp.GRIDDED_RAIN_INTENSITY, grids, res, 0.0, 0.0, 11.0)
+        if scenario == "massflux":
+            res = 80 * kw["dx"]
+            grids = rng.uniform(0.0, 0.05, (3, rows // 80 + 2, cols // 80 + 2))
+            dom.add_gridded(hp.GRIDDED_MASS_FLUX, grids, res, 0.0, 0.0, 17.0)
+            dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, np.array([[0.0, 300.0], [50.0, 0.0]]), 50.0, 50.0)
+        assert dom.boundaries_fused()
     elif step[0] == "update":
         dom.update_timestep()
     elif step[0] == "save":
