@@ -172,8 +172,7 @@ struct hp_domain {
 	int              march2_nbands = 8;               // its row bands (one-round grids: searched)
 	bool             print_tiling = false;
 	// quirk Q3 across pair launches, exactly (hp_kernels.hpp: PairAux): stamps of the cells whose first-step stale value the next launch needs
-	void*            z_state = nullptr;               // State4<T> per cell (allocated with the first pair)
-	unsigned*        z_gen = nullptr;                 // per cell: number of the pair launch that stamped it
+	void*            z_state = nullptr;               // stamp records, one per cell: State4<T> + the number of the pair launch that wrote it (allocated with the first pair)
 	unsigned long long* haz_words = nullptr;          // two words: [g & 1] == g <=> pair launch g stamped something
 	unsigned         pair_gen = 0;                    // number of the last pair launch -- the one that wrote the current state while other_stale holds
 	bool             saved_m1_valid = false;
@@ -537,18 +536,14 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 		return HP_OK;
 	sweep_direction(d, part, tm);
 	const int truncated = ((d->desc.quirks & HP_QUIRK_BDY_TRUNCATED) != 0 ? 1 : 0) | (d->fill_now ? 2 : 0);   // the kernel's `flags`
-	// (FILL: the source was written by pair launch pair_gen, whose stamps say where the destination must NOT get the source's value)
-	PairAux<T> aux{};
-	if (d->fill_now && d->z_state) {
-		aux.stamps = (const StampBufs<T>*)((const char*)d->haz_words + 16); aux.prev_gen = d->pair_gen;
-	}
+
 	LaunchTail<T> tail;
 	const int tail_kind = make_tail<T>(d, blocks, part, stream, tail_limit(), tail);
 #define HP_LAUNCH_K1S(FUSED_, TAIL_, LIST_, NEXT_, SPEC_)                                                                                   \
 	hipLaunchKernelGGL((godunov_march<STRICT, CFL_MODE, FUSED_, TAIL_, T, SPEC_>), dim3(blocks), dim3(256), 0, stream, p,                   \
 	                   (const Scalars<T>*)d->scalars, (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst,                     \
 	                   (const T*)d->manning, (T*)d->cfl_slot, (const T*)d->cfl_slot + SLOT_EDGE + edge_buffer, tm, LIST_, NEXT_,   \
-	                   truncated, tail, aux)
+	                   truncated, tail)
 #define HP_LAUNCH_K1(FUSED_, TAIL_, LIST_, NEXT_) HP_LAUNCH_K1S(FUSED_, TAIL_, LIST_, NEXT_, false)
 	constexpr bool CAN_SPEC = STRICT && sizeof(T) == 8;       // a speculative STRICT fp64 batch: see launch_muscl
 	if (CAN_SPEC && d->spec_now && !d->fusable && tail_kind != 2 && part == PART_ALL) {        // (never with fused boundaries: spec_wanted)
@@ -880,21 +875,26 @@ static bool strip_pairs_possible_here(const hp_domain* d)
 {
 	return pairs_possible_common(d) && d->comm && d->comm_world > 1 && d->peer_direct && d->ghost_rows == 2 && !d->rings_differ;
 }
-// The stamps' buffers (PairAux), allocated with a domain's first pair.  HP_PAIR_STAMPS=0: none -- round 5's behaviour, the cell's
-// current value stands in for the stale one everywhere (A/B runs, and the test that shows what the stamps are for).
+// The stamps' buffers (PairAux), allocated with a domain's first exact pair.
+// Which pairs keep quirk Q3 exact (godunov_march2's HZ instantiation: 4-9 % slower): HP_PAIR_EXACT=1 all of them, =0 none; default: the
+// domains whose area boundaries can REMOVE water -- a loss rate, a mass flux -- where whole regions dry at once and sit untouched, with
+// stale values in the reference's other buffer, for as long as they stay dry.
+static bool pair_exact(const hp_domain* d)
+{
+	static const int forced = std::getenv("HP_PAIR_EXACT") ? (std::atoi(std::getenv("HP_PAIR_EXACT")) != 0 ? 1 : 0) : -1;
+	if (forced >= 0) return forced != 0;
+	for (const Boundary& b : d->bdy)
+		if ((b.kind == 0 && b.definition == HP_UNIFORM_LOSS_RATE) || (b.kind == 1 && b.definition == HP_GRIDDED_MASS_FLUX)) return true;
+	return false;
+}
 static int pair_stamps_alloc(hp_domain* d)
 {
-	static const bool enabled = !(std::getenv("HP_PAIR_STAMPS") && std::atoi(std::getenv("HP_PAIR_STAMPS")) == 0);
-	if (!enabled || d->z_state) return HP_OK;
-	HIP_TRY(hipMalloc(&d->z_state, d->cells * 4 * d->esize));
-	HIP_TRY(hipMalloc((void**)&d->z_gen, d->cells * sizeof(unsigned)));
+	if (!pair_exact(d) || d->z_state) return HP_OK;
+	const size_t rec = (size_t)4 * d->esize + 16;                         // stamp_rec<T>(): the state, then the launch's number
+	HIP_TRY(hipMalloc(&d->z_state, d->cells * rec));
 	HIP_TRY(hipMalloc((void**)&d->haz_words, 64));
-	HIP_TRY(hipMemsetAsync(d->z_gen, 0, d->cells * sizeof(unsigned), d->stream));
+	HIP_TRY(hipMemsetAsync(d->z_state, 0, d->cells * rec, d->stream));
 	HIP_TRY(hipMemsetAsync(d->haz_words, 0, 64, d->stream));
-	// the kernels reach the three buffers through ONE pointer (StampBufs, hp_kernels.hpp): the table sits behind the two words
-	const StampBufs<double> table{(State4<double>*)d->z_state, d->z_gen, d->haz_words};       // (three addresses: the same layout for both precisions)
-	HIP_TRY(hipMemcpyAsync((char*)d->haz_words + 16, &table, sizeof table, hipMemcpyHostToDevice, d->stream));
-	HIP_TRY(hipStreamSynchronize(d->stream));                           // (`table` is a local)
 	return HP_OK;
 }
 // Area boundaries: the pair kernel needs the primary buffer priced WITH the first iteration's boundaries (slot[SLOT_M1]).  Every BDY
@@ -947,7 +947,8 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip, const bool 
 	tail.pair = bdy ? 2 : 1;
 	tail.bdy_flag = bdy && followed ? 1 : 0;
 	PairAux<T> aux{};
-	aux.stamps = d->z_state ? (const StampBufs<T>*)((const char*)d->haz_words + 16) : nullptr;
+	const bool exact = pair_exact(d) && d->z_state != nullptr;
+	if (exact) aux.stamps = StampBufs<T>{(char*)d->z_state, d->haz_words};
 	aux.prev_gen = d->other_stale ? d->pair_gen : 0u;                     // `src` was written by a pair launch: its stamps apply
 	aux.gen = ++d->pair_gen;
 	if (aux.gen == 0) aux.gen = ++d->pair_gen;                            // (0 means "no launch")
@@ -959,14 +960,16 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip, const bool 
 	const bool sample = d->timing_stride > 0 && d->timing_used < d->timing_events.size() &&
 	                    (d->timing_counter++ % (uint64_t)d->timing_stride) == 0;
 	if (sample) HIP_TRY(hipEventRecord(d->timing_events[d->timing_used].first, d->stream));
-#define HP_LAUNCH_K1B(CFL_, BDY_, TAIL_)                                                                                                  \
-	hipLaunchKernelGGL((godunov_march2<false, CFL_, BDY_, TAIL_, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const Scalars<T>*)d->scalars, \
+#define HP_LAUNCH_K1B2(CFL_, BDY_, HZ_, TAIL_)                                                                                            \
+	hipLaunchKernelGGL((godunov_march2<false, CFL_, BDY_, HZ_, TAIL_, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const Scalars<T>*)d->scalars, \
 	                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning, (T*)d->cfl_slot,                    \
 	                   (const T*)d->cfl_slot + SLOT_EDGE, tm, tail, aux)
-	if (strip)    { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, false, 2); else HP_LAUNCH_K1B(0, false, 2); }
+#define HP_LAUNCH_K1B(CFL_, BDY_, TAIL_) do { if (exact) HP_LAUNCH_K1B2(CFL_, BDY_, true, TAIL_); else HP_LAUNCH_K1B2(CFL_, BDY_, false, TAIL_); } while (0)
+	if (strip)    { if (d->desc.dynamic_dt) HP_LAUNCH_K1B2(1, false, false, 2); else HP_LAUNCH_K1B2(0, false, false, 2); }     // (strips: no stamps -- a ghost row's would be the neighbour's to write)
 	else if (bdy) HP_LAUNCH_K1B(1, true, 1);                              // (area boundaries pair with a dynamic timestep only: pairs_possible_common)
 	else          { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, false, 1); else HP_LAUNCH_K1B(0, false, 1); }
 #undef HP_LAUNCH_K1B
+#undef HP_LAUNCH_K1B2
 	d->pair_fused_next = bdy && followed;
 	d->m1_valid = bdy;
 	HIP_TRY(hipGetLastError());
@@ -1004,10 +1007,10 @@ static int repair_other_buffer(hp_domain* d)
 	if (d->z_state) {                                                     // ... except where the last pair launch stamped a different value (PairAux)
 		if (d->desc.precision == 8)
 			hipLaunchKernelGGL((stamps_to_buffer<double>), dim3(1024), dim3(256), 0, d->stream, (State4<double>*)d->state[d->use_alt ^ 1],
-			                   (const State4<double>*)d->z_state, d->z_gen, d->haz_words, d->pair_gen, d->cells);
+			                   StampBufs<double>{(char*)d->z_state, d->haz_words}, d->pair_gen, d->cells);
 		else
 			hipLaunchKernelGGL((stamps_to_buffer<float>), dim3(1024), dim3(256), 0, d->stream, (State4<float>*)d->state[d->use_alt ^ 1],
-			                   (const State4<float>*)d->z_state, d->z_gen, d->haz_words, d->pair_gen, d->cells);
+			                   StampBufs<float>{(char*)d->z_state, d->haz_words}, d->pair_gen, d->cells);
 		HIP_TRY(hipGetLastError());
 	}
 	d->other_stale = false;
@@ -1019,7 +1022,8 @@ int dispatch_begin(hp_domain* d)
 	// after iteration pairs the non-current buffer is out of date; K1 brings it up to date by itself (its FILL flag: every cell of the
 	// launch's rows is stored), any other kernel gets the device copy first
 	static const bool fill_enabled = !(std::getenv("HP_FILL_AFTER_PAIRS") && std::atoi(std::getenv("HP_FILL_AFTER_PAIRS")) == 0);
-	const bool fill = fill_enabled && d->other_stale && d->desc.scheme == HP_SCHEME_GODUNOV && d->desc.kernel != HP_KERNEL_BASIC;
+	// (exact pairs: the device copy, then the stamps on top -- repair_other_buffer -- so that K1 needs no knowledge of them)
+	const bool fill = fill_enabled && d->other_stale && d->desc.scheme == HP_SCHEME_GODUNOV && d->desc.kernel != HP_KERNEL_BASIC && !(pair_exact(d) && d->z_state);
 	if (!fill) { const int rc0 = repair_other_buffer(d); if (rc0 != HP_OK) return rc0; }
 	d->fill_now = fill;
 	const bool strict = d->desc.math_mode == HP_MATH_STRICT;
@@ -1499,7 +1503,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	hipFree(d->state[0]); hipFree(d->state[1]); hipFree(d->bed); hipFree(d->manning);
 	hipFree(d->scalars); hipFree(d->cfl_slot);
 	hipFree(d->saved_state); hipFree(d->saved_scalars); hipFree(d->fused_list); hipFree(d->tail_words);
-	hipFree(d->z_state); hipFree(d->z_gen); hipFree(d->haz_words);
+	hipFree(d->z_state); hipFree(d->haz_words);
 	hipFree(d->spec_state); hipFree(d->spec_scalars);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
@@ -2759,6 +2763,25 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples)
 	}
 	*avg_ms = n ? total / n : 0.0;
 	*samples = n;
+	return HP_OK;
+}
+
+int hp_pair_stats(hp_domain_t* d, uint64_t out[4])
+{
+	int rc = check_domain(d);
+	if (rc != HP_OK) return rc;
+	if (!out) return fail(HP_ERR_INVALID, "out == NULL");
+	out[0] = d->pairs; out[1] = d->pair_cold_starts; out[2] = out[3] = 0;
+	if (!d->z_state) return HP_OK;
+	const size_t rec = (size_t)4 * d->esize + 16;
+	std::vector<char> recs(d->cells * rec);
+	HIP_TRY(hipMemcpyAsync(recs.data(), d->z_state, recs.size(), hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	for (size_t i = 0; i < d->cells; ++i) {
+		unsigned g;
+		std::memcpy(&g, recs.data() + i * rec + 4 * d->esize, sizeof g);
+		out[2] += (g != 0 && g == d->pair_gen); out[3] += (g != 0);
+	}
 	return HP_OK;
 }
 

@@ -706,12 +706,24 @@ template <typename T> struct FusedBdy {
 //    cell.  (Round 5 took the current value everywhere and had 881 181 probe cells to show for it)  The first single
 //    iteration behind pairs (K1's FILL flag) reads the same stamps.
 //  * Area boundaries (BDY).  See the kernel's header.
-// (the three buffers' addresses never change once allocated and are needed on cold paths only: they live in device memory behind ONE
-// pointer, so that the kernels -- whose register budgets have no slack: godunov_march2 runs at 168 VGPRs and 106 SGPRs with spills --
-// keep two scalar registers alive for them instead of six)
-template <typename T> struct StampBufs { State4<T>* z_state; unsigned* z_gen; unsigned long long* haz; };
+// A stamp record: the cell's first-step state followed by the number of the launch that wrote it (16-byte aligned: 48 B fp64, 32 B fp32) --
+// one buffer, so that the march's masked stores of both go through ONE buffer resource.
+template <typename T> constexpr unsigned stamp_rec() { return (unsigned)sizeof(State4<T>) + 16u; }
+template <typename T> struct StampBufs { char* rec; unsigned long long* haz; };
+template <typename T> __device__ __forceinline__ unsigned stamp_gen(const StampBufs<T>& b, const size_t id)
+{
+	return *reinterpret_cast<const unsigned*>(b.rec + id * stamp_rec<T>() + sizeof(State4<T>));
+}
+template <typename T> __device__ __forceinline__ State4<T> stamp_state(const StampBufs<T>& b, const size_t id)
+{
+	const T* v = reinterpret_cast<const T*>(b.rec + id * stamp_rec<T>());
+	State4<T> c; c.z = v[0]; c.zmax = v[1]; c.qx = v[2]; c.qy = v[3];
+	return c;
+}
 template <typename T> struct PairAux {
-	const StampBufs<T>*   stamps;      // nullptr: no stamps (nothing to look up, nothing written down)
+	StampBufs<T>          stamps;      // rec == nullptr: no stamps (nothing to look up, nothing written down).  (By value: kernel arguments are
+	                                   // uniform by construction -- loaded through a pointer the addresses came back as per-lane values and every
+	                                   // buffer access that used them was wrapped in a waterfall loop)
 	unsigned              gen, prev_gen;
 	const AreaBdyList<T>* list;        // (BDY) the domain's area boundaries, as K1's fused epilogue gets them
 	int                   fuse_next;   // (BDY) another iteration of the same batch follows the pair: store the state with ITS boundaries applied
@@ -761,7 +773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
                                                      State4<T>* __restrict__ dst, const T* __restrict__ manning,
                                                      T* cfl_slot, const T* __restrict__ edge_max,
                                                      const TileMap tm, const AreaBdyList<T>* __restrict__ fused_list,
-                                                     const int fuse_next, const int flags, const LaunchTail<T> tail, const PairAux<T> aux)
+                                                     const int fuse_next, const int flags, const LaunchTail<T> tail)
 {
 	if (TAIL != 0 && blockIdx.x >= tail.flux_blocks) {                             // the launch's own tail (LaunchTail above)
 		launch_tail(p, tail);
@@ -790,19 +802,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 	// run_pair) -- the cells the reference leaves untouched (Q3) are stored too, with the value the host's repair copy would have put
 	// there, the source's
 	const bool fill = (flags & 2) != 0;
-	// ... except where the pair launch that wrote `src` stamped the cell (PairAux: the value the reference's buffer would hold there is
-	// not the source's): looked up only if that launch raised its word at all
-	const bool hz_any = fill && aux.stamps != nullptr && aux.prev_gen != 0 && aux.stamps->haz[aux.prev_gen & 1u] == (unsigned long long)aux.prev_gen;
-	auto fill_value = [&](State4<T> v, const long y, const bool want) {
-		if (wave_any(want)) {
-			asm volatile("");
-			if (want) {
-				const size_t id = (size_t)y * p.cols + xc;
-				if (aux.stamps->z_gen[id] == aux.prev_gen) v = aux.stamps->z_state[id];
-			}
-		}
-		return v;
-	};
 
 	// ---- fused area boundaries of the NEXT iteration (see above) ----
 	FusedBdy<T> fb[FUSED_BDY_MAX];
@@ -1057,7 +1056,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 					out = upd;
 				}
 			}
-			if (hz_any) out = fill_value(out, y, dry5 && !disabled && out_x);       // (FILL: wave-uniform)
 			fS = fy.forR;
 			dryS = dryC;
 		}
@@ -1110,10 +1108,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 			fS = face_dry_for_right<AXIS_Y, STRICT>(sC, sN, vs);
 			// (FUSED: the only cells this loop stores are nulls, which no boundary kernel touches -- and, with FILL, the dry cells, which
 			// the cold pass below stores again with their rain)
-			State4<T> kept = rc.c;
-			if (hz_any) kept = fill_value(kept, y, out_x && !disabled);
-			buf_store_state(kept, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
-			if (TAIL == 2) store_peer(kept, y, write);
+			buf_store_state(rc.c, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - (y0 - 1)) * row_state);
+			if (TAIL == 2) store_peer(rc.c, y, write);
 			if (!((int)y >= tm.price_lo && (int)y < tm.price_hi)) {
 			} else if (CFL_MODE == 1) {
 				if (write) {
@@ -1144,8 +1140,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 		for (long y = y0; y < y1; ++y) {
 			if ((stale_rows >> (unsigned)(y - y0)) & 1ull) {
 				const size_t id = (size_t)y * p.cols + xc;
-				State4<T> c = fill ? src[id] : dst[id];
-				if (hz_any && aux.stamps->z_gen[id] == aux.prev_gen) c = aux.stamps->z_state[id];
+				const State4<T> c = fill ? src[id] : dst[id];
 				const T zb = bed[id];
 				if (CFL_MODE == 1 && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 					const T s = cfl_speed_impl<STRICT, PL>(c.z, c.zmax, c.qx, c.qy, zb, p.qs, false, spec_bad);
@@ -1200,7 +1195,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 constexpr int MARCH2_COLS = 60;          // updated columns per wavefront (lanes 2..61)
 template <typename T> struct RowU1 { State4<T> c; T zb; bool plain; };      // plain: c IS the cell's source value, bit for bit (nothing touched it at the first step)
 
-template <bool STRICT, int CFL_MODE, bool BDY, int TAIL, typename T>   // CFL_MODE 1: price what the pair leaves in the primary buffer; 0: fixed timestep
+// HZ: the instantiation that keeps quirk Q3 EXACT across pair launches (the stamps, PairAux).  What it costs the march -- a vote that joins
+// an existing one, the bookkeeping of which intermediate cells are plain copies, the registers both take from a kernel that has none to
+// spare -- measured 3.7 % on still water, 9 % where every tile is live and 8 % on the fp32 rain workload (profiles/r06f_stamps_ab.txt;
+// a branch of its own per row cost 9-34 %, masked stores 6 %), so it runs where the stale values matter: domains whose boundaries
+// REMOVE water (a loss rate dries whole regions at once, and their cells then sit untouched with stale values in the other buffer), or
+// on request (HP_PAIR_EXACT=1).  Without it a first-step-untouched cell passes its current state on, as in round 5: equal to the stale
+// one in every such cell-iteration of the probes (tools/r05_q3_stale_probe.py: 881 181 of them) -- unless the cell dried that very step.
+template <bool STRICT, int CFL_MODE, bool BDY, bool HZ, int TAIL, typename T>   // CFL_MODE 1: price what the pair leaves in the primary buffer; 0: fixed timestep
 // (three waves per SIMD: 167 VGPRs and four spilled registers measured 0.193 ms per iteration at 4096^2 against 0.215 at two waves
 // and 171 registers without spills -- profiles/r05n_two_step.txt; -DHP_K1B_WAVES_MIN=2 builds the other one)
 #ifndef HP_K1B_WAVES_MIN
@@ -1287,16 +1289,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	};
 
 	// ---- quirk Q3 at the first step: the stamps of the launch that wrote `src` (PairAux) ----
-#ifndef HP_PAIR_STAMPS_BUILD
-#define HP_PAIR_STAMPS_BUILD 1          // 0: the kernel of round 5 -- no stamps compiled in (A/B builds: what the bookkeeping costs the march)
-#endif
-	const bool hz_on = HP_PAIR_STAMPS_BUILD != 0 && aux.stamps != nullptr;
-	const bool hz_any = hz_on && aux.prev_gen != 0 && aux.stamps->haz[aux.prev_gen & 1u] == (unsigned long long)aux.prev_gen;     // wave-uniform (scalar loads)
-	// (the first-step value of the row stage B works on waits in LDS for the rare lane that has to write it down: held in registers
-	// it would cost the march eight of them from one end of the row step to the other)
-	__shared__ T park_tab[4 * 4 * 64];
-	T* const park = park_tab + wave * (4 * 64) + lane;
-	bool stamped = false;                                                          // this wavefront wrote a stamp (its launch's word is raised at the end)
+	const bool hz_on = HZ && aux.stamps.rec != nullptr;
+	constexpr unsigned REC = stamp_rec<T>();
+	bool stamped = false;                                  // (LIVE launches, per lane) wrote a stamp: the launch's word is raised after the march
+	const bool hz_any = hz_on && aux.prev_gen != 0 && aux.stamps.haz[aux.prev_gen & 1u] == (unsigned long long)aux.prev_gen;     // wave-uniform (scalar loads)
 
 	// ---- (BDY) which of the three applications are live in THIS launch: scalar arithmetic on the time-control block ----
 	unsigned act = 0;                       // bit j: application j has at least one boundary that acts
@@ -1386,8 +1382,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	// The march, in two builds of the same statements: LIVE carries the boundary applications (a launch in which the hydrological
 	// gate opens at one of its three moments), !LIVE is the kernel as it is without boundaries -- which is what a BDY launch runs on
 	// all the iterations in between (the gate opens once per second of model time).
-	auto march = [&](auto live_tag) {
+	auto march = [&](auto live_tag, auto look_tag) {
 	constexpr bool LIVE = decltype(live_tag)::value;
+	constexpr bool LOOK = decltype(look_tag)::value;         // the launch that wrote `src` stamped cells: stage A looks them up (hardly ever)
 	// one cell's share of application J, in the order the boundaries were added: the statements of bdy_area
 	auto apply = [&](auto j_tag, State4<T> c, const T zb, const long y) {
 		constexpr int J = decltype(j_tag)::value;
@@ -1457,10 +1454,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 				if (touched) { u.c = upd; u.plain = false; }
 				// untouched by the reference (Q3): its destination keeps the state of the iteration before the pair.  That is the cell's
 				// current state -- unless the launch before said otherwise
-				if (hz_any && wave_any(dry5 && !ring_x && !disabled)) {
+				if (LOOK && wave_any(dry5 && !ring_x && !disabled)) {
 					if (dry5 && !ring_x && !disabled) {
 						const size_t id = (size_t)r * p.cols + xc;
-						if (aux.stamps->z_gen[id] == aux.prev_gen) { u.c = aux.stamps->z_state[id]; u.plain = false; }
+						if (stamp_gen(aux.stamps, id) == aux.prev_gen) { u.c = stamp_state(aux.stamps, id); u.plain = false; }
 					}
 				}
 			}
@@ -1488,7 +1485,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		State4<T> out = uc.c;
 		bool write = out_x;
 		bool untouched = false;                                                    // left alone by the second step (Q3): the primary buffer keeps state k
-		if (hz_on && update) { park[0] = uc.c.z; park[64] = uc.c.zmax; park[128] = uc.c.qx; park[192] = uc.c.qy; }
+		// (the row's offset, pinned as a scalar: shared by the stores of the state and of the stamps)
+		const unsigned row_k = (unsigned)__builtin_amdgcn_readfirstlane((int)(y - row_base));
 		if (!skip_b) {
 			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sCb, sN, vs);
 			bool dryC = false, dryN = false;
@@ -1509,7 +1507,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 				}
 				const bool disabled = uc.c.zmax <= T(-9999.0) || uc.c.z == T(-9999.0);
 				const bool dry5 = dryC && dryN && dryE && drySb && dryW;
-				const State4<T> upd = godunov_update<STRICT>(uc.c, uc.zb, n_c, dt_b, fy.forL, fx.forL, fSb, fW, p.dx, inv_dx, vs, with_friction);
+				// Q3 for the launch that follows (PairAux): the first-step value uc.c is written down where that launch could need it and
+				// cannot have it -- a cell that may be dry at its first step and whose value there differs from uc.c.
+				//  * a cell this step leaves alone holds state k afterwards: equal to uc.c if nothing touched it at the first step either
+				//    (`plain`), unknown here otherwise -- written down;
+				//  * a cell this step updates: looked at between the flux step and the friction step (the update's probe), where the old
+				//    state is in registers anyway and everything that decides is known -- a cell that ends the step dry has no friction
+				//    term, so its level (clamped to the bed), its discharge and its maximum level are final there.
+				//  (LIVE launches, whose stored state also receives the next iteration's boundaries, do the same after the update, on
+				//  the state with those applied: further down.)
+				const bool keeps_k = dry5 && out_x && !disabled;                       // this step leaves the cell alone
+				const bool probed = out_x && !disabled && !dry5;
+				const bool pending = !LIVE && hz_on && keeps_k && !uc.plain;
+				const auto probe = make_probe(
+					[&](const State4<T>&, const T z1) { return pending || (!LIVE && hz_on && probed && (z1 - uc.zb) < vs); },
+					[&](const State4<T>& c0, const T z1, const T qx1, const T qy1) {
+						if (LIVE || !hz_on) return;
+						const bool ends_dry = (z1 - uc.zb) < vs;                       // (then the level is clamped to the bed: CLSchemeGodunov.clc:379-380)
+						const bool changed = c0.z != uc.zb || c0.qx != qx1 || c0.qy != qy1 || (z1 > c0.zmax && c0.zmax > T(-9990.0));
+						const bool need = pending || (probed && ends_dry && changed);
+						if (wave_any(need)) {
+							if (need) {
+								const size_t id = (size_t)y * p.cols + xc;
+								T* v = reinterpret_cast<T*>(aux.stamps.rec + id * REC);
+								v[0] = c0.z; v[1] = c0.zmax; v[2] = c0.qx; v[3] = c0.qy;
+								*reinterpret_cast<unsigned*>(aux.stamps.rec + id * REC + sizeof(State4<T>)) = aux.gen;
+								aux.stamps.haz[aux.gen & 1u] = (unsigned long long)aux.gen;        // (the launch's word: every writer writes the same value)
+							}
+						}
+					});
+				const State4<T> upd = godunov_update_impl<STRICT, false, true>(uc.c, uc.zb, n_c, dt_b, fy.forL, fx.forL, fSb, fW, p.dx, inv_dx, vs, with_friction,
+				                                                               (T*)nullptr, probe);
 				if (!disabled) {
 					if (dry5) {                                                        // the primary buffer keeps state k: copied in the cold pass below
 						write = false;
@@ -1528,30 +1556,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 			// that if another iteration of the batch follows; applied by the next launch as it loads the row otherwise)
 			State4<T> next = out;
 			if (live2) next = apply(J2(), out, uc.zb, y);
-			// Q3 for the launch that follows (PairAux): the first-step value uc.c is written down where that launch could need it and
-			// cannot have it -- a cell that may be dry at its first step and whose value there differs from uc.c.  Cells the second step
-			// left alone hold state k: equal to uc.c if nothing touched them at the first step either (`plain`), unknown here otherwise.
-			if (hz_on) {
-				const bool dry_next = (next.z - uc.zb) < vs || (LIVE && !fuse && (out.z - uc.zb) < vs);
-				bool stamp = write && dry_next;
-				stamp = stamp || (untouched && (!uc.plain || (live2 && next.z != out.z && (next.z - uc.zb) < vs)));
+			// (LIVE: Q3's stamps on the state with the next iteration's boundaries applied -- what the next launch will read for the cell,
+			// or, when the batch ends here and that launch applies them itself as it loads, possibly without them)
+			if (LIVE && hz_on) {
+				const bool dry_next = (next.z - uc.zb) < vs || (!fuse && (out.z - uc.zb) < vs);
+				bool stamp = write && dry_next && (uc.c.z != next.z || uc.c.qx != next.qx || uc.c.qy != next.qy || uc.c.zmax != next.zmax ||
+				                                   (!fuse && uc.c.z != out.z));
+				stamp = stamp || (untouched && (!uc.plain || (next.z != out.z && (next.z - uc.zb) < vs)));
 				if (wave_any(stamp)) {
 					asm volatile("");
-					State4<T> first; first.z = park[0]; first.zmax = park[64]; first.qx = park[128]; first.qy = park[192];      // = uc.c
-					const bool differs = untouched || first.z != next.z || first.qx != next.qx || first.qy != next.qy || first.zmax != next.zmax ||
-					                     (LIVE && !fuse && first.z != out.z);
-					stamp = stamp && differs;
-					if (wave_any(stamp)) {
-						if (stamp) {
-							const size_t id = (size_t)y * p.cols + xc;
-							aux.stamps->z_state[id] = first;
-							aux.stamps->z_gen[id] = aux.gen;
-						}
-						stamped = true;
+					if (stamp) {
+						const size_t id = (size_t)y * p.cols + xc;
+						T* v = reinterpret_cast<T*>(aux.stamps.rec + id * REC);
+						v[0] = uc.c.z; v[1] = uc.c.zmax; v[2] = uc.c.qx; v[3] = uc.c.qy;
+						*reinterpret_cast<unsigned*>(aux.stamps.rec + id * REC + sizeof(State4<T>)) = aux.gen;
 					}
+					stamped = stamped || stamp;
 				}
 			}
-			buf_store_state(fuse ? next : out, srd_dst, write ? voff_state : HP_OOB, (unsigned)(y - row_base) * row_state);
+			buf_store_state(fuse ? next : out, srd_dst, write ? voff_state : HP_OOB, row_k * row_state);
 			if (TAIL == 2) store_peer(fuse ? next : out, y, write);
 			if (CFL_MODE == 1 && write && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, uc.zb, p.qs);
@@ -1611,9 +1634,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	if (!live2) vmax1 = vmax;                              // nothing acts on the stored state before the next reduction: one maximum
 	};   // march
 
-	if (BDY && act != 0) march(std::true_type()); else march(std::false_type());
+	auto raise_word = [&]() { if (hz_on && wave_any(stamped) && lane == 0) aux.stamps.haz[aux.gen & 1u] = (unsigned long long)aux.gen; };
+	if (BDY && act != 0) { if (hz_any) march(std::true_type(), std::true_type()); else march(std::true_type(), std::false_type()); }
+	else                 { if (hz_any) march(std::false_type(), std::true_type()); else march(std::false_type(), std::false_type()); }
+	raise_word();
 
-	if (stamped && lane == 0) aux.stamps->haz[aux.gen & 1u] = (unsigned long long)aux.gen;
 	if (CFL_MODE != 0) {
 		if (blockIdx.x == 0 && wave == 0) { const T e = *edge_max; if (e > vmax) vmax = e; if (e > vmax1) vmax1 = e; }
 		vmax = wave_max(vmax);
@@ -1629,12 +1654,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 // the value the reference's other buffer holds there (PairAux) -- so that whatever builds on that buffer next finds what single iterations
 // would have left in it.
 template <typename T>
-__global__ __launch_bounds__(256) void stamps_to_buffer(State4<T>* __restrict__ other, const State4<T>* __restrict__ z_state, const unsigned* __restrict__ z_gen,
-                                                        const unsigned long long* __restrict__ haz, const unsigned gen, const size_t cells)
+__global__ __launch_bounds__(256) void stamps_to_buffer(State4<T>* __restrict__ other, const StampBufs<T> b, const unsigned gen, const size_t cells)
 {
-	if (haz[gen & 1u] != (unsigned long long)gen) return;
+	if (b.haz[gen & 1u] != (unsigned long long)gen) return;
 	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x)
-		if (z_gen[id] == gen) other[id] = z_state[id];
+		if (stamp_gen(b, id) == gen) other[id] = stamp_state(b, id);
 }
 
 // Cold start of iteration pairs on a domain with area boundaries (hp_engine.hip: pair_cold_start): the stand-alone boundary pass and the

@@ -638,11 +638,24 @@ __device__ __forceinline__ T small_to_zero(const T v, const T vs)
 
 // Godunov cell update from its four finished faces (CLSchemeGodunov.clc:321-383).
 // Returns the new state; `c` holds {Z, Zmax, Qx, Qy} of the cell before the step.
-template <bool STRICT, bool CLAMP_FIRST, bool PLAIN, typename T>
+// (Probe: the pair kernel's look at "does this cell end the step dry, and changed" -- quirk Q3's stamps, hp_kernels.hpp: PairAux.  It
+// sits where the old state is still in registers and everything that decides is known: behind the flux step of the level, in front of
+// the friction step -- a cell that ends the step dry has no friction term (CLFriction.clc:36-37), so its discharge after the flux step
+// is final.  `want` (per lane) joins the vote of the block that zeroes the discharge at a stopping condition: no branch of its own on
+// the march's path -- one cost the pair kernel a tenth of its speed, masked stores 6 % -- and `hit` runs inside that block.  NoProbe:
+// nothing, and the vote is the stopping conditions' alone.)
+struct NoProbe {
+	template <typename... A> __device__ __forceinline__ bool want(A&&...) const { return false; }
+	template <typename... A> __device__ __forceinline__ void hit(A&&...) const {}
+};
+template <typename W, typename H> struct Probe2 { W want; H hit; };
+template <typename W, typename H> __device__ __forceinline__ Probe2<W, H> make_probe(W w, H h) { return Probe2<W, H>{w, h}; }
+template <bool STRICT, bool CLAMP_FIRST, bool PLAIN, typename T, typename Probe = NoProbe>
 __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb, const T n, const T dt,
                                                          const FaceFlux<T>& fN, const FaceFlux<T>& fE,
                                                          const FaceFlux<T>& fS, const FaceFlux<T>& fW,
-                                                         const T dx, const T inv_dx, const T vs, const bool with_friction, T* spec_word)
+                                                         const T dx, const T inv_dx, const T vs, const bool with_friction, T* spec_word,
+                                                         const Probe& probe = Probe())
 {
 	bool bad = false;
 	const T g = gravity<T>();
@@ -684,21 +697,27 @@ __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb
 
 	const bool stop = fN.stop || fE.stop || fS.stop || fW.stop;
 	if (STRICT) {
-		if (stop) { c.qx = T(0); c.qy = T(0); }                      // :351-355
-		c.z  = c.z  - dt * d0;                                       // :358-360
-		c.qx = c.qx - dt * d2;
-		c.qy = c.qy - dt * d3;
+		T qx0 = c.qx, qy0 = c.qy;
+		if (stop) { qx0 = T(0); qy0 = T(0); }                        // :351-355
+		const T z1  = c.z - dt * d0;                                 // :358-360
+		const T qx1 = qx0 - dt * d2;
+		const T qy1 = qy0 - dt * d3;
+		if (wave_any(probe.want(c, z1))) probe.hit(c, z1, qx1, qy1);
+		c.z = z1; c.qx = qx1; c.qy = qy1;
 		if (with_friction) friction<true, PLAIN>(c.qx, c.qy, c.z, zb, n, dt, vs, bad);        // :362-372
 		spec_raise<PLAIN>(bad, spec_word);
 	} else {
-		if (wave_any(stop)) {                                    // a stopping condition needs a dry side
-			asm volatile("");                                    // (a real branch: if-converted, its eight selects ran on every row)
-			c.qx = stop ? T(0) : c.qx; c.qy = stop ? T(0) : c.qy;
-		}
+		T qx0 = c.qx, qy0 = c.qy;
 		const T lam = -(dt * inv_dx);
-		c.z  = fma_(lam, d0, c.z);
-		c.qx = fma_(lam, d2, c.qx);
-		c.qy = fma_(lam, d3, c.qy);
+		const T z1 = fma_(lam, d0, c.z);
+		if (wave_any(stop || probe.want(c, z1))) {               // a stopping condition needs a dry side
+			asm volatile("");                                    // (a real branch: if-converted, its eight selects ran on every row)
+			qx0 = stop ? T(0) : qx0; qy0 = stop ? T(0) : qy0;
+			probe.hit(c, z1, fma_(lam, d2, qx0), fma_(lam, d3, qy0));
+		}
+		c.z = z1;
+		c.qx = fma_(lam, d2, qx0);
+		c.qy = fma_(lam, d3, qy0);
 		if (with_friction) friction_fast(c.qx, c.qy, c.z, zb, n, dt, vs);
 	}
 

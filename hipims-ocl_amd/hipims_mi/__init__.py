@@ -37,7 +37,7 @@ EXPORTS = [
     "hp_strip_comm_destroy", "hp_strip_info", "hp_strip_peer_ticket", "hp_strip_peer_connect", "hp_strip_peer_round",
     "hp_strip_peer_disconnect", "hp_timer_start",
     "hp_timer_stop", "hp_kernel_timing", "hp_kernel_timing_read", "hp_kernel_timing_overhead",
-    "hp_launch_counts",
+    "hp_launch_counts", "hp_pair_stats",
 ]
 
 
@@ -496,6 +496,15 @@ class Domain:
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(self.lib, self.lib.hp_launch_counts(self.h, C.byref(a), C.byref(b)), "hp_launch_counts")
         return a.value, b.value
+
+    def pair_stats(self):
+        """Diagnostics of the iteration pairs (hp_pair_stats): dict(pairs, cold_starts, stamped_last, stamped_ever); blocks."""
+        if not hasattr(self.lib, "hp_pair_stats"):
+            return None
+        out = (C.c_uint64 * 4)()
+        self.lib.hp_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _check(self.lib, self.lib.hp_pair_stats(self.h, out), "hp_pair_stats")
+        return dict(pairs=out[0], cold_starts=out[1], stamped_last=out[2], stamped_ever=out[3])
 
     def kernel_timing_overhead(self):
         """Cost of an empty event pair (ms) that kernel_timing_read() has taken off every sample (0.0 with a library that

@@ -352,6 +352,15 @@ int hp_kernel_timing_overhead(hp_domain_t* d, double* overhead_ms);
  * by an advance launch).  bench.py states its roofline basis from the difference of two readings around the timed region. */
 int hp_launch_counts(hp_domain_t* d, uint64_t* flux_launches, uint64_t* with_tail);
 
+/* (Round 6: pairs also run on domains whose boundary conditions are area boundaries the flux kernel can carry -- hp_boundaries_fused --
+ * and quirk Q3 holds across pair launches EXACTLY: a cell the reference leaves untouched at a pair's first step keeps what its
+ * destination buffer held (CLSchemeGodunov.clc:248-255), a value that never leaves the registers when pairs follow each other -- the
+ * launch before writes it down ("stamps" it) for the cells that could need it, hp_kernels.hpp: PairAux.)
+ * Diagnostics of that machinery, for tests and A/B runs; blocks.  out[0] iteration pairs run, out[1] pairs that started cold on a
+ * domain with area boundaries (stand-alone boundary pass + reduction in front: after single iterations, an upload, a new target
+ * time), out[2] cells stamped by the LAST pair launch, out[3] cells that carry a stamp of any launch. */
+int hp_pair_stats(hp_domain_t* d, uint64_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

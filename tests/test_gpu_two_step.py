@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(os.path.dirname(__file__), "two_step_worker.py")
 
 
-def run(scenario, precision, tmp_path, mode):
-    out = os.path.join(str(tmp_path), f"{scenario}_{precision}_{mode}.npz")
+def run(scenario, precision, tmp_path, mode, **env):
+    out = os.path.join(str(tmp_path), f"{scenario}_{precision}_{mode}{''.join('_' + k + v for k, v in env.items())}.npz")
     r = subprocess.run([sys.executable, WORKER, scenario, precision, out], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, HP_TWO_STEP=str(mode)))
+                       env=dict(os.environ, HP_TWO_STEP=str(mode), **env))
     assert r.returncode == 0, r.stdout + r.stderr
     return np.load(out)
 
@@ -81,13 +81,57 @@ def test_pairs_with_area_boundaries_are_the_same_computation(scenario, precision
     the oracle by test_gpu_fused_rain.py) bit for bit: uniform rain, rain + loss (drying: quirk Q3's stale values, the stamps), gridded
     rain, mass flux + rain, timesteps above a second (every gate open), over odd / even batches, downloads, a sync point,
     tst_UpdateTimestep and a checkpoint."""
-    single, pairs = run(scenario, precision, tmp_path, 0), run(scenario, precision, tmp_path, 1)
+    single, pairs = run(scenario, precision, tmp_path, 0), run(scenario, precision, tmp_path, 1, HP_PAIR_EXACT="1")
     assert int(single["launches"]) == int(single["iterations"])
     assert int(pairs["launches"]) < int(pairs["iterations"]) * 0.75             # (every batch of the plan starts cold or ends single)
     assert int(pairs["iterations"]) == int(single["iterations"])
     for key in ("t", "dt", "ok", "skipped"):
         assert pairs[key] == single[key], key
     assert np.array_equal(pairs["state"], single["state"])
+
+
+@pytest.mark.parametrize("scenario", ["rough", "damdry"])
+def test_exact_pairs_without_boundaries(scenario, tmp_path):
+    """HP_PAIR_EXACT=1 on domains without boundary conditions (where the default leaves the stamps out, for speed): the same bits as the
+    single iterations, as the default's -- wet/dry terrain, a dry-bed dam break through a sync point and a checkpoint."""
+    single, exact = run(scenario, "f64", tmp_path, 0), run(scenario, "f64", tmp_path, 1, HP_PAIR_EXACT="1")
+    assert int(exact["launches"]) < int(exact["iterations"]) * 0.62
+    for key in ("t", "dt", "ok", "skipped"):
+        assert exact[key] == single[key], key
+    assert np.array_equal(exact["state"], single["state"])
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("scenario", ["rain", "gridrain"])
+def test_default_pairs_with_rain(scenario, precision, tmp_path):
+    """Rain only (nothing removes water): the default runs such domains' pairs WITHOUT the stamps (godunov_march2's HZ = false: 4-9 %
+    faster) -- a cell left untouched at a pair's first step passes its current state on where the reference keeps a stale one, which
+    differ only if the cell dried out that very step.  Held to the single iterations at FAST's own bar against the oracle (depth RMSE
+    1e-9 m fp64, 1e-4 m fp32) -- and, on these workloads, found equal to the last bit."""
+    single, pairs = run(scenario, precision, tmp_path, 0), run(scenario, precision, tmp_path, 1)
+    assert int(pairs["launches"]) < int(pairs["iterations"]) * 0.75 and int(pairs["stamped_ever"]) == 0
+    d = np.abs(pairs["state"][..., 0].astype(np.float64) - single["state"][..., 0])
+    rmse = float(np.sqrt(np.mean(d ** 2)))
+    assert rmse < (1e-9 if precision == "f64" else 1e-4), rmse
+    assert abs(float(pairs["t"]) - float(single["t"])) <= (1e-12 if precision == "f64" else 1e-5) * float(single["t"])
+    print(f"default pairs with {scenario} {precision}: depth RMSE vs single iterations {rmse:.3e} m, equal bits: {np.array_equal(pairs['state'], single['state'])}")
+
+
+def test_the_stamps_are_what_makes_pairs_exact_where_cells_dry_out(tmp_path):
+    """Quirk Q3 across pair launches (hp_kernels.hpp: PairAux).  A cell the reference leaves untouched at a pair's first
+    step keeps the value of the iteration before the pair -- which only the launch before ever had.  Where the loss rate dries whole
+    regions at once such cells are many: with the stamps switched off (HP_PAIR_EXACT=0: round 5's behaviour, the cell's current value
+    stands in -- what domains without such boundaries run by default, for speed) the run parts from the single iterations; with them it does not, and the stamps were really written."""
+    outs = {}
+    for name, env in (("single", {"HP_TWO_STEP": "0"}), ("stamps", {"HP_TWO_STEP": "1"}), ("none", {"HP_TWO_STEP": "1", "HP_PAIR_EXACT": "0"})):
+        out = os.path.join(str(tmp_path), f"{name}.npz")
+        r = subprocess.run([sys.executable, WORKER, "rainloss", "f64", out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = np.load(out)
+    assert np.array_equal(outs["stamps"]["state"], outs["single"]["state"]) and outs["stamps"]["t"] == outs["single"]["t"]
+    assert int(outs["stamps"]["stamped_ever"]) > 0 and int(outs["none"]["stamped_ever"]) == 0
+    assert int(outs["stamps"]["cold_starts"]) >= 1 and int(outs["stamps"]["pairs"]) == int(outs["none"]["pairs"]) > 100
+    assert not np.array_equal(outs["none"]["state"], outs["single"]["state"])           # (what the stamps are for)
 
 
 def test_default_takes_pairs_on_big_grids_only(tmp_path):

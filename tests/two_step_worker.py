@@ -96,7 +96,8 @@ for step in plan:
 final = dom.download()
 sc = dom.read_scalars()
 counts = dom.launch_counts()
+ps = dom.pair_stats() or dict(pairs=0, cold_starts=0, stamped_last=0, stamped_ever=0)
 np.savez(out, state=final, t=sc["time"], dt=sc["timestep"], ok=sc["batch_successful"], skipped=sc["batch_skipped"],
-         iterations=sc["iterations"], launches=counts[0])
+         iterations=sc["iterations"], launches=counts[0], pairs=ps["pairs"], cold_starts=ps["cold_starts"], stamped_ever=ps["stamped_ever"])
 dom.close()
 print(f"{scenario} {precision}: t = {sc['time']!r}, iterations {sc['iterations']}, flux launches {counts[0]}")
