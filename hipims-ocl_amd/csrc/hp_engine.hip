@@ -179,6 +179,14 @@ struct hp_domain {
 	bool             pair_fused_next = false;         // the last pair stored its state with the next iteration's boundaries applied (SLOT_BDY = 1)
 	bool             m1_valid = false;                // area boundaries: cfl_slot[SLOT_M1] prices the primary buffer with the next iteration's boundaries (left by the last pair)
 	uint64_t         pair_cold_starts = 0;
+	// STRICT: pairs or single iterations, by measurement (pair_tuner: the two are the same bits; which is faster depends on how much of
+	// the water stands still)
+	hipEvent_t       tune_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	int              tune_phase = 0;                  // 0: sample at the next opportunity, 1: a sample is in flight, 2: decided
+	bool             tune_prefer_pairs = true;
+	uint64_t         tune_next = 0;                   // iteration count from which the next sample is due
+	uint64_t         tune_samples = 0, tune_switches = 0;
+	float            tune_pair_ms = 0.f, tune_single_ms = 0.f;
 	uint64_t         pairs = 0;                       // iteration pairs run by it
 	unsigned         single_streak = 0;               // single iterations since the last pair (step_begin_impl: which launches hp_kernel_timing samples)
 	uint64_t         flux_launches = 0, flux_launches_tailed = 0;   // whole-domain flux launches of hp_step_batch / hp_strip_step_batch, and how many carried their own tail block
@@ -828,7 +836,13 @@ static bool pairs_possible_common(const hp_domain* d)
 	// (godunov_march2, BDY); single domains only.  HP_PAIR_BDY=0 keeps such domains on single iterations (A/B runs).
 	static const bool bdy_enabled = !(std::getenv("HP_PAIR_BDY") && std::atoi(std::getenv("HP_PAIR_BDY")) == 0);
 	const bool bdy_ok = d->bdy.empty() || (bdy_enabled && d->fusable && !d->comm && d->comm_world <= 1 && d->desc.dynamic_dt);
-	return d->desc.scheme == HP_SCHEME_GODUNOV && d->desc.kernel != HP_KERNEL_BASIC && d->desc.math_mode == HP_MATH_FAST &&
+	// STRICT (round 6): the same statements in the same order as K1's, so the pair is the same computation there too -- always with
+	// the stamps (the exact mode promises the reference's bits); no boundaries, single domains, dynamic timestep.  What it is for: rows
+	// of still water are a copy in STRICT (K1's skip), and a pair copies them at half the bytes.  HP_PAIR_STRICT=0 switches it off.
+	static const bool strict_enabled = !(std::getenv("HP_PAIR_STRICT") && std::atoi(std::getenv("HP_PAIR_STRICT")) == 0);
+	const bool math_ok = d->desc.math_mode == HP_MATH_FAST ||
+	                     (strict_enabled && d->bdy.empty() && !d->comm && d->comm_world <= 1 && d->desc.dynamic_dt && !d->spec_now);
+	return d->desc.scheme == HP_SCHEME_GODUNOV && d->desc.kernel != HP_KERNEL_BASIC && math_ok &&
 	       bdy_ok && (!d->desc.dynamic_dt || (d->desc.quirks & HP_QUIRK_CFL_READS_PRIMARY) != 0) &&
 	       tail_enabled && d->tail_words != nullptr && d->desc.rows >= 5 && d->desc.cols >= 5;
 }
@@ -881,6 +895,7 @@ static bool strip_pairs_possible_here(const hp_domain* d)
 // stale values in the reference's other buffer, for as long as they stay dry.
 static bool pair_exact(const hp_domain* d)
 {
+	if (d->desc.math_mode == HP_MATH_STRICT) return true;
 	static const int forced = std::getenv("HP_PAIR_EXACT") ? (std::atoi(std::getenv("HP_PAIR_EXACT")) != 0 ? 1 : 0) : -1;
 	if (forced >= 0) return forced != 0;
 	for (const Boundary& b : d->bdy)
@@ -923,7 +938,11 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip, const bool 
 		lo = south ? d->ghost_rows : 1;
 		hi = d->desc.rows - (north ? d->ghost_rows : 1);
 	} else launch_rows(d, 1, lo, hi);
-	if (!make_tile_map(lo, hi, 1, PART_ALL, (int)((p.cols - 2 + MARCH2_COLS - 1) / MARCH2_COLS), d->march2_rseg, d->march2_rseg, 0, tm, blocks, d->march2_rseg,
+	// (STRICT: 12-row tiles -- its live tiles cost 1300 instructions per row and stage, and a 24-row one is what the launch waits for at its
+	// end: S-DAM 4096^2 0.275 ms per iteration at 24 rows, 0.2645 at 12, 0.281 at 8; profiles/r06i_strict_pair_tile_sweep.txt)
+	static const bool rseg_forced = std::getenv("HP_MARCH2_RSEG") != nullptr;
+	const int rseg2 = (d->desc.math_mode == HP_MATH_STRICT && !rseg_forced) ? std::min(d->march2_rseg, 12) : d->march2_rseg;
+	if (!make_tile_map(lo, hi, 1, PART_ALL, (int)((p.cols - 2 + MARCH2_COLS - 1) / MARCH2_COLS), rseg2, rseg2, 0, tm, blocks, rseg2,
 	                   0, d->own_lo, d->own_hi, d->march2_nbands))
 		return HP_ERR_STATE;
 	if (blocks > tail_limit()) return HP_ERR_STATE;                      // (the caller falls back to single iterations)
@@ -965,6 +984,11 @@ template <typename T> int run_pair_t(hp_domain* d, const bool strip, const bool 
 	                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning, (T*)d->cfl_slot,                    \
 	                   (const T*)d->cfl_slot + SLOT_EDGE, tm, tail, aux)
 #define HP_LAUNCH_K1B(CFL_, BDY_, TAIL_) do { if (exact) HP_LAUNCH_K1B2(CFL_, BDY_, true, TAIL_); else HP_LAUNCH_K1B2(CFL_, BDY_, false, TAIL_); } while (0)
+	if (d->desc.math_mode == HP_MATH_STRICT)
+		hipLaunchKernelGGL((godunov_march2<true, 1, false, true, 1, T>), dim3(blocks), dim3(256), 0, d->stream, p, (const Scalars<T>*)d->scalars,
+		                   (const T*)d->bed, (const State4<T>*)src, (State4<T>*)dst, (const T*)d->manning, (T*)d->cfl_slot,
+		                   (const T*)d->cfl_slot + SLOT_EDGE, tm, tail, aux);
+	else
 	if (strip)    { if (d->desc.dynamic_dt) HP_LAUNCH_K1B2(1, false, false, 2); else HP_LAUNCH_K1B2(0, false, false, 2); }     // (strips: no stamps -- a ghost row's would be the neighbour's to write)
 	else if (bdy) HP_LAUNCH_K1B(1, true, 1);                              // (area boundaries pair with a dynamic timestep only: pairs_possible_common)
 	else          { if (d->desc.dynamic_dt) HP_LAUNCH_K1B(1, false, 1); else HP_LAUNCH_K1B(0, false, 1); }
@@ -1504,6 +1528,7 @@ int hp_domain_destroy(hp_domain_t* d)
 	hipFree(d->scalars); hipFree(d->cfl_slot);
 	hipFree(d->saved_state); hipFree(d->saved_scalars); hipFree(d->fused_list); hipFree(d->tail_words);
 	hipFree(d->z_state); hipFree(d->haz_words);
+	for (hipEvent_t e : d->tune_ev) if (e) hipEventDestroy(e);
 	hipFree(d->spec_state); hipFree(d->spec_scalars);
 	if (d->host_scalars) hipHostFree(d->host_scalars);
 	if (d->ev_start) hipEventDestroy(d->ev_start);
@@ -1533,6 +1558,7 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 		HIP_TRY(hipMemcpyAsync(d->state[1], host, bytes, hipMemcpyHostToDevice, d->stream));
 		d->other_stale = false;
 		d->rings_differ = false;
+		if (d->tune_phase == 2) d->tune_phase = 0;
 		d->use_alt = 0;                                                   // :1075
 		d->need_full_reduce = true;
 		d->edge_dirty = true;
@@ -1625,6 +1651,7 @@ int hp_state_restore(hp_domain_t* d)
 	d->rings_differ = d->saved_rings_differ;
 	d->rings_checked = false;
 	d->m1_valid = d->saved_m1_valid;                                      // (slot[SLOT_M1] has come back with the slot block)
+	if (d->tune_phase == 2) d->tune_phase = 0;                            // (another state: the exact mode's pairs-or-singles choice is measured anew)
 	d->pair_fused_next = false;                                           // (a checkpoint is taken between batches: nothing fused is in the buffer)
 	d->ghost_valid = d->saved_ghost_valid;
 	// a bed or state upload between save and restore has left its own marks: they stay
@@ -1917,26 +1944,81 @@ int spec_begin(hp_domain* d)
 	d->spec_now = true;
 	return HP_OK;
 }
+// The exact mode's choice between pairs and single iterations (round 6).  STRICT pairs are STRICT single iterations bit for bit, so the
+// choice is free -- and workload dependent: rows of still water are a copy in STRICT (K1's skip) which a pair makes at half the bytes
+// (S-DAM 4096^2: 0.299 -> 0.265 ms per iteration), while water that moves everywhere is bound by instruction issue, where the pair's two
+// extra first-step rows per tile and its narrower wavefronts cost 13 % (S-ROUGH: 0.60 -> 0.68 ms; profiles/r06h_strict_pairs.txt).  So the
+// engine measures: every 512 iterations two pairs and four single iterations are bracketed by events on the domain's stream
+// (nothing blocks: the events are looked at when a later batch call finds them complete) and the faster flavour runs until the next sample.
+// HP_PAIR_TUNE=0: always pairs where eligible.
+static bool tuner_on(const hp_domain* d)
+{
+	static const bool enabled = !(std::getenv("HP_PAIR_TUNE") && std::atoi(std::getenv("HP_PAIR_TUNE")) == 0);
+	return enabled && d->desc.math_mode == HP_MATH_STRICT && two_step_mode() != 1;
+}
+static int tuner_poll(hp_domain* d)
+{
+	if (d->tune_phase == 1 && hipEventQuery(d->tune_ev[3]) == hipSuccess) {
+		float pair_ms = 0.f, single_ms = 0.f;
+		HIP_TRY(hipEventElapsedTime(&pair_ms, d->tune_ev[0], d->tune_ev[1]));
+		HIP_TRY(hipEventElapsedTime(&single_ms, d->tune_ev[2], d->tune_ev[3]));
+		const bool prefer = pair_ms < 0.98f * single_ms;
+		if (prefer != d->tune_prefer_pairs) d->tune_switches++;
+		d->tune_prefer_pairs = prefer;
+		d->tune_pair_ms = pair_ms; d->tune_single_ms = single_ms;
+		d->tune_samples++;
+		d->tune_phase = 2;
+		d->tune_next = d->iterations + 512;
+	}
+	if (d->tune_phase == 2 && d->iterations >= d->tune_next) d->tune_phase = 0;
+	return HP_OK;
+}
+int run_single(hp_domain* d, const bool followed)
+{
+	// (K1 FUSED) every iteration but the last carries its successor's rain / loss: between batches the buffers are
+	// what the reference's are -- a download never sees rain of an iteration that has not begun
+	d->fuse_next = followed;
+	d->m1_valid = false;                           // (a single iteration prices one maximum: the next pair starts cold)
+	d->tail_allowed = true;                        // nothing is queued between the flux launch and the advance in this loop
+	int rc = dispatch_begin(d);
+	d->tail_allowed = false;
+	if (rc != HP_OK) return rc;
+	return dispatch_end(d);
+}
 int run_iterations(hp_domain* d, uint32_t n_iterations)
 {
 	int rc;
+	const bool tune = tuner_on(d);
+	if (tune && (rc = tuner_poll(d)) != HP_OK) return rc;
 	for (uint32_t i = 0; i < n_iterations; ++i) {
-		// two iterations in one pass where that is the same computation (run_pair)
-		if (i + 2 <= n_iterations && d->rings_differ && !d->rings_checked && pairs_possible(d) && (rc = rings_really_differ(d)) != HP_OK) return rc;
-		if (i + 2 <= n_iterations && pair_eligible(d)) {
+		// (STRICT) a sample: three pairs, then six single iterations -- the first pair and the first two single iterations warm the
+		// kernel's code and are not timed, the rest are bracketed by events
+		if (tune && d->tune_phase == 0 && i + 12 <= n_iterations && !d->rings_differ && pair_eligible(d)) {
+			for (hipEvent_t& e : d->tune_ev) if (!e) HIP_TRY(hipEventCreate(&e));
+			if ((rc = pair_stamps_alloc(d)) != HP_OK) return rc;           // (the first pair's allocation and its memset are not the pair's price)
+			rc = run_pair(d, false, true);
+			if (rc == HP_OK) {
+				HIP_TRY(hipEventRecord(d->tune_ev[0], d->stream));
+				if ((rc = run_pair(d, false, true)) != HP_OK || (rc = run_pair(d, false, true)) != HP_OK) return rc;
+				HIP_TRY(hipEventRecord(d->tune_ev[1], d->stream));
+				if ((rc = repair_other_buffer(d)) != HP_OK) return rc;    // (not part of an iteration's price: a run of single iterations pays it once)
+				if ((rc = run_single(d, true)) != HP_OK || (rc = run_single(d, true)) != HP_OK) return rc;
+				HIP_TRY(hipEventRecord(d->tune_ev[2], d->stream));
+				for (int k = 0; k < 4; ++k)
+					if ((rc = run_single(d, k < 3 || i + 12 < n_iterations)) != HP_OK) return rc;
+				HIP_TRY(hipEventRecord(d->tune_ev[3], d->stream));
+				d->tune_phase = 1;
+				i += 11;
+				continue;
+			}
+			if (rc != HP_ERR_STATE) return rc;
+		}
+		if (i + 2 <= n_iterations && (!tune || d->tune_prefer_pairs) && pair_eligible(d)) {
 			rc = run_pair(d, false, i + 2 < n_iterations);
 			if (rc == HP_OK) { ++i; continue; }
 			if (rc != HP_ERR_STATE) return rc;                 // (HP_ERR_STATE: not launchable as a pair -- single iterations)
 		}
-		// (K1 FUSED) every iteration but the last carries its successor's rain / loss: between batches the buffers are
-		// what the reference's are -- a download never sees rain of an iteration that has not begun
-		d->fuse_next = i + 1 < n_iterations;
-		d->m1_valid = false;                           // (a single iteration prices one maximum: the next pair starts cold)
-		d->tail_allowed = true;                        // nothing is queued between the flux launch and the advance in this loop
-		rc = dispatch_begin(d);
-		d->tail_allowed = false;
-		if (rc != HP_OK) return rc;
-		if ((rc = dispatch_end(d)) != HP_OK) return rc;
+		if ((rc = run_single(d, i + 1 < n_iterations)) != HP_OK) return rc;
 	}
 	d->fuse_next = 0;
 	return HP_OK;
@@ -2766,12 +2848,16 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples)
 	return HP_OK;
 }
 
-int hp_pair_stats(hp_domain_t* d, uint64_t out[4])
+int hp_pair_stats(hp_domain_t* d, uint64_t out[8])
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
 	if (!out) return fail(HP_ERR_INVALID, "out == NULL");
 	out[0] = d->pairs; out[1] = d->pair_cold_starts; out[2] = out[3] = 0;
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	if (tuner_on(d) && (rc = tuner_poll(d)) != HP_OK) return rc;
+	out[4] = d->tune_samples; out[5] = d->tune_switches; out[6] = d->tune_prefer_pairs ? 1 : 0;
+	out[7] = d->tune_single_ms > 0.f ? (uint64_t)(1000.0 * d->tune_pair_ms / d->tune_single_ms) : 0;
 	if (!d->z_state) return HP_OK;
 	const size_t rec = (size_t)4 * d->esize + 16;
 	std::vector<char> recs(d->cells * rec);

@@ -1208,7 +1208,8 @@ template <bool STRICT, int CFL_MODE, bool BDY, bool HZ, int TAIL, typename T>   
 #ifndef HP_K1B_WAVES_MIN
 #define HP_K1B_WAVES_MIN 3
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 4 : (STRICT ? 2 : HP_K1B_WAVES_MIN), sizeof(T) == 4 ? 5 : (STRICT ? 2 : 3)))) void godunov_march2(
+// (STRICT: two waves per SIMD in fp64, three in fp32 -- no vector register of the exact flavour is spilled: tests/test_resource_usage.py)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (STRICT ? 3 : 4) : (STRICT ? 2 : HP_K1B_WAVES_MIN), sizeof(T) == 4 ? (STRICT ? 3 : 5) : (STRICT ? 2 : 3)))) void godunov_march2(
 	const Params<T> p, const Scalars<T>* sc, const T* __restrict__ bed, const State4<T>* __restrict__ src,
 	State4<T>* __restrict__ dst, const T* __restrict__ manning, T* cfl_slot, const T* __restrict__ edge_max,
 	const TileMap tm, const LaunchTail<T> tail, const PairAux<T> aux)
@@ -1412,12 +1413,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	Side<T> sCa;
 	FaceFlux<T> fSa = {};
 	bool drySa;
+	// Still water (STRICT; K1's skip, see there: a row whose 64 cells hold ONE wet state at rest between two rows that hold the same
+	// state cell for cell comes out of the update as it went in, bit for bit).  Both stages have it -- stage B on the intermediate rows
+	// -- and on such rows a pair is what it is for the FAST flavour: a copy at half the bytes.
+	constexpr bool STILL = STRICT;
+	constexpr unsigned REST_S = 1, REST_C = 2, EQ_S = 4, PRICED = 16;              // (K1's flags, one word per stage)
+	unsigned stA = 0, stB = 0;
+	auto at_rest = [&](const State4<T>& c) { return wave_all(c.qx == T(0) && c.qy == T(0)) != 0; };
+	auto same_level = [&](const State4<T>& a, const T za, const State4<T>& b, const T zb_) { return wave_all(a.z == b.z && za == zb_) != 0; };
+	auto one_wet_state = [&](const State4<T>& c, const T zb_) {
+		const T z_first = first_lane(c.z), b_first = first_lane(zb_);
+		return wave_all(c.z == z_first && zb_ == b_first && (c.z - zb_) > vs && !(c.zmax <= T(-9999.0) || c.z == T(-9999.0))) != 0;
+	};
 	{
 		RowRegs<T> rs = load_row(y0 - 2);
 		if (live0) { rs.c = apply(J0(), rs.c, rs.zb, y0 - 2 < 0 ? 0 : y0 - 2); rc.c = apply(J0(), rc.c, rc.zb, y0 - 1); }
 		const Side<T> sS = make_side<STRICT>(rs.c.z, rs.c.qx, rs.c.qy, rs.zb, vs);
 		sCa = make_side<STRICT>(rc.c.z, rc.c.qx, rc.c.qy, rc.zb, vs);
 		drySa = (rs.c.z - rs.zb) < vs;
+		if (STILL) {
+			if (at_rest(rs.c)) stA |= REST_S;
+			if (at_rest(rc.c)) stA |= REST_C;
+			if (stA == (REST_S | REST_C) && same_level(rs.c, rs.zb, rc.c, rc.zb)) stA |= EQ_S;
+		}
 		if (!skip_a) fSa = face_solve<AXIS_Y, STRICT, true, true>(sS, sCa, vs).forR;
 	}
 	auto stage_a = [&](const long r, const RowRegs<T>& rn_in, RowRegs<T>& pre) {
@@ -1426,8 +1444,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		if (live0) rn.c = apply(J0(), rn.c, rn.zb, r + 1 > last_row ? last_row : r + 1);   // (the row enters the march here: boundaries first, CSchemeGodunov.cpp:1638)
 		RowU1<T> u; u.c = rc.c; u.zb = rc.zb; u.plain = true;
 		Side<T> sN = sCa;
-		if (!skip_a) {
-			const bool ring_row = r <= 0 || r >= last_row;                         // wave-uniform: passes through, but its north face is needed
+		const bool ring_row = r <= 0 || r >= last_row;                             // wave-uniform: passes through, but its north face is needed
+		bool still = false;
+		if (STILL) {
+			const bool rest_n = at_rest(rn.c);
+			const bool eq_n = (stA & REST_C) && rest_n && same_level(rc.c, rc.zb, rn.c, rn.zb);
+			if (!skip_a && !ring_row && eq_n && (stA & (EQ_S | REST_S)) == (EQ_S | REST_S)) still = one_wet_state(rc.c, rc.zb);
+			stA = ((stA & REST_C) ? REST_S : 0u) | (rest_n ? REST_C : 0u) | (eq_n ? EQ_S : 0u);
+		}
+		if (still) {
+			// (the side and the south flux the rows hand each other stay as they are: the rows hold one state)
+			if (u.c.z > u.c.zmax && u.c.zmax > T(-9990.0)) u.c.zmax = u.c.z;          // :375-376, all that is left of the update
+			u.plain = false;                                                       // (never asked: a still cell is wet)
+			drySa = false;
+		} else if (!skip_a) {
 			sN = make_side<STRICT>(rn.c.z, rn.c.qx, rn.c.qy, rn.zb, vs);
 			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sCa, sN, vs);
 			// (a face whose lanes all have water on both sides lies between wet cells: K1's row step)
@@ -1481,13 +1511,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	FaceFlux<T> fSb = {};
 	bool drySb = false;
 	auto stage_b = [&](const long y, const RowU1<T>& un, const T n_next, const bool update) {
-		const Side<T> sN = make_side<STRICT>(un.c.z, un.c.qx, un.c.qy, un.zb, vs);
 		State4<T> out = uc.c;
 		bool write = out_x;
 		bool untouched = false;                                                    // left alone by the second step (Q3): the primary buffer keeps state k
-		// (the row's offset, pinned as a scalar: shared by the stores of the state and of the stamps)
+		// (the row's offset, pinned as a scalar)
 		const unsigned row_k = (unsigned)__builtin_amdgcn_readfirstlane((int)(y - row_base));
-		if (!skip_b) {
+		bool still = false, skip_cfl = false;
+		if (STILL) {
+			const bool rest_n = at_rest(un.c);
+			const bool eq_n = (stB & REST_C) && rest_n && same_level(uc.c, uc.zb, un.c, un.zb);
+			if (update && !skip_b && eq_n && (stB & (EQ_S | REST_S)) == (EQ_S | REST_S)) still = one_wet_state(uc.c, uc.zb);
+			stB = (stB & PRICED) | ((stB & REST_C) ? REST_S : 0u) | (rest_n ? REST_C : 0u) | (eq_n ? EQ_S : 0u);
+		}
+		Side<T> sN = sCb;
+		if (still) {
+			if (out.z > out.zmax && out.zmax > T(-9990.0)) out.zmax = out.z;          // :375-376
+			drySb = false;
+			// ONE state across the wave: if the still row below (the same state, by its own test) has priced it, pricing it again
+			// cannot change the maximum
+			skip_cfl = (stB & PRICED) != 0;
+			if ((int)y >= tm.price_lo && (int)y < tm.price_hi && wave_any(out_x && out.zmax > T(-9999.0))) stB |= PRICED;
+		} else {
+			stB &= ~PRICED;
+			sN = make_side<STRICT>(un.c.z, un.c.qx, un.c.qy, un.zb, vs);
+		}
+		if (!still && !skip_b) {
 			const FacePair<T> fy = face_solve<AXIS_Y, STRICT, true, true>(sCb, sN, vs);
 			bool dryC = false, dryN = false;
 			if (!LAZY_DRY || !fy.wet) {
@@ -1576,7 +1624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 			}
 			buf_store_state(fuse ? next : out, srd_dst, write ? voff_state : HP_OOB, row_k * row_state);
 			if (TAIL == 2) store_peer(fuse ? next : out, y, write);
-			if (CFL_MODE == 1 && write && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
+			if (CFL_MODE == 1 && write && !skip_cfl && (int)y >= tm.price_lo && (int)y < tm.price_hi) {
 				const T s = cfl_speed<STRICT>(out.z, out.zmax, out.qx, out.qy, uc.zb, p.qs);
 				if (s > vmax) vmax = s;
 				if (live2) {                                                           // ... and what the next iteration's reduction will find (slot[SLOT_M1])
@@ -1595,6 +1643,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 		uc = stage_a(y0 - 1, rP, rQ);                                              // (rc = row y0, rP -> rQ holds row y0 + 1)
 		n_c = n0;
 		sCb = make_side<STRICT>(uc.c.z, uc.c.qx, uc.c.qy, uc.zb, vs);
+		if (STILL && at_rest(uc.c)) stB |= REST_C;
 		const T n1 = rc.n;
 		const RowU1<T> u0 = stage_a(y0, rQ, rP);
 		stage_b(y0 - 1, u0, n1, false);                                            // stage B without an update: the face below row y0 and its dry flag

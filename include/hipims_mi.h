@@ -358,8 +358,10 @@ int hp_launch_counts(hp_domain_t* d, uint64_t* flux_launches, uint64_t* with_tai
  * launch before writes it down ("stamps" it) for the cells that could need it, hp_kernels.hpp: PairAux.)
  * Diagnostics of that machinery, for tests and A/B runs; blocks.  out[0] iteration pairs run, out[1] pairs that started cold on a
  * domain with area boundaries (stand-alone boundary pass + reduction in front: after single iterations, an upload, a new target
- * time), out[2] cells stamped by the LAST pair launch, out[3] cells that carry a stamp of any launch. */
-int hp_pair_stats(hp_domain_t* d, uint64_t out[4]);
+ * time), out[2] cells stamped by the LAST pair launch, out[3] cells that carry a stamp of any launch; the exact mode's choice between
+ * pairs and single iterations (the same bits; chosen by measurement, hp_engine.hip: tuner_poll): out[4] samples taken, out[5] changes
+ * of mind, out[6] 1 if pairs are the current choice, out[7] the last sample's pair time over its two single iterations' time, x 1000. */
+int hp_pair_stats(hp_domain_t* d, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

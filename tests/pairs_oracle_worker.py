@@ -17,6 +17,9 @@ from hipims_mi import synthetic as syn  # noqa: E402
 case, precision, out = sys.argv[1:4]
 real = np.float64 if precision == "f64" else np.float32
 batches = None
+math_mode = hp.MATH_FAST
+if case.startswith("strict_"):              # the exact mode's pairs: held to the oracle BIT FOR BIT by the test
+    case, math_mode = case[len("strict_"):], hp.MATH_STRICT
 if case == "f6_rough":                      # fixture F6's rough bed (god_q_state200: the reference's own kernels)
     cols, rows, n = 64, 64, 200
     st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=None)
@@ -40,7 +43,7 @@ ref = oracle.OracleSim(cols, rows, precision=precision, threads=min(16, os.cpu_c
 ref.upload(st, bed, man)
 ref.set_target(1e9)
 ref.run(n)
-dom = hp.Domain(cols, rows, precision=precision, math_mode=hp.MATH_FAST)
+dom = hp.Domain(cols, rows, precision=precision, math_mode=math_mode)
 dom.upload(st, bed, man)
 dom.set_target_time(1e9)
 for b in (batches or [n]):

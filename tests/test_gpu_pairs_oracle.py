@@ -76,6 +76,19 @@ def test_pair_kernel_against_the_reference_kernel_fixtures(precision, tmp_path):
             assert rmse < 1e-4, (case, rmse)
 
 
+@pytest.mark.parametrize("case", ["strict_rough1024", "strict_damdry1024", "strict_f6_rough"])
+def test_strict_pair_kernel_is_the_oracle_bit_for_bit(case, tmp_path):
+    """godunov_march2<STRICT> (round 6) against the oracle: every cell of the final state, the elapsed time and the timestep, bit for
+    bit -- 1024^2 wet/dry rough terrain and the dry-bed dam break with friction, 250 iterations as 125 launches; fixture F6's rough bed
+    against the reference's own kernels."""
+    d = run(case, "f64", tmp_path)
+    assert int(d["launches"]) < 0.62 * int(d["iterations"])
+    assert np.array_equal(d["got"], d["want"])
+    assert float(d["t"]) == float(d["t_ref"]) and float(d["dt"]) == float(d["dt_ref"])
+    if case == "strict_f6_rough":
+        assert np.array_equal(d["got"], load_golden("f6_f7_trajectories_f64")["god_q_state200"])
+
+
 def test_default_selection_against_the_oracle(tmp_path):
     """No HP_TWO_STEP in the environment: 1500 x 1100 lies above the default's threshold, so the selection logic itself
     (hp_domain_create: march2_pays, the one-round tiling search) is what chooses godunov_march2 here; two batches of odd length put

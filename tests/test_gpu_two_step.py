@@ -90,6 +90,39 @@ def test_pairs_with_area_boundaries_are_the_same_computation(scenario, precision
     assert np.array_equal(pairs["state"], single["state"])
 
 
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("scenario", ["strict_dam", "strict_rough", "strict_damdry"])
+def test_strict_pairs_are_the_same_computation(scenario, precision, tmp_path):
+    """Round 6: the exact mode pairs too (godunov_march2<STRICT>: K1's statements in K1's order, still-water rows skipped in both
+    stages, quirk Q3's stamps always on).  Same bits as the single STRICT iterations -- which tests/test_gpu_strict_friction.py and
+    the fixtures hold to the reference's kernels -- state, time, timestep, counters."""
+    single, pairs = run(scenario, precision, tmp_path, 0), run(scenario, precision, tmp_path, 1)
+    assert int(single["launches"]) == int(single["iterations"])
+    assert int(pairs["launches"]) < int(pairs["iterations"]) * 0.62
+    for key in ("t", "dt", "ok", "skipped"):
+        assert pairs[key] == single[key], key
+    assert np.array_equal(pairs["state"], single["state"])
+
+
+@pytest.mark.parametrize("scenario", ["strict_tune_dam", "strict_tune_rough"])
+def test_the_exact_mode_chooses_between_pairs_and_single_iterations_by_measurement(scenario, tmp_path):
+    """STRICT pairs are STRICT single iterations bit for bit, and which is faster depends on the water (still rows are a copy, which a pair
+    makes at half the bytes; moving water is bound by instruction issue, where the pair's overheads cost): no HP_TWO_STEP in the
+    environment, the engine samples one pair against the two single iterations behind it (events, nothing blocks) and runs what won.
+    Whatever it chooses, and the sample itself, leave the same bits as single iterations throughout."""
+    env = {k: v for k, v in os.environ.items() if k != "HP_TWO_STEP"}
+    outs = {}
+    for name, extra in (("tuned", {}), ("single", {"HP_TWO_STEP": "0"})):
+        out = os.path.join(str(tmp_path), f"{name}.npz")
+        r = subprocess.run([sys.executable, WORKER, scenario, "f64", out], capture_output=True, text=True, timeout=900, env=dict(env, **extra))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = np.load(out)
+    t, s1 = outs["tuned"], outs["single"]
+    assert np.array_equal(t["state"], s1["state"]) and t["t"] == s1["t"] and t["dt"] == s1["dt"]
+    assert int(t["tune_samples"]) >= 1 and int(t["pairs"]) >= 1
+    print(f"{scenario}: pair / two single iterations = {float(t['pair_over_single']):.3f}, prefers pairs: {bool(t['prefers_pairs'])}, launches {int(t['launches'])} of {int(t['iterations'])}")
+
+
 @pytest.mark.parametrize("scenario", ["rough", "damdry"])
 def test_exact_pairs_without_boundaries(scenario, tmp_path):
     """HP_PAIR_EXACT=1 on domains without boundary conditions (where the default leaves the stamps out, for speed): the same bits as the

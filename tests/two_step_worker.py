@@ -14,6 +14,9 @@ from hipims_mi import synthetic as syn  # noqa: E402
 scenario, precision, out = sys.argv[1:4]
 real = np.float64 if precision == "f64" else np.float32
 kw = {}
+math_mode = hp.MATH_FAST
+if scenario.startswith("strict_"):          # the same scenarios in the exact mode (round 6: STRICT pairs)
+    scenario, math_mode = scenario[len("strict_"):], hp.MATH_STRICT
 if scenario == "dam":                       # all wet, walls: the benchmark's shape
     cols, rows = 1030, 700
     st, bed, man = syn.s_dam(cols, rows, dtype=real)
@@ -31,6 +34,10 @@ elif scenario == "fixed":                   # fixed timestep (no reduction at al
     st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
     kw = dict(dynamic_dt=False, dt_fixed=0.01)
     plan = [("run", 41), ("run", 40)]
+elif scenario in ("tune_dam", "tune_rough"):   # big enough for pairs by default: the exact mode's tuner samples a pair against two single iterations
+    cols, rows = 2048, 1500
+    st, bed, man = (syn.s_dam(cols, rows, dtype=real) if scenario == "tune_dam" else syn.s_rough(cols, rows, dtype=real, manning=0.03))
+    plan = [("run", 30), ("run", 21), ("run", 40), ("download",), ("run", 30)]     # (a sample takes a batch of twelve iterations or more)
 elif scenario == "rainlater":               # pairs first, then a rain boundary arrives: the first single iteration behind the pairs is K1 with FUSED
     cols, rows = 500, 333                   # boundaries AND the FILL flag (the buffer it writes is two states old); dry land keeps untouched cells
     st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
@@ -55,7 +62,7 @@ elif scenario in ("rain", "rainloss", "gridrain", "bigdt", "drying", "massflux")
         plan = [("settime", 70.0)] + plan
 else:
     raise SystemExit(scenario)
-dom = hp.Domain(cols, rows, precision=precision, math_mode=hp.MATH_FAST, **kw)
+dom = hp.Domain(cols, rows, precision=precision, math_mode=math_mode, **kw)
 dom.upload(st, bed, man)
 dom.set_target_time(1e9)
 for step in plan:
@@ -98,6 +105,7 @@ sc = dom.read_scalars()
 counts = dom.launch_counts()
 ps = dom.pair_stats() or dict(pairs=0, cold_starts=0, stamped_last=0, stamped_ever=0)
 np.savez(out, state=final, t=sc["time"], dt=sc["timestep"], ok=sc["batch_successful"], skipped=sc["batch_skipped"],
-         iterations=sc["iterations"], launches=counts[0], pairs=ps["pairs"], cold_starts=ps["cold_starts"], stamped_ever=ps["stamped_ever"])
+         iterations=sc["iterations"], launches=counts[0], pairs=ps["pairs"], cold_starts=ps["cold_starts"], stamped_ever=ps["stamped_ever"],
+         tune_samples=ps.get("tune_samples", 0), prefers_pairs=ps.get("prefers_pairs", True), pair_over_single=ps.get("pair_over_single", 0.0))
 dom.close()
 print(f"{scenario} {precision}: t = {sc['time']!r}, iterations {sc['iterations']}, flux launches {counts[0]}")
