@@ -229,11 +229,12 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
         # HIPIMS_MI_BACKEND=gloo: rehearsal of this branch with several processes on one GPU (host-staged exchange)
         backend = os.environ.get("HIPIMS_MI_BACKEND", "nccl")
         device = local_rank if backend == "nccl" else local_rank % max(1, hp.device_count())
-        # --exchange-period 2: two reaches of ghost rows, one exchange per two iterations -- and, for Godunov FAST strips big enough,
-        # iteration PAIRS as one launch (hp_engine.hip: run_pair; the weak-scaling shape gains 20 % on one GPU).  Opt-in: the
-        # default keeps the transport every multi-rank test and probe of five rounds has run on
+        # default (round 6): two reaches of ghost rows wherever the strips can then run iteration PAIRS as one launch (Godunov FAST, the
+        # library's own loop, no area boundaries: hipims_mi/strips.py) -- the weak-scaling shape gains 20 % on one GPU, the 4096 x 514
+        # strong-scaling strip 10 % -- one reach otherwise; --exchange-period 1 / 2 forces
         runner = StripRunner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
-                             device=device, rank=rank, world=world, backend=backend, exchange_period=args.exchange_period)
+                             device=device, rank=rank, world=world, backend=backend, exchange_period=(args.exchange_period or None),
+                             area_boundaries=(workload == "s-rain"))
     if workload == "s-rain":
         # built in row blocks (the float64 intermediates of 8192^2 at once are 6 GB and most of the leg's wall time)
         n_local = runner.local_hi - runner.local_lo
@@ -317,6 +318,7 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
                              f"batch of the {cols}x{rows} leg -- the strips did not exchange correctly; no line is printed for a broken run")
     strip_info = runner.domain.strip_info() if world > 1 and getattr(runner, "loop", "") == "cxx" else None
     leg = dict(cols=cols, rows=rows, world=world, math=math, elapsed=elapsed, runs=runs, k_ms=k_ms, k_n=k_n, sc=sc,
+               exchange_period=getattr(runner, "exchange_period", 1),
                overhead_ms=overhead_ms, strip_info=strip_info, loop=getattr(runner, "loop", "batch call"),
                cells_per_launch=cols * runner.local_rows_total, flux_kernel=runner.flux_kernel_name, levels=levels,
                fused=(runner.domain.boundaries_fused() if workload == "s-rain" else None), workload=workload,
@@ -373,7 +375,7 @@ def parallelism_of(leg):
     world, si = leg["world"], leg["strip_info"]
     s = f"row-strips x{world}"
     if world > 1:
-        s += f", per-iteration loop: {leg['loop']}"
+        s += f", per-iteration loop: {leg['loop']}, {leg.get('exchange_period', 1)} iteration(s) per ghost-row exchange"
     if si:
         s += (f", collective library {si['library']} reporting {si['comm_ranks']} ranks, halo overlap {'on' if si['halo_overlap'] else 'off'}, "
               f"maximum over the strips by {'peer-written mailboxes' if si['peer_max'] else 'all-reduce'}, ghost rows "
@@ -407,8 +409,9 @@ def main():
     ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
                     help="N > 1: both (default) = `value` from the strong leg (the metric's 4096^2 grid cut into N strips) and the "
                          "object `weak` from the configs' ladder (16.8 Mcell per GPU); weak / strong = that leg only")
-    ap.add_argument("--exchange-period", type=int, choices=[1, 2], default=1,
-                    help="N > 1: iterations per ghost-row exchange (2: two reaches of ghost rows; lets big Godunov strips run iteration pairs)")
+    ap.add_argument("--exchange-period", type=int, choices=[0, 1, 2], default=0,
+                    help="N > 1: iterations per ghost-row exchange (2: two reaches of ghost rows, which lets Godunov FAST strips run iteration "
+                         "pairs; 0 = 2 where that is possible, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-manning-leg", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")

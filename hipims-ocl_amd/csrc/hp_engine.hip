@@ -377,7 +377,7 @@ inline bool make_tile_map(long lo, long hi, int g, int part, int nstrips, int rs
 	const long rows = hi - lo;
 	// Row bands: 8, one per XCD -- or, for a whole-domain launch that fits the chip in ONE round, the number the tiling
 	// search of hp_domain_create found (pick_tiling: such a launch is bound by its most loaded CU, and 8 x groups x segments
-	// only offers coarse block counts).  HP_NBANDS forces a number (tools/r04_band_sweep.py).
+	// only offers coarse block counts).  HP_NBANDS forces a number (tools/history/r04_band_sweep.py).
 	static const int nbands_env = std::getenv("HP_NBANDS") ? std::atoi(std::getenv("HP_NBANDS")) : 0;
 	tm.nbands = part != PART_ALL ? 8 : (nbands_env >= 1 && nbands_env <= 64 ? nbands_env : (nbands >= 1 && nbands <= 64 ? nbands : 8));
 	tm.band_rows = (int)((rows + tm.nbands - 1) / tm.nbands);
@@ -1277,7 +1277,7 @@ int hp_domain_create(const hp_domain_desc_t* desc, hp_domain_t** out)
 			// tiles of 16 rows on 768 block slots) lasts as long as ONE tile does, so the shortest tile that still fits in one
 			// round wins: 13-row tiles put that strip into 680 blocks (56 -> 51 us per iteration).  Fine-tune within
 			// (rseg/2, rseg] where the halving above left a middle-sized tile; launches of more than one round are left alone
-			// (tools/r03k.sh: 2048^2, 4096 x 1026 and 8192 x 514 lose 0-9 % with shorter tiles).
+			// (tools/history/r03k.sh: 2048^2, 4096 x 1026 and 8192 x 514 lose 0-9 % with shorter tiles).
 			if (refine && rseg >= 8) {
 				const long band_rows = (updated_rows + 7) / 8, slots = (long)cus * blocks_per_cu;
 				auto cost = [&](int r) {

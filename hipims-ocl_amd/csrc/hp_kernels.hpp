@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(march_waves
 //  (no kernel ever writes them).
 //  Cells the reference leaves untouched (quirk Q3).  First step: its destination would keep what it held, and that is what the
 //  second step would read; here the cell's CURRENT state stands in -- on every wet/dry workload tried (S-ROUGH, the dry-bed dam
-//  break, config C1; 1750 iterations of the reference's kernels, tools/r05_q3_stale_probe.py) the two were equal in every such
+//  break, config C1; 1750 iterations of the reference's kernels, tools/history/r05_q3_stale_probe.py) the two were equal in every such
 //  cell at every step.  Second step: the primary buffer keeps state k, and this kernel stores exactly that.
 //  The pass writes into the OTHER buffer; the host then swaps the two pointers (hp_engine.hip: run_pair), so "primary" is again
 //  the buffer that holds the newest state, as after two single iterations.
@@ -1201,7 +1201,7 @@ template <typename T> struct RowU1 { State4<T> c; T zb; bool plain; };      // p
 // a branch of its own per row cost 9-34 %, masked stores 6 %), so it runs where the stale values matter: domains whose boundaries
 // REMOVE water (a loss rate dries whole regions at once, and their cells then sit untouched with stale values in the other buffer), or
 // on request (HP_PAIR_EXACT=1).  Without it a first-step-untouched cell passes its current state on, as in round 5: equal to the stale
-// one in every such cell-iteration of the probes (tools/r05_q3_stale_probe.py: 881 181 of them) -- unless the cell dried that very step.
+// one in every such cell-iteration of the probes (tools/history/r05_q3_stale_probe.py: 881 181 of them) -- unless the cell dried that very step.
 template <bool STRICT, int CFL_MODE, bool BDY, bool HZ, int TAIL, typename T>   // CFL_MODE 1: price what the pair leaves in the primary buffer; 0: fixed timestep
 // (three waves per SIMD: 167 VGPRs and four spilled registers measured 0.193 ms per iteration at 4096^2 against 0.215 at two waves
 // and 171 registers without spills -- profiles/r05n_two_step.txt; -DHP_K1B_WAVES_MIN=2 builds the other one)

@@ -163,13 +163,25 @@ class StripRunner:
     CPU tests substitute an oracle-backed engine; the default builds the HIP engine."""
 
     def __init__(self, cols, rows, scheme=SCHEME_GODUNOV, precision="f64", rank=0, world=1, device=0,
-                 engine_factory=None, backend=None, init_process_group=True, overlap=None, loop=None, exchange_period=1, **kw):
+                 engine_factory=None, backend=None, init_process_group=True, overlap=None, loop=None, exchange_period=None,
+                 area_boundaries=False, **kw):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.cols, self.rows, self.rank, self.world = cols, rows, rank, world
         # ghost rows stored per interior side: one stencil reach, exchanged after every iteration -- or two, exchanged after
-        # every second one by the library's own strip loop (the strip recomputes a reach of its neighbour's rows in between)
+        # every second one by the library's own strip loop (the strip recomputes a reach of its neighbour's rows in between).
+        # None = the best the configuration allows (round 6): two reaches wherever the strips can then run iteration PAIRS -- the HIP
+        # engine under the library's own loop (one GPU per rank), Godunov scheme, FAST arithmetic, the tuned kernel, no area boundaries
+        # to come (`area_boundaries`: the caller's word) -- whether every rank really can is settled by the ranks' handshake at the
+        # start of each batch (hp_strip_step_batch); everything else exchanges after every iteration, as an explicit 1 does.
+        if exchange_period is None:
+            from . import KERNEL_AUTO, MATH_FAST
+            want_loop = loop or os.environ.get("HIPIMS_MI_STRIP_LOOP", "cxx" if (engine_factory is None and (backend or "nccl") == "nccl") else "torch")
+            pairs = (engine_factory is None and (backend or "nccl") == "nccl" and want_loop == "cxx" and world > 1 and scheme == SCHEME_GODUNOV
+                     and kw.get("math_mode", MATH_FAST) == MATH_FAST and kw.get("kernel", KERNEL_AUTO) == KERNEL_AUTO and not area_boundaries
+                     and os.environ.get("HP_TWO_STEP", "") != "0")
+            exchange_period = 2 if pairs else 1
         if exchange_period not in (1, 2):
             raise ValueError("exchange_period must be 1 or 2")
         self.exchange_period = exchange_period

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_two_step.py::test_pairs_fuzz and tools/r05_two_step_soak.sh: random single-domain Godunov configurations
+"""Worker of tests/test_gpu_two_step.py::test_pairs_fuzz and tools/history/r05_two_step_soak.sh: random single-domain Godunov configurations
 (shape, precision, workload, Manning array or not, friction, dx, Courant number, dynamic / fixed timestep, batch pattern with
 downloads, partial uploads, target-time changes, update-timestep calls and checkpoints in between) run on the FAST engine; prints one
 line per seed with a SHA-256 of everything observable.  Run twice (HP_TWO_STEP=0 / 1): the lines must be identical.

@@ -2,7 +2,7 @@
 """Round 4: is the headline launch bimodal (0.247 / 0.257 ms) because of where the buffers land?  One process creates the 4096^2
 domain again and again -- sometimes with a dummy allocation in front that shifts every later address -- and times the same steps."""
 import os, sys, time, ctypes
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "hipims-ocl_amd"))
 os.environ["HIPIMS_MI_NO_TORCH"] = "1"
 import numpy as np

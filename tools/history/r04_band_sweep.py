@@ -3,7 +3,7 @@
 8-band TileMap cannot offer.  Runs itself once per (HP_NBANDS, HP_MARCH_RSEG) in a child process (both are read once).
 usage: r04_band_sweep.py [cols rows]"""
 import os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.join(ROOT, "hipims-ocl_amd"))
     os.environ["HIPIMS_MI_NO_TORCH"] = "1"

@@ -3,7 +3,7 @@
 :69-70 -- no faces, no update; every row is still loaded, stored and priced): the kernel's own memory structure without its arithmetic.
 Against the same launch with arithmetic, and tools/membench's march copy, this says what the arithmetic costs the headline launch."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "hipims-ocl_amd"))
 os.environ["HIPIMS_MI_NO_TORCH"] = "1"
 import numpy as np

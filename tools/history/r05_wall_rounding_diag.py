@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """round 5 diagnostic: where does FAST first leave the oracle on the emerging-bed dam break (and the fp32 walled dam break)?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "hipims-ocl_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np
 import hipims_mi as hp

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hipims-ocl_amd")]
 import hipims_mi as hp  # noqa: E402
 import oracle  # noqa: E402

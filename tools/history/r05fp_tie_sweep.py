@@ -6,7 +6,7 @@ import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 B = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-manning-leg", "--no-moving-leg", "--no-strict-leg",
      "--repeats", "3", "--steps", "400", "--warmup", "40"]
 
