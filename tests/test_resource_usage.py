@@ -54,8 +54,11 @@ def test_spills_and_scratch_stay_within_the_committed_table(built):
         "\n".join(f"  {n}: {w}" for n, w in over)
     assert not strict_spills, f"STRICT instantiations with vector spills that the table does not name: {strict_spills}"
     # the headline kernels' shape is part of the design: three waves per SIMD for the fp64 marches
-    for name in ("hp::godunov_march2<1, 1, double>", "hp::godunov_march<false, 1, false, 1, double, false>"):
+    for name in ("hp::godunov_march2<false, 1, false, false, 1, double>", "hp::godunov_march<false, 1, false, 1, double, false>"):
         assert recs[name]["waves"] == 3, (name, recs[name]["waves"])
+    # ... and the exact flavour of the pair kernel (round 6) spills no vector register at all: two waves per SIMD in fp64, three in fp32
+    for name, waves in (("hp::godunov_march2<true, 1, false, true, 1, double>", 2), ("hp::godunov_march2<true, 1, false, true, 1, float>", 3)):
+        assert recs[name]["vgpr_spill"] == 0 and recs[name]["scratch"] == 0 and recs[name]["waves"] == waves, (name, recs[name])
 
 
 def test_no_register_of_a_16_byte_store_is_written_inside_the_hazard_window(built, tmp_path):
