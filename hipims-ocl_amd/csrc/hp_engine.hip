@@ -558,6 +558,14 @@ int launch_march(hp_domain* d, const void* src, void* dst, int edge_buffer, int 
 		if (tail_kind == 1) HP_LAUNCH_K1S(false, 1, (const AreaBdyList<T>*)nullptr, 0, CAN_SPEC);
 		else                HP_LAUNCH_K1S(false, 0, (const AreaBdyList<T>*)nullptr, 0, CAN_SPEC);
 	} else
+#ifdef HP_KEEP_SPEC_FUSED
+	// (the instantiation round 5 deleted -- the speculative flavour with FUSED boundaries, LAB_NOTES R5.13 -- kept buildable for the
+	// study of what went wrong with it: a library built with -DHP_KEEP_SPEC_FUSED speculates on such domains too)
+	if (CAN_SPEC && d->spec_now && d->fusable && tail_kind != 2 && part == PART_ALL) {
+		if (tail_kind == 1) HP_LAUNCH_K1S(true, 1, (const AreaBdyList<T>*)d->fused_list, d->fuse_next, CAN_SPEC);
+		else                HP_LAUNCH_K1S(true, 0, (const AreaBdyList<T>*)d->fused_list, d->fuse_next, CAN_SPEC);
+	} else
+#endif
 	if (d->fusable) {
 		if (tail_kind == 2)      HP_LAUNCH_K1(true, 2, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
 		else if (tail_kind == 1) HP_LAUNCH_K1(true, 1, (const AreaBdyList<T>*)d->fused_list, d->fuse_next);
@@ -1924,7 +1932,12 @@ bool spec_wanted(const hp_domain* d, uint32_t n)
 	// 1e-4, no word raised; the same source built for two waves per SIMD, without the vector spills, is exact again:
 	// profiles/r05fg_spec_fused_tail_miscompare.txt).  A 2-3 % experiment is not worth an instantiation that only holds while the
 	// register allocator is lucky: such domains run the plain STRICT kernels.
-	return enabled && n >= SPEC_MIN && d->desc.math_mode == HP_MATH_STRICT && d->desc.precision == 8 && !d->comm && !d->fusable &&
+#ifdef HP_KEEP_SPEC_FUSED
+	const bool fusable_ok = true;
+#else
+	const bool fusable_ok = !d->fusable;
+#endif
+	return enabled && n >= SPEC_MIN && d->desc.math_mode == HP_MATH_STRICT && d->desc.precision == 8 && !d->comm && fusable_ok &&
 	       d->desc.kernel != HP_KERNEL_BASIC && (d->desc.scheme == HP_SCHEME_GODUNOV || d->desc.scheme == HP_SCHEME_MUSCL_HANCOCK);
 }
 int spec_begin(hp_domain* d)

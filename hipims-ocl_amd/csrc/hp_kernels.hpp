@@ -522,9 +522,12 @@ __device__ __forceinline__ float buf_load_scalar(__amdgpu_buffer_rsrc_t r, const
 // words values of their own first: defined by an (empty) asm, they have no other copy the fence could be fed from, so keeping them
 // alive to the fence means keeping the store's registers.  The build's assembly is scanned for the pattern on every build
 // (tests/test_resource_usage.py): a store whose data or offset register is written inside the window fails the CPU suite.
+#ifndef HP_STORE_OPERANDS_OWN
+#define HP_STORE_OPERANDS_OWN 1         // 0: round 5's stores (the study of LAB_NOTES R6.x builds both)
+#endif
 __device__ __forceinline__ void store_operands_own(hp_u32x4& a)
 {
-	asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+	if (HP_STORE_OPERANDS_OWN) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
 }
 __device__ __forceinline__ void store_fence(const hp_u32x4& a, const unsigned voff, const unsigned soff)
 {
