@@ -843,7 +843,10 @@ static bool pairs_possible_common(const hp_domain* d)
 	// the pair kernel applies them between its two steps and prices the state it stores with and without the next iteration's
 	// (godunov_march2, BDY); single domains only.  HP_PAIR_BDY=0 keeps such domains on single iterations (A/B runs).
 	static const bool bdy_enabled = !(std::getenv("HP_PAIR_BDY") && std::atoi(std::getenv("HP_PAIR_BDY")) == 0);
-	const bool bdy_ok = d->bdy.empty() || (bdy_enabled && d->fusable && !d->comm && d->comm_world <= 1 && d->desc.dynamic_dt);
+	// (fp32: from 30 M cells on -- S-RAIN 4096^2 fp32 LOSES 3 % in pairs, 0.1436 -> 0.1478 ms, where fp64 gains 7.5 % and 8192^2 gains 8-9 %
+	// in both precisions: profiles/r06w_srain_pairs_by_size.txt; HP_TWO_STEP=1 overrides)
+	const bool bdy_size_ok = d->desc.precision == 8 || d->cells >= 30000000 || mode > 0;
+	const bool bdy_ok = d->bdy.empty() || (bdy_enabled && bdy_size_ok && d->fusable && !d->comm && d->comm_world <= 1 && d->desc.dynamic_dt);
 	// STRICT (round 6): the same statements in the same order as K1's, so the pair is the same computation there too -- always with
 	// the stamps (the exact mode promises the reference's bits); no boundaries, single domains, dynamic timestep.  What it is for: rows
 	// of still water are a copy in STRICT (K1's skip), and a pair copies them at half the bytes.  HP_PAIR_STRICT=0 switches it off.

@@ -1483,7 +1483,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 				const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0); // :214-218
 				const bool dry5 = dryC && dryN && dryE && drySa && dryW;               // :248-255 (untouched: see PairAux)
 				const State4<T> upd = godunov_update<STRICT>(rc.c, rc.zb, rc.n, dt_a, fy.forL, fx.forL, fSa, fW, p.dx, inv_dx, vs, with_friction);
-				const bool touched = !(ring_x || disabled || dry5);
+				// (lanes 0 and 63 have no west / east neighbour of their own -- the rotate hands them a cell from the far end of the wavefront --
+				// and nothing reads what the first step makes of them except stage B's wave-wide votes: they keep their source state, a real
+				// cell of the row, instead of an update from a foreign flux that on a thin film drains them dry and sends every wavefront of
+				// the second step down the dry-side paths.  S-RAIN 8192^2 fp32: 640 M -> see profiles/r06u_* VALU per pair)
+				const bool touched = !(ring_x || disabled || dry5 || lane == 0 || lane == 63);
 				if (touched) { u.c = upd; u.plain = false; }
 				// untouched by the reference (Q3): its destination keeps the state of the iteration before the pair.  That is the cell's
 				// current state -- unless the launch before said otherwise

@@ -343,20 +343,23 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples);   
 /* The cost of an empty event pair that the last hp_kernel_timing() measured and hp_kernel_timing_read() takes off every
  * sample (raw average = avg_ms + this): reported so that lines with and without the correction can be compared. */
 int hp_kernel_timing_overhead(hp_domain_t* d, double* overhead_ms);
-/* (Round 5: where it is the same computation -- Godunov scheme, FAST arithmetic, single domain, no boundary conditions, quirk Q1 on,
- * a grid of at least two rounds of blocks -- hp_step_batch runs PAIRS of iterations as one launch each (hp_kernels.hpp:
- * godunov_march2; bit-identical to the single iterations, half the HBM traffic).  HP_TWO_STEP=0 / 1 in the environment forces it
- * off / on.  Everything observable through this interface is the same either way; hp_launch_counts shows which ran.) */
+/* Iteration PAIRS.  Where it is the same computation -- Godunov scheme, the tuned kernel, quirk Q1 on, no boundary conditions or only
+ * area boundaries the flux kernel can carry (hp_boundaries_fused), a grid of about a round of blocks and more -- hp_step_batch runs two
+ * iterations as ONE launch (hp_kernels.hpp: godunov_march2; half the HBM traffic).  Everything observable through this interface is what
+ * single iterations leave, with ONE condition in FAST arithmetic: a cell the reference leaves untouched at a pair's first step (quirk Q3,
+ * CLSchemeGodunov.clc:248-255) passes its current state on where the reference keeps the stale one of the iteration before -- different
+ * only if the cell dried out that very step.  The EXACT flavour writes those stale values down between launches (4-9 % slower) and runs
+ * where they matter: STRICT arithmetic always, domains whose boundaries remove water (loss rate, mass flux), and on request.
+ *   HP_TWO_STEP=0 / 1    pairs off / on wherever eligible (default: by grid size; STRICT: by the engine's own measurement, the two being
+ *                        the same bits)                    HP_PAIR_EXACT=0 / 1   the exact flavour nowhere / everywhere
+ *   HP_PAIR_BDY=0        domains with area boundaries keep single iterations      HP_PAIR_STRICT=0   so does STRICT arithmetic
+ * hp_launch_counts and hp_pair_stats show what ran. */
 /* How many whole-domain flux launches the domain has queued since it was created, and how many of them carried their own tail
  * block (reduction + time advance inside the flux launch: an iteration is then ONE launch; otherwise the flux launch is followed
  * by an advance launch).  bench.py states its roofline basis from the difference of two readings around the timed region. */
 int hp_launch_counts(hp_domain_t* d, uint64_t* flux_launches, uint64_t* with_tail);
 
-/* (Round 6: pairs also run on domains whose boundary conditions are area boundaries the flux kernel can carry -- hp_boundaries_fused --
- * and quirk Q3 holds across pair launches EXACTLY: a cell the reference leaves untouched at a pair's first step keeps what its
- * destination buffer held (CLSchemeGodunov.clc:248-255), a value that never leaves the registers when pairs follow each other -- the
- * launch before writes it down ("stamps" it) for the cells that could need it, hp_kernels.hpp: PairAux.)
- * Diagnostics of that machinery, for tests and A/B runs; blocks.  out[0] iteration pairs run, out[1] pairs that started cold on a
+/* Diagnostics of the iteration pairs, for tests and A/B runs; blocks.  out[0] iteration pairs run, out[1] pairs that started cold on a
  * domain with area boundaries (stand-alone boundary pass + reduction in front: after single iterations, an upload, a new target
  * time), out[2] cells stamped by the LAST pair launch, out[3] cells that carry a stamp of any launch; the exact mode's choice between
  * pairs and single iterations (the same bits; chosen by measurement, hp_engine.hip: tuner_poll): out[4] samples taken, out[5] changes
