@@ -63,10 +63,12 @@ def pmc_counters(kernel_substr, stem):
     return best
 
 
-SIMDS, CLOCK_HZ, CYCLES_PER_WAVE_INSTRUCTION = 1024, 2.4e9, 4      # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 vector instruction issues over 2 cycles in fp32 (32 lanes per cycle; `v_fma_f32`
+# 2 cyc with several waves on the SIMD) and over 4 in fp64 (half rate; measured 4.3 per fp64 wave-instruction by the round-5 profiles)
+SIMDS, CLOCK_HZ, CYCLES_PER_WAVE_INSTRUCTION = 1024, 2.4e9, {"f64": 4, "f32": 2}
 
 
-def attach_pmc(roof, kernel_substr, stem):
+def attach_pmc(roof, kernel_substr, stem, precision="f64"):
     """`traffic` (measured HBM GB/s) and the two fractions that say what bounds the kernel, from the committed PMC summary of the same
     command: hbm_frac_measured = traffic / peak (what the HBM interface really sees; `frac` is ALGORITHMIC bytes per second, SURVEY
     8(d)'s 80 B per cell-step, and exceeds it where a launch covers two iterations), valu_issue_frac = the share of the launch the
@@ -81,7 +83,8 @@ def attach_pmc(roof, kernel_substr, stem):
     roof["hbm_frac_measured"] = roof["traffic"] / HBM_PEAK_GBS
     if c.get("valu"):
         roof["valu_instructions_per_launch"] = c["valu"]
-        roof["valu_issue_frac"] = c["valu"] * CYCLES_PER_WAVE_INSTRUCTION / (SIMDS * CLOCK_HZ) / (k_ms * 1e-3)
+        roof["valu_cycles_per_wave_instruction"] = CYCLES_PER_WAVE_INSTRUCTION[precision]
+        roof["valu_issue_frac"] = c["valu"] * CYCLES_PER_WAVE_INSTRUCTION[precision] / (SIMDS * CLOCK_HZ) / (k_ms * 1e-3)
 
 
 def usable_cores():
@@ -556,13 +559,14 @@ def main():
                                    "kernel": rw["kernel"], "sim_time_s": moving_leg["sc"]["time"]}
         def extra_leg(what, a, leg, stem, kernel_substr):
             r = roofline_of(a, leg)
-            attach_pmc(r, kernel_substr, stem)
+            attach_pmc(r, kernel_substr, stem, a.precision)
             n = leg["cols"] * leg["rows"]
             e = {"what": what + ": " + workload_of(a, leg), "value": n * a.steps / leg["elapsed"] / 1e6, "unit": "Mcell-steps/s",
                  "dtype": a.precision, "ms_per_step": leg["elapsed"] / a.steps * 1e3,
                  "timed_steps": [a.warmup + a.evolve_steps, a.warmup + a.evolve_steps + a.steps], "sim_time_s": leg["sc"]["time"]}
             for key in ("frac", "achieved", "kernel", "frac_basis", "avg_launch_ms", "frac_event_sampled", "launches_sampled", "iterations_per_launch",
-                        "algorithmic_bytes_per_cell_step", "frac_of_bytes_launch_must_move", "traffic", "traffic_source", "hbm_frac_measured", "valu_issue_frac"):
+                        "algorithmic_bytes_per_cell_step", "frac_of_bytes_launch_must_move", "traffic", "traffic_source", "hbm_frac_measured", "valu_issue_frac",
+                        "valu_cycles_per_wave_instruction"):
                 if key in r:
                     e[key] = r[key]
             if leg.get("fused") is not None:
@@ -580,7 +584,7 @@ def main():
         if default_cfg:
             # (the pair kernel's name when launches covered two iterations: hp::godunov_march2<...>)
             attach_pmc(out["roofline"], "godunov_march2<" if out["roofline"]["iterations_per_launch"] == 2 else args.scheme + "_march<false",
-                       args.scheme + "4096")
+                       args.scheme + "4096", args.precision)
         if not args.no_cpu_baseline and world == 1:
             scheme = {"godunov": hp.SCHEME_GODUNOV, "muscl": hp.SCHEME_MUSCL_HANCOCK, "inertial": hp.SCHEME_INERTIAL}[args.scheme]
             out["cpu_baseline"] = cpu_baseline(main_leg["cols"], args.precision, scheme, main_leg["levels"])
