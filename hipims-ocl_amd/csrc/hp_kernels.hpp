@@ -1212,7 +1212,17 @@ template <bool STRICT, int CFL_MODE, bool BDY, bool HZ, int TAIL, typename T>   
 #define HP_K1B_WAVES_MIN 3
 #endif
 // (STRICT: two waves per SIMD in fp64, three in fp32 -- no vector register of the exact flavour is spilled: tests/test_resource_usage.py)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (STRICT ? 3 : 4) : (STRICT ? 2 : HP_K1B_WAVES_MIN), sizeof(T) == 4 ? (STRICT ? 3 : 5) : (STRICT ? 2 : 3)))) void godunov_march2(
+// (fp32: FIVE waves per SIMD, 96 VGPRs -- against the 4-5 of round 5, where the allocator settled for four: C5's shape 8192^2 S-RAIN 0.5003 ->
+// 0.4795 ms, S-DAM 4096^2 fp32 0.1062 -> 0.1005; three waves 0.560 / 0.118, six (80 VGPRs, 29-78 spilled) 0.775 / 0.152 --
+// profiles/r06x_f32_pair_waves.txt.  The fp32 march is bound by latency, not by issue: a vector instruction takes it two cycles.)
+#ifndef HP_K1B_F32_WAVES_MIN
+#define HP_K1B_F32_WAVES_MIN 5
+#endif
+#ifndef HP_K1B_F32_WAVES_MAX
+#define HP_K1B_F32_WAVES_MAX 5
+#endif
+// (the exact flavour, HZ, keeps round 5's four: at five its fp32 instantiations spill 20-70 vector registers)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (STRICT ? 3 : (HZ ? 4 : HP_K1B_F32_WAVES_MIN)) : (STRICT ? 2 : HP_K1B_WAVES_MIN), sizeof(T) == 4 ? (STRICT ? 3 : HP_K1B_F32_WAVES_MAX) : (STRICT ? 2 : 3)))) void godunov_march2(
 	const Params<T> p, const Scalars<T>* sc, const T* __restrict__ bed, const State4<T>* __restrict__ src,
 	State4<T>* __restrict__ dst, const T* __restrict__ manning, T* cfl_slot, const T* __restrict__ edge_max,
 	const TileMap tm, const LaunchTail<T> tail, const PairAux<T> aux)

@@ -41,3 +41,8 @@ line "S-RAIN 8192x1026 godunov f32 strip (C5 share)" --workload s-rain --precisi
 HP_PAIR_EXACT=1 line "S-DAM 4096^2 godunov f64, every pair exact" 
 HP_PAIR_EXACT=1 line "S-ROUGH 4096^2 godunov f64, every pair exact" --workload s-rough
 } | tee $OUT/workloads.txt
+# the strong-scaling strip: alone, and cut in two with thread ranks over the strips' own transport (pairs: two reaches of ghost rows)
+{ echo "== tools/strong_probe.py (one rank's share of 4096^2 / 8, batch call and strip loop)"; timeout 600 python tools/strong_probe.py 2>&1 | grep -v amdgpu.ids | tail -12;
+  echo "== PERIOD=2 tools/strong_probe.py"; PERIOD=2 timeout 600 python tools/strong_probe.py 2>&1 | grep -v amdgpu.ids | tail -12;
+  echo "== tools/strong_probe_pair.py"; timeout 600 python tools/strong_probe_pair.py 2>&1 | grep -v amdgpu.ids | tail -12; } > $OUT/strong_probes.txt 2>&1
+tail -5 $OUT/strong_probes.txt
