@@ -177,15 +177,16 @@ def test_default_takes_pairs_on_big_grids_only(tmp_path):
 
 
 def test_pairs_fuzz():
-    """Forty random configurations -- shapes from 5 x 5 to 1500 x 1100, both precisions, dam breaks and wet/dry terrain with
-    null cells, Manning arrays, friction on / off, fixed and dynamic timestep, batches of random length with downloads, partial
-    uploads, new target times, tst_UpdateTimestep and checkpoints in between: pairs forced on against pairs off, every
+    """Forty random configurations -- shapes from 5 x 5 to 1500 x 1100, both precisions, FAST and (round 6) now and then STRICT, dam breaks
+    and wet/dry terrain with null cells, Manning arrays, friction on / off, fixed and dynamic timestep, (round 6) uniform rain / a loss
+    rate / gridded rain / a mass flux in random combination, batches of random length with downloads, partial
+    uploads, new target times, tst_UpdateTimestep and checkpoints in between: pairs forced on (exact flavour) against pairs off, every
     observable (states at every download, time, timestep, counters) hashed -- the two runs must print the same lines."""
     worker = os.path.join(os.path.dirname(__file__), "two_step_fuzz_worker.py")
     outs = []
     for mode in ("0", "1"):
         r = subprocess.run([sys.executable, worker, "500", "40"], capture_output=True, text=True, timeout=900,
-                           env=dict(os.environ, HP_TWO_STEP=mode))
+                           env=dict(os.environ, HP_TWO_STEP=mode, HP_PAIR_EXACT="1"))
         assert r.returncode == 0, r.stdout + r.stderr
         lines = [l for l in r.stdout.splitlines() if l.startswith("seed ")]
         assert len(lines) == 40
@@ -193,4 +194,4 @@ def test_pairs_fuzz():
     strip = lambda l: l.split("  # ")[0]
     assert [strip(l) for l in outs[0]] == [strip(l) for l in outs[1]]
     launches = lambda ls: sum(int(l.split("launches ")[1]) for l in ls)
-    assert launches(outs[1]) < 0.8 * launches(outs[0])                      # (and pairs really ran)
+    assert launches(outs[1]) < 0.85 * launches(outs[0])                     # (and pairs really ran)

@@ -1,7 +1,7 @@
 """Worker of tests/test_gpu_two_step.py::test_pairs_fuzz and tools/history/r05_two_step_soak.sh: random single-domain Godunov configurations
 (shape, precision, workload, Manning array or not, friction, dx, Courant number, dynamic / fixed timestep, batch pattern with
 downloads, partial uploads, target-time changes, update-timestep calls and checkpoints in between) run on the FAST engine; prints one
-line per seed with a SHA-256 of everything observable.  Run twice (HP_TWO_STEP=0 / 1): the lines must be identical.
+line per seed with a SHA-256 of everything observable.  Run twice (HP_TWO_STEP=0 / 1, the latter with HP_PAIR_EXACT=1: quirk Q3's stamps on every domain): the lines must be identical.
 usage: two_step_fuzz_worker.py <first seed> <count>"""
 import hashlib
 import os
@@ -38,8 +38,23 @@ for seed in range(first, first + count):
     kw = dict(dx=float(rng.choice([0.5, 1.0, 2.0, 3.0])), courant=float(rng.choice([0.3, 0.5])), friction=bool(rng.random() < 0.8))
     if rng.random() < 0.2:
         kw.update(dynamic_dt=False, dt_fixed=float(rng.choice([0.002, 0.01])))
-    dom = hp.Domain(cols, rows, precision=precision, math_mode=hp.MATH_FAST, **kw)
+    # (round 6) the exact mode now and then (STRICT pairs), and area boundaries -- uniform rain, a loss rate, coarse gridded rain, a mass
+    # flux, alone or together, with series short enough to change slice inside a run (pairs with boundaries: godunov_march2 BDY)
+    strict = rng.random() < 0.2
+    with_bdy = rng.random() < 0.45
+    if with_bdy and "dt_fixed" in kw:
+        kw.pop("dynamic_dt"); kw.pop("dt_fixed")
+    dom = hp.Domain(cols, rows, precision=precision, math_mode=hp.MATH_STRICT if strict else hp.MATH_FAST, **kw)
     dom.upload(st, bed, man)
+    if with_bdy:
+        if rng.random() < 0.7:
+            dom.add_uniform(hp.UNIFORM_RAIN_INTENSITY, np.array([[0.0, float(rng.uniform(50, 900))], [0.7, float(rng.uniform(0, 300))], [1.4, 0.0], [2.1, 0.0]]), 0.7, 2.1)
+        if rng.random() < 0.4:
+            dom.add_uniform(hp.UNIFORM_LOSS_RATE, np.array([[0.0, float(rng.uniform(100, 2000))], [100.0, 0.0]]), 100.0, 100.0)
+        if rng.random() < 0.5:
+            res = float(rng.choice([64, 80, 200])) * kw["dx"]
+            grids = rng.uniform(0.0, 600.0, (3, int(rows * kw["dx"] / res) + 2, int(cols * kw["dx"] / res) + 2))
+            dom.add_gridded(hp.GRIDDED_RAIN_INTENSITY if rng.random() < 0.7 else hp.GRIDDED_MASS_FLUX, grids if rng.random() < 0.7 else grids * 1e-4, res, 0.0, 0.0, float(rng.choice([0.5, 3.0])))
     dom.set_target_time(float(rng.choice([1e9, 0.6, 2.0])))
     h = hashlib.sha256()
     blown = False                                    # a fixed timestep beyond the CFL limit ends in NaNs: where they sit and what their payloads are is not held to anything
@@ -78,5 +93,5 @@ for seed in range(first, first + count):
         np.savez(os.path.join(dump, f"seed{seed}_{os.environ.get('HP_TWO_STEP', 'x')}.npz"), ops=np.array([t[0] for t in trace]),
                  times=np.array([t[1]["time"] for t in trace]), dts=np.array([t[1]["timestep"] for t in trace]),
                  its=np.array([t[1]["iterations"] for t in trace]), states=np.stack([t[2] for t in trace]))
-    print(f"seed {seed} {precision} {cols}x{rows} kind {kind} iterations {sc['iterations']} t {sc['time']!r} {'non-finite-state-not-compared' if blown else h.hexdigest()}  # launches {counts[0]}")
+    print(f"seed {seed} {precision}{' strict' if strict else ''}{' bdy' if with_bdy else ''} {cols}x{rows} kind {kind} iterations {sc['iterations']} t {sc['time']!r} {'non-finite-state-not-compared' if blown else h.hexdigest()}  # launches {counts[0]}")
     dom.close()
