@@ -2864,7 +2864,7 @@ int hp_kernel_timing_read(hp_domain_t* d, double* avg_ms, uint32_t* samples)
 	return HP_OK;
 }
 
-int hp_pair_stats(hp_domain_t* d, uint64_t out[8])
+int hp_pair_stats(hp_domain_t* d, uint64_t out[12])
 {
 	int rc = check_domain(d);
 	if (rc != HP_OK) return rc;
@@ -2874,6 +2874,12 @@ int hp_pair_stats(hp_domain_t* d, uint64_t out[8])
 	if (tuner_on(d) && (rc = tuner_poll(d)) != HP_OK) return rc;
 	out[4] = d->tune_samples; out[5] = d->tune_switches; out[6] = d->tune_prefer_pairs ? 1 : 0;
 	out[7] = d->tune_single_ms > 0.f ? (uint64_t)(1000.0 * d->tune_pair_ms / d->tune_single_ms) : 0;
+	out[8] = out[9] = out[10] = out[11] = 0;
+	if (d->haz_words) {
+		unsigned long long used = 0;
+		HIP_TRY(hipMemcpy(&used, d->haz_words + 2, sizeof used, hipMemcpyDeviceToHost));
+		out[8] = used;
+	}
 	if (!d->z_state) return HP_OK;
 	const size_t rec = (size_t)4 * d->esize + 16;
 	std::vector<char> recs(d->cells * rec);

@@ -1504,7 +1504,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 				if (LOOK && wave_any(dry5 && !ring_x && !disabled)) {
 					if (dry5 && !ring_x && !disabled) {
 						const size_t id = (size_t)r * p.cols + xc;
-						if (stamp_gen(aux.stamps, id) == aux.prev_gen) { u.c = stamp_state(aux.stamps, id); u.plain = false; }
+						if (stamp_gen(aux.stamps, id) == aux.prev_gen) {
+							const State4<T> kept = stamp_state(aux.stamps, id);
+							// (audit: a stale value that is NOT the cell's current state -- what the flavour without stamps would have got wrong)
+							if (kept.z != u.c.z || kept.zmax != u.c.zmax || kept.qx != u.c.qx || kept.qy != u.c.qy) atomicAdd(aux.stamps.haz + 2, 1ull);
+							u.c = kept; u.plain = false;
+						}
 					}
 				}
 			}

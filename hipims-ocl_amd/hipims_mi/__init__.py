@@ -501,11 +501,11 @@ class Domain:
         """Diagnostics of the iteration pairs (hp_pair_stats): dict(pairs, cold_starts, stamped_last, stamped_ever); blocks."""
         if not hasattr(self.lib, "hp_pair_stats"):
             return None
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 12)()
         self.lib.hp_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _check(self.lib, self.lib.hp_pair_stats(self.h, out), "hp_pair_stats")
         return dict(pairs=out[0], cold_starts=out[1], stamped_last=out[2], stamped_ever=out[3], tune_samples=out[4],
-                    tune_switches=out[5], prefers_pairs=bool(out[6]), pair_over_single=out[7] / 1000.0)
+                    tune_switches=out[5], prefers_pairs=bool(out[6]), pair_over_single=out[7] / 1000.0, stale_used=out[8])
 
     def kernel_timing_overhead(self):
         """Cost of an empty event pair (ms) that kernel_timing_read() has taken off every sample (0.0 with a library that

@@ -363,8 +363,10 @@ int hp_launch_counts(hp_domain_t* d, uint64_t* flux_launches, uint64_t* with_tai
  * domain with area boundaries (stand-alone boundary pass + reduction in front: after single iterations, an upload, a new target
  * time), out[2] cells stamped by the LAST pair launch, out[3] cells that carry a stamp of any launch; the exact mode's choice between
  * pairs and single iterations (the same bits; chosen by measurement, hp_engine.hip: tuner_poll): out[4] samples taken, out[5] changes
- * of mind, out[6] 1 if pairs are the current choice, out[7] the last sample's pair time over its two single iterations' time, x 1000. */
-int hp_pair_stats(hp_domain_t* d, uint64_t out[8]);
+ * of mind, out[6] 1 if pairs are the current choice, out[7] the last sample's pair time over its two single iterations' time, x 1000;
+ * out[8] (exact flavour) stale values taken from a stamp that DIFFERED from the cell's current state -- the cells the flavour without
+ * stamps would have got wrong on this run (0: it would have left the same bits); out[9..11] reserved. */
+int hp_pair_stats(hp_domain_t* d, uint64_t out[12]);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ counts = dom.launch_counts()
 ps = dom.pair_stats() or dict(pairs=0, cold_starts=0, stamped_last=0, stamped_ever=0)
 np.savez(out, state=final, t=sc["time"], dt=sc["timestep"], ok=sc["batch_successful"], skipped=sc["batch_skipped"],
          iterations=sc["iterations"], launches=counts[0], pairs=ps["pairs"], cold_starts=ps["cold_starts"], stamped_ever=ps["stamped_ever"],
-         tune_samples=ps.get("tune_samples", 0), prefers_pairs=ps.get("prefers_pairs", True), pair_over_single=ps.get("pair_over_single", 0.0))
+         tune_samples=ps.get("tune_samples", 0), prefers_pairs=ps.get("prefers_pairs", True), pair_over_single=ps.get("pair_over_single", 0.0),
+         stale_used=ps.get("stale_used", 0))
 dom.close()
 print(f"{scenario} {precision}: t = {sc['time']!r}, iterations {sc['iterations']}, flux launches {counts[0]}")
