@@ -236,6 +236,9 @@ def test_bench_multi_rank_branch_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["value"] > 0
     assert "REHEARSAL" in d["config"]["parallelism"] and "cpu_baseline" not in d
+    # (round 6: the line says how many iterations go between ghost-row exchanges; a rehearsal -- host-staged transport, the torch loop --
+    # exchanges after every one; under RCCL with the library's own loop eligible strips take two and run iteration pairs)
+    assert "1 iteration(s) per ghost-row exchange" in d["config"]["parallelism"]
     # the strong leg is the line's value: the metric's grid (here 512 x 512) cut into two strips
     assert d["scaling"] == "strong" and "512x512" in d["config"]["workload"] and d["config"]["cells_per_gpu"] == 512 * 256
     assert d["config"]["successful_iterations"] == 35 and d["roofline"]["cells_per_launch"] == 512 * (256 + 1)

@@ -155,6 +155,20 @@ def test_default_pairs_with_rain(scenario, precision, tmp_path):
     print(f"default pairs with {scenario} {precision}: depth RMSE vs single iterations {rmse:.3e} m, equal bits: {np.array_equal(pairs['state'], single['state'])}")
 
 
+def test_config_c1_in_pairs_is_config_c1_in_single_iterations(tmp_path):
+    """Config C1 -- the reference's example model, uniform rain + uniform drainage on its own DEM -- 2000 iterations in FAST arithmetic with
+    pairs forced (the grid is far below the size from which pairs pay; the loss rate makes them the exact flavour by default) against
+    single iterations: every bit of the state, the time, the timestep.  Its cells dry out under the drainage all the time: the stamps
+    are written by the thousand and stale values that differ from the current state are really taken (the audit counter)."""
+    single, pairs = run("c1", "f64", tmp_path, 0), run("c1", "f64", tmp_path, 1)
+    assert int(pairs["launches"]) < int(pairs["iterations"]) * 0.62 and int(pairs["iterations"]) == 2000
+    for key in ("t", "dt", "ok", "skipped"):
+        assert pairs[key] == single[key], key
+    assert np.array_equal(pairs["state"], single["state"])
+    assert int(pairs["stamped_ever"]) > 0
+    print(f"c1: stamps on {int(pairs['stamped_ever'])} cells, stale values that differed and were taken: {int(pairs['stale_used'])}, cold starts {int(pairs['cold_starts'])}")
+
+
 def test_the_stamps_are_what_makes_pairs_exact_where_cells_dry_out(tmp_path):
     """Quirk Q3 across pair launches (hp_kernels.hpp: PairAux).  A cell the reference leaves untouched at a pair's first
     step keeps the value of the iteration before the pair -- which only the launch before ever had.  Where the loss rate dries whole

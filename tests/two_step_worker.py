@@ -38,6 +38,18 @@ elif scenario in ("tune_dam", "tune_rough"):   # big enough for pairs by default
     cols, rows = 2048, 1500
     st, bed, man = (syn.s_dam(cols, rows, dtype=real) if scenario == "tune_dam" else syn.s_rough(cols, rows, dtype=real, manning=0.03))
     plan = [("run", 30), ("run", 21), ("run", 40), ("download",), ("run", 30)]     # (a sample takes a batch of twelve iterations or more)
+elif scenario == "c1":                       # config C1, the reference's example model (rain 70 mm/h + drainage 12 mm/h on its own DEM), through the front end
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hipims_mi import frontend
+    from model_dir import make_newcastle
+    import pathlib
+    cfg = frontend.parse_configuration(make_newcastle(pathlib.Path(tempfile.mkdtemp(prefix="c1_"))))
+    st, bed, man, res = frontend.build_domain(cfg)
+    cols, rows = 342, 195
+    st, bed, man = st.astype(real), bed.astype(real), man.astype(real)
+    kw = dict(dx=res, t_end=cfg.duration)
+    plan = [("c1bdy",), ("run", 512), ("run", 512), ("download",), ("run", 511), ("run", 465)]
 elif scenario == "rainlater":               # pairs first, then a rain boundary arrives: the first single iteration behind the pairs is K1 with FUSED
     cols, rows = 500, 333                   # boundaries AND the FILL flag (the buffer it writes is two states old); dry land keeps untouched cells
     st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=0.03)
@@ -73,6 +85,9 @@ for step in plan:
     elif step[0] == "target":
         # (None: a sync point a little ahead of wherever the run is -- clipped and suspended iterations inside the next batch)
         dom.set_target_time(step[1] if step[1] is not None else dom.read_scalars()["time"] * 1.02 + 0.5)
+    elif step[0] == "c1bdy":
+        frontend.attach_boundaries(cfg, dom, cols)
+        assert dom.boundaries_fused()
     elif step[0] == "settime":
         dom.set_time(step[1])
     elif step[0] == "bdy":
