@@ -181,6 +181,14 @@ class StripRunner:
             pairs = (engine_factory is None and (backend or "nccl") == "nccl" and want_loop == "cxx" and world > 1 and scheme == SCHEME_GODUNOV
                      and kw.get("math_mode", MATH_FAST) == MATH_FAST and kw.get("kernel", KERNEL_AUTO) == KERNEL_AUTO and not area_boundaries
                      and os.environ.get("HP_TWO_STEP", "") != "0")
+            if pairs:
+                # (two reaches belong to the library's own loop: without the collective library -- every rank finds that out the same
+                # way -- the run falls back to the torch loop below, which exchanges after every iteration)
+                from . import HipimsError, comm_load
+                try:
+                    comm_load()
+                except HipimsError:
+                    pairs = False
             exchange_period = 2 if pairs else 1
         if exchange_period not in (1, 2):
             raise ValueError("exchange_period must be 1 or 2")
