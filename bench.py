@@ -211,7 +211,7 @@ def variant(args, **kw):
     return argparse.Namespace(**{**vars(args), **kw})
 
 
-def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=False, repeats=None, last=True, workload=None):
+def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=False, repeats=None, last=True, workload=None, force_period=None):
     """One timed leg: build this rank's runner for a `cols x rows` grid cut into `world` strips, load the workload, pre-warm,
     then `repeats` x (restore, W warm-up steps, EXACTLY K timed steps between barrier + device sync); median repeat.
     Returns what rank 0 needs for the line (every rank gets the same timing numbers: max over ranks)."""
@@ -236,7 +236,7 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
         # library's own loop, no area boundaries: hipims_mi/strips.py) -- the weak-scaling shape gains 20 % on one GPU, the 4096 x 514
         # strong-scaling strip 10 % -- one reach otherwise; --exchange-period 1 / 2 forces
         runner = StripRunner(cols, rows, dx=dx, scheme=scheme, precision=args.precision, math_mode=math_mode, kernel=kernel,
-                             device=device, rank=rank, world=world, backend=backend, exchange_period=(args.exchange_period or None),
+                             device=device, rank=rank, world=world, backend=backend, exchange_period=(force_period or args.exchange_period or None),
                              area_boundaries=(workload == "s-rain"))
     if workload == "s-rain":
         # built in row blocks (the float64 intermediates of 8192^2 at once are 6 GB and most of the leg's wall time)
@@ -316,6 +316,15 @@ def run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=F
     #      channel, whatever transport the strip loop used (RCCL send/receive, or the strips' direct writes over xGMI) ----
     if world > 1:
         bad = runner.verify_ghost_rows()
+        if bad and args.exchange_period == 0 and force_period is None and getattr(runner, "exchange_period", 1) == 2:
+            # the automatic choice -- two reaches of ghost rows, iteration pairs on the strips, a path no multi-GPU node had run before
+            # this line was written -- did not verify (the same verdict on every rank: verify_ghost_rows is collective): the leg is run
+            # again on the transport every earlier probe used, and the line says so
+            runner.close(destroy_group=False)
+            leg = run_leg(args, hp, cols, rows, world, rank, local_rank, math, manning_array=manning_array, repeats=repeats, last=last,
+                          workload=workload, force_period=1)
+            leg["exchange_fallback"] = f"two reaches + iteration pairs: {bad} ghost-row cells differed from their owners' after the timed batch; re-run with one reach"
+            return leg
         if bad:
             raise SystemExit(f"bench.py --gpus {world}: {bad} ghost-row cells differ from their owners' values after the timed "
                              f"batch of the {cols}x{rows} leg -- the strips did not exchange correctly; no line is printed for a broken run")
@@ -383,6 +392,8 @@ def parallelism_of(leg):
         s += (f", collective library {si['library']} reporting {si['comm_ranks']} ranks, halo overlap {'on' if si['halo_overlap'] else 'off'}, "
               f"maximum over the strips by {'peer-written mailboxes' if si['peer_max'] else 'all-reduce'}, ghost rows "
               f"{'stored into the neighbours by the strips themselves' if si['peer_halo'] else 'sent and received through the library'}")
+    if leg.get("exchange_fallback"):
+        s += f" [FALLBACK: {leg['exchange_fallback']}]"
     if world > 1 and os.environ.get("HIPIMS_MI_BACKEND", "nccl") != "nccl":
         s += " (REHEARSAL: gloo, host-staged exchange, shared GPU -- not a measurement)"
     return s
