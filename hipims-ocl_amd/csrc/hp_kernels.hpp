@@ -1257,6 +1257,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	advance_scalars(p, s1, p.dynamic_dt ? cfl_slot[BDY ? SLOT_M1 : SLOT_SAVED] : T(0));
 	const T dt_b = s1.dt;
 	const bool skip_a = dt_a <= T(0), skip_b = dt_b <= T(0);                       // CLSchemeGodunov.clc:201-206: the state is copied
+	// (FAST: -(dt / dx) and dt g of the two steps, formed once and moved to SCALAR register pairs -- an fp64 product has no scalar
+	// instruction, so left to the compiler they sit in eight vector registers for the whole march, which this kernel does not have:
+	// they were what it spilled and re-loaded from scratch in front of every friction term)
+	// (fp64 only: S-DAM 4096^2 0.1861 -> 0.1829 ms, S-ROUGH 0.246 -> 0.2397 on one box, no scratch left in the kernel; the fp32 kernels have
+	// the registers and lost 1.4 % with it -- profiles/r06af_scalar_step_constants_ab.txt)
+	constexpr bool SCALAR_CONSTS = !STRICT && sizeof(T) == 8;
+	const StepConsts<T> ka{uniform_value(-(dt_a * p.inv_dx)), uniform_value(dt_a * gravity<T>()), SCALAR_CONSTS};
+	const StepConsts<T> kb{uniform_value(-(dt_b * p.inv_dx)), uniform_value(dt_b * gravity<T>()), SCALAR_CONSTS};
 
 	// the wave's window: rows from y0 - 2 (as far as the grid goes), columns from the strip's first halo column
 	const long row_base = y0 - 2 < 0 ? 0 : y0 - 2, col_base = strip * MARCH2_COLS - 1 < 0 ? 0 : strip * MARCH2_COLS - 1;
@@ -1492,7 +1500,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 				}
 				const bool disabled = rc.c.zmax <= T(-9999.0) || rc.c.z == T(-9999.0); // :214-218
 				const bool dry5 = dryC && dryN && dryE && drySa && dryW;               // :248-255 (untouched: see PairAux)
-				const State4<T> upd = godunov_update<STRICT>(rc.c, rc.zb, rc.n, dt_a, fy.forL, fx.forL, fSa, fW, p.dx, inv_dx, vs, with_friction);
+				const State4<T> upd = godunov_update_impl<STRICT, false, true>(rc.c, rc.zb, rc.n, dt_a, fy.forL, fx.forL, fSa, fW, p.dx, inv_dx, vs, with_friction,
+				                                                               (T*)nullptr, NoProbe(), ka);
 				// (lanes 0 and 63 have no west / east neighbour of their own -- the rotate hands them a cell from the far end of the wavefront --
 				// and nothing reads what the first step makes of them except stage B's wave-wide votes: they keep their source state, a real
 				// cell of the row, instead of an update from a foreign flux that on a thin film drains them dry and sends every wavefront of
@@ -1607,7 +1616,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 						}
 					});
 				const State4<T> upd = godunov_update_impl<STRICT, false, true>(uc.c, uc.zb, n_c, dt_b, fy.forL, fx.forL, fSb, fW, p.dx, inv_dx, vs, with_friction,
-				                                                               (T*)nullptr, probe);
+				                                                               (T*)nullptr, probe, kb);
 				if (!disabled) {
 					if (dry5) {                                                        // the primary buffer keeps state k: copied in the cold pass below
 						write = false;

@@ -70,6 +70,12 @@ __device__ __forceinline__ float  floor_(float x)  { return __builtin_floorf(x);
 // pair ANDed with exec.  Same values; all active lanes vote, as with __all / __any.
 __device__ __forceinline__ bool wave_all(const bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 __device__ __forceinline__ bool wave_any(const bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+// a value every lane holds alike, moved to scalar registers (v_readfirstlane): vector instructions take it as a scalar operand
+__device__ __forceinline__ float uniform_value(const float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_value(const double v)
+{
+	return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // v_max_f64 / v_min_f64 WITHOUT the canonicalising v_max x, x, x the compiler puts in front of fmax / fmin whenever an operand
 // comes out of memory, a lane move or a select (it must assume a signalling NaN; the hardware instruction quiets one by itself).
@@ -608,16 +614,15 @@ __device__ __forceinline__ void friction(T& qx, T& qy, const T z, const T zb, co
 // (:52-65) is a clamp of fx at one -- no sign cases, no division by Q.  Cells the reference skips (h or Q below
 // VERY_SMALL, :36-37) take fx = 0, and a wavefront without an active cell skips the arithmetic (still water).
 template <typename T>
-__device__ __forceinline__ void friction_fast(T& qx, T& qy, const T z, const T zb, const T n, const T dt, const T vs)
+__device__ __forceinline__ void friction_fast(T& qx, T& qy, const T z, const T zb, const T n, const T dtg, const T vs)      // dtg = dt g
 {
-	const T g = gravity<T>();
 	const T h = z - zb;
 	const T q = sqrt_fast(fma_(qx, qx, qy * qy));
 	const bool active = !(h < vs || q < vs);
 	if (!wave_any(active)) return;
 	const T rc = rcbrt_fast(h);                              // h^(-1/3)
 	const T rc2 = rc * rc, rc4 = rc2 * rc2;
-	const T A = ((dt * g) * (n * n)) * (rc4 * rc2 * rc);     // dt g n^2 h^(-7/3)
+	const T A = (dtg * (n * n)) * (rc4 * rc2 * rc);          // dt g n^2 h^(-7/3)
 	const T qx2 = qx * qx, qy2 = qy * qy;                    // (recomputed here: two multiplications against two live registers)
 	const T aq2 = A * (qx2 + qy2);
 	const T denx = fma_(A, fma_(T(2), qx2, qy2), q), deny = fma_(A, fma_(T(2), qy2, qx2), q);
@@ -650,12 +655,15 @@ struct NoProbe {
 };
 template <typename W, typename H> struct Probe2 { W want; H hit; };
 template <typename W, typename H> __device__ __forceinline__ Probe2<W, H> make_probe(W w, H h) { return Probe2<W, H>{w, h}; }
+// lam = -(dt / dx), dtg = dt g: wave-uniform and the same on every row of a launch.  `given`: the kernel formed them once and holds them
+// in scalar registers (uniform_value); otherwise the update forms them itself and the compiler keeps them where it likes.
+template <typename T> struct StepConsts { T lam, dtg; bool given; };
 template <bool STRICT, bool CLAMP_FIRST, bool PLAIN, typename T, typename Probe = NoProbe>
 __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb, const T n, const T dt,
                                                          const FaceFlux<T>& fN, const FaceFlux<T>& fE,
                                                          const FaceFlux<T>& fS, const FaceFlux<T>& fW,
                                                          const T dx, const T inv_dx, const T vs, const bool with_friction, T* spec_word,
-                                                         const Probe& probe = Probe())
+                                                         const Probe& probe = Probe(), const StepConsts<T> pre = StepConsts<T>{T(0), T(0), false})
 {
 	bool bad = false;
 	const T g = gravity<T>();
@@ -708,7 +716,9 @@ __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb
 		spec_raise<PLAIN>(bad, spec_word);
 	} else {
 		T qx0 = c.qx, qy0 = c.qy;
-		const T lam = -(dt * inv_dx);
+		// (StepConsts: the two wave-uniform, row-invariant products of the step handed in as SCALAR register pairs by a kernel that has no
+		// vector registers to keep them in -- the pair kernel, round 6)
+		const T lam = pre.given ? pre.lam : -(dt * inv_dx);
 		const T z1 = fma_(lam, d0, c.z);
 		if (wave_any(stop || probe.want(c, z1))) {               // a stopping condition needs a dry side
 			asm volatile("");                                    // (a real branch: if-converted, its eight selects ran on every row)
@@ -718,7 +728,7 @@ __device__ __forceinline__ State4<T> godunov_update_impl(State4<T> c, const T zb
 		c.z = z1;
 		c.qx = fma_(lam, d2, qx0);
 		c.qy = fma_(lam, d3, qy0);
-		if (with_friction) friction_fast(c.qx, c.qy, c.z, zb, n, dt, vs);
+		if (with_friction) friction_fast(c.qx, c.qy, c.z, zb, n, pre.given ? pre.dtg : dt * g, vs);
 	}
 
 	if (CLAMP_FIRST) {                                               // mch_2nd_cacheNone order (MUSCL :791-796)
