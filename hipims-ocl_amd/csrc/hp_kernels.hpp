@@ -1263,8 +1263,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	// (fp64 only: S-DAM 4096^2 0.1861 -> 0.1829 ms, S-ROUGH 0.246 -> 0.2397 on one box, no scratch left in the kernel; the fp32 kernels have
 	// the registers and lost 1.4 % with it -- profiles/r06af_scalar_step_constants_ab.txt)
 	constexpr bool SCALAR_CONSTS = !STRICT && sizeof(T) == 8;
-	const StepConsts<T> ka{uniform_value(-(dt_a * p.inv_dx)), uniform_value(dt_a * gravity<T>()), SCALAR_CONSTS};
-	const StepConsts<T> kb{uniform_value(-(dt_b * p.inv_dx)), uniform_value(dt_b * gravity<T>()), SCALAR_CONSTS};
+	constexpr bool HIDE = BDY || HZ;                                               // (hp_math.hpp: uniform_value)
+	const StepConsts<T> ka{uniform_value<HIDE>(-(dt_a * p.inv_dx)), uniform_value<HIDE>(dt_a * gravity<T>()), SCALAR_CONSTS};
+	const StepConsts<T> kb{uniform_value<HIDE>(-(dt_b * p.inv_dx)), uniform_value<HIDE>(dt_b * gravity<T>()), SCALAR_CONSTS};
 
 	// the wave's window: rows from y0 - 2 (as far as the grid goes), columns from the strip's first halo column
 	const long row_base = y0 - 2 < 0 ? 0 : y0 - 2, col_base = strip * MARCH2_COLS - 1 < 0 ? 0 : strip * MARCH2_COLS - 1;

@@ -72,10 +72,18 @@ __device__ __forceinline__ bool wave_all(const bool p) { return __builtin_amdgcn
 __device__ __forceinline__ bool wave_any(const bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // a value every lane holds alike, moved to scalar registers (v_readfirstlane): vector instructions take it as a scalar operand
 __device__ __forceinline__ float uniform_value(const float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ double uniform_value(const double v)
+// HIDE: an empty statement in front hides where v comes from.  Without it the compiler moves the readfirstlane in front of a
+// multiplication by a constant (and drops it behind operands it knows to be uniform): the product is a vector instruction again and
+// sits in a pair of vector registers for the whole kernel -- harmless where there is room (the plain pair kernel measures 0.8 %
+// FASTER that way: fewer scalar spill moves in its loop), a spill with a scratch re-load in front of every friction term where not
+// (the pair kernels with area boundaries and with stamps: S-RAIN 4096^2 fp64 0.2676 -> 0.2544 ms, every pair exact on S-ROUGH
+// 0.2766 -> 0.2556: profiles/r06ag_opaque_uniform_value_ab.txt)
+template <bool HIDE = false> __device__ __forceinline__ double uniform_value(double v)
 {
+	if constexpr (HIDE) asm("" : "+v"(v));
 	return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+template <bool HIDE> __device__ __forceinline__ float uniform_value(const float v) { return uniform_value(v); }
 
 // v_max_f64 / v_min_f64 WITHOUT the canonicalising v_max x, x, x the compiler puts in front of fmax / fmin whenever an operand
 // comes out of memory, a lane move or a select (it must assume a signalling NaN; the hardware instruction quiets one by itself).
