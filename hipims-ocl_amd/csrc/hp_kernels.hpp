@@ -1257,11 +1257,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 	advance_scalars(p, s1, p.dynamic_dt ? cfl_slot[BDY ? SLOT_M1 : SLOT_SAVED] : T(0));
 	const T dt_b = s1.dt;
 	const bool skip_a = dt_a <= T(0), skip_b = dt_b <= T(0);                       // CLSchemeGodunov.clc:201-206: the state is copied
-	// (FAST: -(dt / dx) and dt g of the two steps, formed once and moved to SCALAR register pairs -- an fp64 product has no scalar
-	// instruction, so left to the compiler they sit in eight vector registers for the whole march, which this kernel does not have:
-	// they were what it spilled and re-loaded from scratch in front of every friction term)
-	// (fp64 only: S-DAM 4096^2 0.1861 -> 0.1829 ms, S-ROUGH 0.246 -> 0.2397 on one box, no scratch left in the kernel; the fp32 kernels have
-	// the registers and lost 1.4 % with it -- profiles/r06af_scalar_step_constants_ab.txt)
+	// (FAST fp64: -(dt / dx) and dt g of the two steps, formed once at the kernel's start and handed to the update instead of being formed
+	// there -- an fp64 product has no scalar instruction, so left alone they sit in eight vector registers for the whole march, which
+	// this kernel does not have: they were what it spilled and re-loaded from scratch in front of every friction term.  The plain kernel
+	// leaves the rest to the compiler (which keeps -(dt / dx) in scalar pairs and dt g in vector ones: S-DAM 4096^2 0.1861 -> 0.1829 ms,
+	// S-ROUGH 0.246 -> 0.2397 on one box, no scratch left; profiles/r06af_scalar_step_constants_ab.txt); the kernels with area
+	// boundaries or stamps force all four into scalar registers (uniform_value<HIDE>, hp_math.hpp: S-RAIN 0.2676 -> 0.2544 ms).
+	// fp32 has the registers and lost 1.4 % with it)
 	constexpr bool SCALAR_CONSTS = !STRICT && sizeof(T) == 8;
 	constexpr bool HIDE = BDY || HZ;                                               // (hp_math.hpp: uniform_value)
 	const StepConsts<T> ka{uniform_value<HIDE>(-(dt_a * p.inv_dx)), uniform_value<HIDE>(dt_a * gravity<T>()), SCALAR_CONSTS};
