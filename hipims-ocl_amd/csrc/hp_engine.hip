@@ -844,7 +844,8 @@ static bool pairs_possible_common(const hp_domain* d)
 	// (godunov_march2, BDY); single domains only.  HP_PAIR_BDY=0 keeps such domains on single iterations (A/B runs).
 	static const bool bdy_enabled = !(std::getenv("HP_PAIR_BDY") && std::atoi(std::getenv("HP_PAIR_BDY")) == 0);
 	// (fp32: from 30 M cells on -- S-RAIN 4096^2 fp32 LOSES 3 % in pairs, 0.1436 -> 0.1478 ms, where fp64 gains 7.5 % and 8192^2 gains 8-9 %
-	// in both precisions: profiles/r06w_srain_pairs_by_size.txt; HP_TWO_STEP=1 overrides)
+	// in both precisions: profiles/r06w_srain_pairs_by_size.txt; with five waves per SIMD, the final binary: level at 16.8 M and 25 M cells,
+	// +5 % at 37.7 M, +13 % at 67 M: profiles/r06ah_f32_bdy_pairs_by_size.txt; HP_TWO_STEP=1 overrides)
 	const bool bdy_size_ok = d->desc.precision == 8 || d->cells >= 30000000 || mode > 0;
 	const bool bdy_ok = d->bdy.empty() || (bdy_enabled && bdy_size_ok && d->fusable && !d->comm && d->comm_world <= 1 && d->desc.dynamic_dt);
 	// STRICT (round 6): the same statements in the same order as K1's, so the pair is the same computation there too -- always with
