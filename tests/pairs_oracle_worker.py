@@ -17,6 +17,7 @@ from hipims_mi import synthetic as syn  # noqa: E402
 case, precision, out = sys.argv[1:4]
 real = np.float64 if precision == "f64" else np.float32
 batches = None
+boundaries, dx = [], 1.0
 math_mode = hp.MATH_FAST
 if case.startswith("strict_"):              # the exact mode's pairs: held to the oracle BIT FOR BIT by the test
     case, math_mode = case[len("strict_"):], hp.MATH_STRICT
@@ -36,15 +37,45 @@ elif case == "default1500":                 # above the default's threshold (1.5
     cols, rows, n = 1500, 1100, 120
     st, bed, man = syn.s_rough(cols, rows, dtype=real, manning=None)
     batches = [61, 59]                      # an odd batch: a single iteration between the pairs, K1's FILL flag behind them
+elif case == "f9_uniform":                  # fixture F9 (the reference's kernels): uniform rain + a loss rate -- in PAIRS here, the exact flavour (a loss rate)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import load_golden
+    g = load_golden("f9_rain_f64")
+    rows, cols = g["bed"].shape
+    n = 420
+    st, bed, man = g["state"].astype(real), g["bed"].astype(real), g["manning"].astype(real)
+    boundaries = [("uniform", hp.UNIFORM_RAIN_INTENSITY, g["series"], 3600.0, 10800.0), ("uniform", hp.UNIFORM_LOSS_RATE, g["loss"], 10800.0, 10800.0)]
+elif case in ("rain1024", "rainloss1024", "bigdt1024", "bigdt700"):  # pairs WITH area boundaries (round 6: godunov_march2 BDY): pools on mostly dry rough
+    # terrain, uniform rain + gridded rain on rain cells 128 model cells wide (+ a loss rate: the exact flavour).  bigdt: 40 m cells and 608
+    # iterations -- the first 600 at the 0.1 s the reference holds the timestep to during the first minute (CLDynamicTimestep.clc:128-129),
+    # then eight with timesteps of up to 7.8 s from the reduction: the hydrological gate opens on every iteration and every pair prices its
+    # stored state with and without the next iteration's rain.  (No further: under such timesteps this film amplifies rounding tenfold
+    # every five iterations -- FAST and the oracle are 1e-3 m and 2 % in elapsed time apart after a hundred, while the STRICT engine stays
+    # the oracle bit for bit: tools/diag_bigdt.py)
+    cols, rows, n, dx = (1024, 1024, 250, 2.0) if not case.startswith("bigdt") else (1024, 1024, 608 if case == "bigdt1024" else 700, 40.0)
+    st, bed, man = syn.s_rough(cols, rows, dtype=np.float64, manning=None)
+    st[..., 0] = np.maximum(bed, st[..., 0] - 0.6); st[..., 1] = st[..., 0]; st[..., 2:] = 0
+    st[0] = st[-1] = 0; st[:, 0] = st[:, -1] = 0
+    st, bed, man = st.astype(real), bed.astype(real), man.astype(real)
+    grids = np.random.default_rng(5).uniform(0.0, 800.0, (4, rows // 128 + 2, cols // 128 + 2))
+    boundaries = [("uniform", hp.UNIFORM_RAIN_INTENSITY, np.array([[0.0, 600.0], [30.0, 200.0], [60.0, 0.0], [90.0, 0.0]]), 30.0, 90.0),
+                  ("gridded", hp.GRIDDED_RAIN_INTENSITY, grids, 128 * dx, 0.0, 0.0, 11.0)]
+    if case != "rain1024":
+        boundaries.append(("uniform", hp.UNIFORM_LOSS_RATE, np.array([[0.0, 900.0], [1000.0, 900.0]]), 1000.0, 1000.0))
 else:
     raise SystemExit(case)
 
-ref = oracle.OracleSim(cols, rows, precision=precision, threads=min(16, os.cpu_count() or 1))
+ref = oracle.OracleSim(cols, rows, dx=dx, precision=precision, threads=min(16, os.cpu_count() or 1))
 ref.upload(st, bed, man)
+dom = hp.Domain(cols, rows, dx=dx, precision=precision, math_mode=math_mode)
+dom.upload(st, bed, man)
+for b in boundaries:
+    for sim in (ref, dom):
+        (sim.add_uniform if b[0] == "uniform" else sim.add_gridded)(*b[1:])
+if boundaries:
+    assert dom.boundaries_fused()
 ref.set_target(1e9)
 ref.run(n)
-dom = hp.Domain(cols, rows, precision=precision, math_mode=math_mode)
-dom.upload(st, bed, man)
 dom.set_target_time(1e9)
 for b in (batches or [n]):
     dom.step_batch(b)

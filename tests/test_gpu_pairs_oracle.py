@@ -89,6 +89,61 @@ def test_strict_pair_kernel_is_the_oracle_bit_for_bit(case, tmp_path):
         assert np.array_equal(d["got"], load_golden("f6_f7_trajectories_f64")["god_q_state200"])
 
 
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["rain1024", "rainloss1024", "bigdt1024"])
+def test_pair_kernel_with_area_boundaries_against_the_oracle(case, precision, tmp_path):
+    """godunov_march2 with area boundaries (round 6: the second iteration's rain in registers between the two steps, the state stored
+    with the next iteration's, priced both ways) against the ORACLE -- tests/test_gpu_two_step.py holds such pairs to single
+    iterations, which is a self-comparison.  1024^2 at 2 m, pools on mostly dry rough terrain, uniform rain + gridded rain on rain
+    cells 128 model cells wide, 250 iterations as pair launches; with a loss rate on top the engine takes the exact flavour (stamps);
+    bigdt1024: 40 m cells, 608 iterations -- past the first minute (the reference holds the timestep at 0.1 s until then) the timestep
+    comes out of the reduction at up to 7.8 s, so the hydrological gate opens on every iteration and the elapsed time depends on
+    every pair having priced its stored state WITH the next iteration's rain (eight such iterations: the film amplifies rounding
+    tenfold every five of them, see the worker).  north_star's FAST bars.
+    Reference: Boundaries/CLBoundaries.clc:130-246, the hydrological gate CLDynamicTimestep.clc:61-66."""
+    if case == "bigdt1024" and precision == "f32":
+        pytest.skip("fp32 rounding under 7-second timesteps on this film is 5e-3 in elapsed time after eight iterations (measured): not a parity case")
+    d = run(case, precision, tmp_path)
+    assert int(d["launches"]) < 0.62 * int(d["iterations"]), (int(d["launches"]), int(d["iterations"]))
+    rmse, mx = depth_errors(d["got"], d["want"], d["bed"])
+    t_rel = abs(float(d["t"]) - float(d["t_ref"])) / float(d["t_ref"])
+    record("pairs_with_boundaries_vs_oracle", workload=case, precision=precision, rmse=rmse, max=mx, time_rel=t_rel,
+           launches=int(d["launches"]), iterations=int(d["iterations"]))
+    wet = np.maximum(0, d["want"][..., 0].astype(np.float64) - d["bed"])
+    assert (wet > 1e-4).mean() > 0.3                      # the rain has wetted the terrain: the comparison is not of dry land
+    if precision == "f64":
+        assert rmse < 1e-9 and mx < 1e-7, (rmse, mx)
+        assert t_rel <= 1e-12, t_rel
+    else:
+        assert rmse < 1e-4 and t_rel <= 1e-4, (rmse, t_rel)
+    if case == "bigdt1024":
+        assert float(d["t"]) > 80.0                            # eight iterations took the run from t = 60 s past 80 s: timesteps far beyond a second
+    assert int(d["ok"]) == int(d["ok_ref"])
+
+
+def test_strict_engine_is_the_oracle_through_the_regime_that_amplifies_rounding(tmp_path):
+    """The same 40-m film for 700 iterations -- a hundred of them at timesteps of up to 7.8 s, where FAST arithmetic and the oracle end
+    1e-3 m and 2 % in elapsed time apart (rounding grows tenfold every five iterations: tools/diag_bigdt.py) -- in the exact mode:
+    every bit of the state, the time and the timestep (single iterations with the boundaries fused into the flux kernel: the exact
+    mode does not pair under area boundaries)."""
+    d = run("strict_bigdt700", "f64", tmp_path, two_step=None)
+    assert np.array_equal(d["got"], d["want"])
+    assert float(d["t"]) == float(d["t_ref"]) and float(d["dt"]) == float(d["dt_ref"]) and float(d["t"]) > 500.0
+
+
+def test_pair_kernel_with_rain_and_loss_against_the_reference_kernel_fixture(tmp_path):
+    """Fixture F9's uniform rain + loss rate (tests/golden/generate.py: the reference's own kernels, 420 iterations) run in PAIRS
+    (exact flavour: a loss rate dries whole regions at once): the bars of test_gpu_parity's single-iteration test of the same fixture."""
+    d = run("f9_uniform", "f64", tmp_path)
+    assert int(d["launches"]) < 0.62 * int(d["iterations"])
+    check(d, "f64", "f9_uniform")
+    g = load_golden("f9_rain_f64")
+    rmse, mx = depth_errors(d["got"], g["uniform_state"], d["bed"])
+    record("pairs_vs_fixture_f9", workload="f9_uniform", precision="f64", rmse=rmse, max=mx)
+    assert rmse < 1e-9 and mx < 1e-7, (rmse, mx)
+    assert abs(float(d["t"]) - float(g["uniform_t"])) < 1e-9
+
+
 def test_default_selection_against_the_oracle(tmp_path):
     """No HP_TWO_STEP in the environment: 1500 x 1100 lies above the default's threshold, so the selection logic itself
     (hp_domain_create: march2_pays, the one-round tiling search) is what chooses godunov_march2 here; two batches of odd length put
