@@ -1965,9 +1965,13 @@ int spec_begin(hp_domain* d)
 // choice is free -- and workload dependent: rows of still water are a copy in STRICT (K1's skip) which a pair makes at half the bytes
 // (S-DAM 4096^2: 0.299 -> 0.265 ms per iteration), while water that moves everywhere is bound by instruction issue, where the pair's two
 // extra first-step rows per tile and its narrower wavefronts cost 13 % (S-ROUGH: 0.60 -> 0.68 ms; profiles/r06h_strict_pairs.txt).  So the
-// engine measures: every 512 iterations two pairs and four single iterations are bracketed by events on the domain's stream
-// (nothing blocks: the events are looked at when a later batch call finds them complete) and the faster flavour runs until the next sample.
-// HP_PAIR_TUNE=0: always pairs where eligible.
+// engine measures: every 128 iterations two pairs and four single iterations are bracketed by events on the domain's stream
+// (nothing blocks: the events are looked at every sixteen iterations of the batch loop and when a batch starts -- a host that queues far
+// ahead of the device sees them complete at the next batch call) and the faster flavour runs until the next sample.
+// (Round 6, late: the period was 512 and the events were only looked at when a batch STARTED -- on a developing S-DAM flood the crossover
+// lies near iteration 1000 and the engine ran pairs until the sample of iteration 1750, 9 % behind single iterations all the while;
+// now, in batches of 250, it switches in the batch that contains the crossover: tools/strict_tuner_probe.py, profiles/r06ak_*.  A sample costs one copy of the state and six iterations in the slower flavour: 0.1-0.2 % at this period.)
+// HP_PAIR_TUNE=0: always pairs where eligible; HP_PAIR_TUNE_PERIOD=n: iterations between samples.
 static bool tuner_on(const hp_domain* d)
 {
 	static const bool enabled = !(std::getenv("HP_PAIR_TUNE") && std::atoi(std::getenv("HP_PAIR_TUNE")) == 0);
@@ -1985,7 +1989,8 @@ static int tuner_poll(hp_domain* d)
 		d->tune_pair_ms = pair_ms; d->tune_single_ms = single_ms;
 		d->tune_samples++;
 		d->tune_phase = 2;
-		d->tune_next = d->iterations + 512;
+		static const uint64_t period = std::getenv("HP_PAIR_TUNE_PERIOD") ? (uint64_t)std::max(12L, std::atol(std::getenv("HP_PAIR_TUNE_PERIOD"))) : 128;
+		d->tune_next = d->iterations + period;
 	}
 	if (d->tune_phase == 2 && d->iterations >= d->tune_next) d->tune_phase = 0;
 	return HP_OK;
@@ -2008,6 +2013,7 @@ int run_iterations(hp_domain* d, uint32_t n_iterations)
 	const bool tune = tuner_on(d);
 	if (tune && (rc = tuner_poll(d)) != HP_OK) return rc;
 	for (uint32_t i = 0; i < n_iterations; ++i) {
+		if (tune && d->tune_phase != 0 && (i & 15u) == 15u && (rc = tuner_poll(d)) != HP_OK) return rc;   // (two event queries: host time, behind the queue)
 		// (STRICT) a sample: three pairs, then six single iterations -- the first pair and the first two single iterations warm the
 		// kernel's code and are not timed, the rest are bracketed by events
 		if (tune && d->tune_phase == 0 && i + 12 <= n_iterations && !d->rings_differ && pair_eligible(d)) {
