@@ -2888,15 +2888,18 @@ int hp_pair_stats(hp_domain_t* d, uint64_t out[12])
 		out[8] = used;
 	}
 	if (!d->z_state) return HP_OK;
-	const size_t rec = (size_t)4 * d->esize + 16;
-	std::vector<char> recs(d->cells * rec);
-	HIP_TRY(hipMemcpyAsync(recs.data(), d->z_state, recs.size(), hipMemcpyDeviceToHost, d->stream));
+	// (counted on the device: the records are 48 bytes a cell)
+	unsigned long long* counts = d->haz_words + 4;                        // (words 4 and 5 of the 64-byte block: 0-1 the launches' words, 2 the audit)
+	HIP_TRY(hipMemsetAsync(counts, 0, 16, d->stream));
+	if (d->desc.precision == 8)
+		hipLaunchKernelGGL((stamps_count<double>), dim3(1024), dim3(256), 0, d->stream, StampBufs<double>{(char*)d->z_state, d->haz_words}, d->pair_gen, d->cells, counts);
+	else
+		hipLaunchKernelGGL((stamps_count<float>), dim3(1024), dim3(256), 0, d->stream, StampBufs<float>{(char*)d->z_state, d->haz_words}, d->pair_gen, d->cells, counts);
+	HIP_TRY(hipGetLastError());
+	unsigned long long host_counts[2] = {0, 0};
+	HIP_TRY(hipMemcpyAsync(host_counts, counts, sizeof host_counts, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
-	for (size_t i = 0; i < d->cells; ++i) {
-		unsigned g;
-		std::memcpy(&g, recs.data() + i * rec + 4 * d->esize, sizeof g);
-		out[2] += (g != 0 && g == d->pair_gen); out[3] += (g != 0);
-	}
+	out[2] = host_counts[0]; out[3] = host_counts[1];
 	return HP_OK;
 }
 

@@ -1744,6 +1744,20 @@ __global__ __launch_bounds__(256) void stamps_to_buffer(State4<T>* __restrict__ 
 		if (stamp_gen(b, id) == gen) other[id] = stamp_state(b, id);
 }
 
+// hp_pair_stats: cells stamped by launch `gen` (counts[0]) and cells that carry any launch's stamp (counts[1]) -- counted where the records
+// are (they are 48 bytes a cell: a copy to the host idles the device for tens of milliseconds on a large grid)
+template <typename T>
+__global__ __launch_bounds__(256) void stamps_count(const StampBufs<T> b, const unsigned gen, const size_t cells, unsigned long long* counts)
+{
+	unsigned long long last = 0, any = 0;
+	for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < cells; id += (size_t)gridDim.x * blockDim.x) {
+		const unsigned g = stamp_gen(b, id);
+		last += (g != 0 && g == gen); any += (g != 0);
+	}
+	for (int off = 32; off > 0; off >>= 1) { last += __shfl_down(last, off); any += __shfl_down(any, off); }
+	if ((threadIdx.x & 63) == 0 && (last | any)) { atomicAdd(counts, last); atomicAdd(counts + 1, any); }
+}
+
 // Cold start of iteration pairs on a domain with area boundaries (hp_engine.hip: pair_cold_start): the stand-alone boundary pass and the
 // stand-alone reduction have just done the first half of iteration k the reference's way -- boundaries in place, the primary buffer
 // priced -- and this moves the result to where the pair kernel looks for it.

@@ -359,7 +359,8 @@ int hp_kernel_timing_overhead(hp_domain_t* d, double* overhead_ms);
  * by an advance launch).  bench.py states its roofline basis from the difference of two readings around the timed region. */
 int hp_launch_counts(hp_domain_t* d, uint64_t* flux_launches, uint64_t* with_tail);
 
-/* Diagnostics of the iteration pairs, for tests and A/B runs; blocks.  out[0] iteration pairs run, out[1] pairs that started cold on a
+/* Diagnostics of the iteration pairs, for tests and A/B runs; blocks (a stream synchronisation; the stamps are counted by a small kernel,
+ * nothing of their size is copied).  out[0] iteration pairs run, out[1] pairs that started cold on a
  * domain with area boundaries (stand-alone boundary pass + reduction in front: after single iterations, an upload, a new target
  * time), out[2] cells stamped by the LAST pair launch, out[3] cells that carry a stamp of any launch; the exact mode's choice between
  * pairs and single iterations (the same bits; chosen by measurement, hp_engine.hip: tuner_poll): out[4] samples taken, out[5] changes
