@@ -522,6 +522,9 @@ __device__ __forceinline__ float buf_load_scalar(__amdgpu_buffer_rsrc_t r, const
 // words values of their own first: defined by an (empty) asm, they have no other copy the fence could be fed from, so keeping them
 // alive to the fence means keeping the store's registers.  The build's assembly is scanned for the pattern on every build
 // (tests/test_resource_usage.py): a store whose data or offset register is written inside the window fails the CPU suite.
+#ifndef HP_K1B_STRICT_WAVES
+#define HP_K1B_STRICT_WAVES 2        // waves per SIMD of the exact mode's fp64 pair kernel (3: 168 registers, spills -- see LAB_NOTES R6.6)
+#endif
 #ifndef HP_STORE_OPERANDS_OWN
 #define HP_STORE_OPERANDS_OWN 1         // 0: round 5's stores (the study of LAB_NOTES R6.x builds both)
 #endif
@@ -1222,7 +1225,7 @@ template <bool STRICT, int CFL_MODE, bool BDY, bool HZ, int TAIL, typename T>   
 #define HP_K1B_F32_WAVES_MAX 5
 #endif
 // (the exact flavour, HZ, keeps round 5's four: at five its fp32 instantiations spill 20-70 vector registers)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (STRICT ? 3 : (HZ ? 4 : HP_K1B_F32_WAVES_MIN)) : (STRICT ? 2 : HP_K1B_WAVES_MIN), sizeof(T) == 4 ? (STRICT ? 3 : HP_K1B_F32_WAVES_MAX) : (STRICT ? 2 : 3)))) void godunov_march2(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (STRICT ? 3 : (HZ ? 4 : HP_K1B_F32_WAVES_MIN)) : (STRICT ? HP_K1B_STRICT_WAVES : HP_K1B_WAVES_MIN), sizeof(T) == 4 ? (STRICT ? 3 : HP_K1B_F32_WAVES_MAX) : (STRICT ? HP_K1B_STRICT_WAVES : 3)))) void godunov_march2(
 	const Params<T> p, const Scalars<T>* sc, const T* __restrict__ bed, const State4<T>* __restrict__ src,
 	State4<T>* __restrict__ dst, const T* __restrict__ manning, T* cfl_slot, const T* __restrict__ edge_max,
 	const TileMap tm, const LaunchTail<T> tail, const PairAux<T> aux)
