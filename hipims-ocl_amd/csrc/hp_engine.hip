@@ -1570,7 +1570,7 @@ int hp_domain_upload(hp_domain_t* d, int which, const void* host, size_t bytes)
 		HIP_TRY(hipMemcpyAsync(d->state[1], host, bytes, hipMemcpyHostToDevice, d->stream));
 		d->other_stale = false;
 		d->rings_differ = false;
-		if (d->tune_phase == 2) d->tune_phase = 0;
+		d->tune_phase = 0;                                                // (a sample still in flight measured the state that has just been replaced)
 		d->use_alt = 0;                                                   // :1075
 		d->need_full_reduce = true;
 		d->edge_dirty = true;
@@ -1663,7 +1663,10 @@ int hp_state_restore(hp_domain_t* d)
 	d->rings_differ = d->saved_rings_differ;
 	d->rings_checked = false;
 	d->m1_valid = d->saved_m1_valid;                                      // (slot[SLOT_M1] has come back with the slot block)
-	if (d->tune_phase == 2) d->tune_phase = 0;                            // (another state: the exact mode's pairs-or-singles choice is measured anew)
+	d->tune_phase = 0;                                                    // (another state: the exact mode's pairs-or-singles choice is measured anew -- a sample
+	                                                                      // still in flight measured the state that is being replaced: with samples every 128
+	                                                                      // iterations bench.py's restore found one in flight nearly every time and the timed
+	                                                                      // region ran on a choice made for the pre-warmed flood)
 	d->pair_fused_next = false;                                           // (a checkpoint is taken between batches: nothing fused is in the buffer)
 	d->ghost_valid = d->saved_ghost_valid;
 	// a bed or state upload between save and restore has left its own marks: they stay

@@ -123,6 +123,35 @@ def test_the_exact_mode_chooses_between_pairs_and_single_iterations_by_measureme
     print(f"{scenario}: pair / two single iterations = {float(t['pair_over_single']):.3f}, prefers pairs: {bool(t['prefers_pairs'])}, launches {int(t['launches'])} of {int(t['iterations'])}")
 
 
+def test_a_restore_discards_the_sample_in_flight(tmp_path):
+    """The measurement belongs to the state it was taken on: hp_state_restore (and an upload) start it anew even when a sample is still
+    in flight -- bench.py restores its checkpoint right behind a pre-warm phase whose last batch had taken one, and the timed region
+    then ran on a choice made for the pre-warmed flood (the strict leg fell from 0.63 to 0.55 when samples became frequent enough
+    for that to happen nearly every time).  A batch of sixteen iterations from a fresh state that samples is twelve flux launches (two
+    single iterations until the reduction is current, the sample's three pairs and six single iterations, one pair); one that does
+    not is nine."""
+    code = f"""
+import sys; sys.path[:0] = [{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hipims-ocl_amd")!r}]
+import numpy as np, hipims_mi as hp
+from hipims_mi import synthetic as syn
+st, bed, man = syn.s_dam(2048, 1500, dtype=np.float64)
+dom = hp.Domain(2048, 1500, math_mode=hp.MATH_STRICT)
+dom.upload(st, bed, man); dom.set_target_time(1e9)
+dom.state_save()
+counts = []
+for k in range(3):
+    c0 = dom.launch_counts()[0]; dom.step_batch(16); counts.append(dom.launch_counts()[0] - c0)   # (no synchronisation: the sample is in flight)
+    dom.state_restore()
+dom.read_scalars()
+print("LAUNCHES", counts)
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("HP_TWO_STEP", "HP_PAIR_TUNE", "HP_PAIR_STRICT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("LAUNCHES")][-1]
+    assert line == "LAUNCHES [12, 12, 12]", line
+
+
 @pytest.mark.parametrize("scenario", ["rough", "damdry"])
 def test_exact_pairs_without_boundaries(scenario, tmp_path):
     """HP_PAIR_EXACT=1 on domains without boundary conditions (where the default leaves the stamps out, for speed): the same bits as the
