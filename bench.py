@@ -468,8 +468,8 @@ def main():
         strict_args = args
         if args.math == "fast" and not args.no_strict_leg:
             # (the exact mode chooses between iteration pairs and single iterations by measurement -- the same bits either way -- from
-            # a sample of twelve iterations every 512, taken anew after a state restore: at least 24 warm-up steps keep that sample
-            # out of a short timed region, where it would stand for 60 % of the steps instead of 2 %)
+            # a sample of twelve iterations every 128, taken anew after a state restore: at least 24 warm-up steps keep that sample
+            # out of a short timed region, where it would stand for 60 % of the steps instead of 9 %)
             strict_args = variant(args, warmup=max(args.warmup, 24))
             strict_leg = run_leg(strict_args, hp, cols, rows, 1, 0, local_rank, "strict", repeats=1)
         c3_legs, c5_leg = {}, None
