@@ -42,6 +42,8 @@ for seed in range(first, first + count):
     # flux, alone or together, with series short enough to change slice inside a run (pairs with boundaries: godunov_march2 BDY)
     strict = rng.random() < 0.2
     with_bdy = rng.random() < 0.45
+    if os.environ.get("FUZZ_STRICT_TUNER"):              # (tools/r06_tuner_soak.sh: every seed in the exact mode without boundaries -- the tuner's ground)
+        strict, with_bdy = True, False
     if with_bdy and "dt_fixed" in kw:
         kw.pop("dynamic_dt"); kw.pop("dt_fixed")
     dom = hp.Domain(cols, rows, precision=precision, math_mode=hp.MATH_STRICT if strict else hp.MATH_FAST, **kw)
@@ -65,7 +67,7 @@ for seed in range(first, first + count):
         if dump:
             trace.append((int(op), dom.read_scalars(), dom.download()))
         if op <= 4:
-            dom.step_batch(int(rng.integers(1, 40)))
+            dom.step_batch(int(rng.integers(1, 40)) + (16 if os.environ.get("FUZZ_STRICT_TUNER") else 0))   # (a sample wants a batch of fourteen iterations and more)
         elif op == 5:
             a = dom.download()
             blown = blown or not np.isfinite(a).all()
